@@ -1,0 +1,128 @@
+"""CPU oracle vs golden vectors produced by the reference itself.
+
+The f64 build of the oracle must reproduce the reference (float64 numpy) to <= 1e-12 relative
+(+1e-13 absolute for near-cancelling quantities); the f32 build -- what the HIP kernel is compared
+with -- must stay within 1e-6 relative + small absolute single-step error.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as po
+import golden_util as gu
+
+SCENARIOS = gu.scenario_names()
+
+
+def test_constants_match_reference():
+    """G1: URDF scalars + derived constants (envs/agents.py:138-156)."""
+    with open(os.path.join(gu.GOLDEN, "constants.json")) as f:
+        ref = json.load(f)
+    k = po.constants()
+    for name, v in k.items():
+        assert v == pytest.approx(ref[name], rel=1e-15, abs=0), name
+    for task in ("hover", "circle", "takeoff"):
+        for label, noise in (("noise_free", -1), ("noisy", 1)):
+            env = po.OracleEnv(task, observation_noise=noise)
+            assert env.obs_dim == ref["obs_dim"][task][label]
+    e = po.OracleEnv("hover")
+    assert e.get("A")[0] == pytest.approx(ref["A0"], rel=1e-15)
+    assert e.get("B")[0] == pytest.approx(ref["B0"], rel=1e-15)
+    assert e.get("K")[0] == pytest.approx(ref["K0"], rel=1e-15)
+
+
+def test_reference_tables():
+    """Circle / TakeOff reference trajectories (circle.py:45-56, takeoff.py:43-47) are recomputed
+    analytically by the oracle's update_target."""
+    with open(os.path.join(gu.GOLDEN, "constants.json")) as f:
+        ref = json.load(f)
+    circ = np.array(ref["circle_ref"])
+    e = po.OracleEnv("circle", observation_noise=-1)
+    import ctypes as C
+    o = (C.c_double * 24)()
+    for t in range(300):
+        e.set("iteration", t)
+        e.set("ref_offset", 0)
+        e.L.po_compute_observation_f64(C.byref(e.cfg), C.byref(e.env), None, o)
+        np.testing.assert_allclose(e.get("target_pos"), circ[t], rtol=0, atol=1e-16)
+    zt = np.array(ref["takeoff_ref_z"])
+    e = po.OracleEnv("takeoff", observation_noise=-1)
+    for t in (0, 1, 17, 298, 299, 300, 450):
+        e.set("iteration", t)
+        e.L.po_compute_observation_f64(C.byref(e.cfg), C.byref(e.env), None, o)
+        assert e.get("target_pos")[2] == zt[min(t, 299)]
+
+
+def test_quaternion_convention():
+    """pybullet boundary: order [x,y,z,w], ZYX (reference tests/test_quaternion.py:35-43 and
+    envs/utils.py:32-56), plus an independent scipy cross-check of all three restated functions."""
+    from scipy.spatial.transform import Rotation
+    d = np.load(os.path.join(gu.GOLDEN, "quaternion.npz"))
+    for rpy, q in zip(d["rpy"], d["quat"]):
+        qo = po.quat_from_euler(rpy)
+        np.testing.assert_allclose(qo, q, rtol=0, atol=3e-16)
+        # round trip of the reference test: Euler(Q(rpy)) == rpy for |angles| < pi/2 in pitch
+        if abs(rpy[1]) < 1.5:
+            np.testing.assert_allclose(po.euler_from_quat(qo), rpy, rtol=0, atol=1e-13)
+        rot = Rotation.from_euler("xyz", rpy)
+        np.testing.assert_allclose(po.matrix_from_quat(qo), rot.as_matrix(), rtol=0, atol=1e-15)
+        qs = rot.as_quat()
+        qs = qs if np.dot(qs, qo) > 0 else -qs
+        np.testing.assert_allclose(qo, qs, rtol=0, atol=1e-15)
+
+
+def test_ground_effect_formula():
+    """G7: BasePhysics.calculate_ground_effect (envs/physics.py:27-58)."""
+    d = np.load(os.path.join(gu.GOLDEN, "ground_effect.npz"))
+    import ctypes as C
+    e = po.OracleEnv("takeoff", observation_noise=-1)
+    for xyz, rpy, f, ge in zip(d["xyz"], d["rpy"], d["forces"], d["ge"]):
+        e.set("xyz", xyz)
+        e.set("rpy", rpy)
+        e.set("quat", po.quat_from_euler(rpy))
+        out = (C.c_double * 4)()
+        e.L.po_ground_effect_f64(C.byref(e.env), (C.c_double * 4)(*f), out)
+        np.testing.assert_allclose(np.array(out), ge, rtol=1e-12, atol=1e-18)
+
+
+def _replay(name, precision, rtol, atol, resync):
+    g = gu.Golden(name)
+    env = gu.make_oracle(g, precision)
+    assert env.obs_dim == g.D
+    for ep in range(g.E):
+        obs = gu.begin_episode(env, g, ep)
+        gu.assert_close(obs, g["reset_obs"][ep], rtol, atol, f"{name} ep{ep} reset obs")
+        for k in gu.DYN_FIELDS + ["x", "last_action", "dt", "m", "J", "ftf0", "ftf1", "A", "B", "K", "lpf", "gyro_bias"]:
+            gu.assert_close(env.get(k), g["reset_" + k][ep], rtol, atol, f"{name} ep{ep} reset {k}")
+        assert env.get("ref_offset") == g["reset_ref_offset"][ep]
+        for t in range(g.n_valid(ep)):
+            if resync and t > 0:
+                # single-step parity: restart every step from the reference's recorded state
+                for k in gu.DYN_FIELDS + ["x", "last_action", "env_last_action", "act_hist", "obs_hist", "ou", "gyro_bias", "lpf", "kf_state"]:
+                    env.set(k, g["step_" + k][ep, t - 1])
+            obs, r, term, trunc, cost = env.step(g["actions"][ep, t])
+            w = f"{name} ep{ep} t{t}"
+            gu.assert_close(obs, g["obs"][ep, t], rtol, atol, w + " obs")
+            gu.assert_close(r, g["reward"][ep, t], rtol, atol * 10, w + " reward")
+            for k in gu.DYN_FIELDS + ["x", "ou", "gyro_bias", "lpf"]:
+                gu.assert_close(env.get(k), g["step_" + k][ep, t], rtol, atol, w + " " + k)
+            assert term == bool(g["terminated"][ep, t]), w
+            assert trunc == bool(g["truncated"][ep, t]), w
+            assert cost == g["cost"][ep, t], w
+            assert env.get("iteration") == g["step_iteration"][ep, t]
+
+
+@pytest.mark.parametrize("name", SCENARIOS)
+def test_oracle_f64_matches_reference(name):
+    """Whole recorded trajectories (no re-synchronisation): float64 oracle == reference."""
+    _replay(name, "f64", rtol=1e-12, atol=1e-13, resync=False)
+
+
+@pytest.mark.parametrize("name", SCENARIOS)
+def test_oracle_f32_single_step(name):
+    """float32 oracle, re-synchronised to the reference state before every step: 1e-6 relative
+    (north_star tolerance) + 2e-6 absolute for near-cancelling terms (yaw torque, tau_x/tau_y at
+    equal thrusts integrate into rpy_dot with 1/J ~ 6e4 gain)."""
+    _replay(name, "f32", rtol=1e-6, atol=2e-6, resync=True)
