@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of the fused HIP step on DroneHoverSimpleEnv-v0, 2^20 envs per GPU.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the
+driver launches it under torch.distributed.run (one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+
+A "step" is one lockstep pds_step over all envs of the rank (auto-reset ON, so TimeLimit truncations,
+terminations and in-kernel Philox resets are inside the timed region).  Inputs (the action ring)
+are resident in HBM before the timed region.  Envs shard across ranks with no data-path collective
+(weak scaling: 2^20 envs per GPU); `--allgather-obs` adds the optional RCCL all-gather of the
+observations for the single-policy layout.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(task, kw, target_seconds=12.0):
+    """Time the CPU oracle (C restatement, float32, OpenMP over envs) on a bounded sample of the
+    same workload: N_cpu envs, same action recipe, auto-reset on.  Reported baseline only."""
+    import numpy as np
+    from oracle import oracle as po
+    n_cpu = 65536
+    threads = po.lib().po_max_threads()
+    orc = po.OracleBatch(task, n_cpu, precision="f32", nthreads=threads, **kw)
+    orc.reset(0, 0)
+    rs = np.random.RandomState(0)
+    hover = -1.0 + 2.0 / 2.25
+    acts = (hover + 0.1 * rs.standard_normal((8, n_cpu, 4))).astype(np.float32)
+    t0 = time.perf_counter()
+    orc.step(acts[0], seed=0, tick=1)
+    one = time.perf_counter() - t0
+    steps = int(max(4, min(2000, target_seconds / max(one, 1e-4))))
+    t0 = time.perf_counter()
+    for s in range(steps):
+        orc.step(acts[s % 8], seed=0, tick=2 + s)
+    dt = time.perf_counter() - t0
+    return {"value": n_cpu * steps / dt, "unit": "env-steps/s", "cores": int(threads), "kind": "port",
+            "sample": f"oracle/phoenix_oracle.c float32 + OpenMP, {n_cpu} envs x {steps} steps "
+                      f"({dt:.1f} s), same Hover config and action recipe, auto-reset on"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--envs-per-gpu", type=int, default=1 << 20)
+    ap.add_argument("--task", default="hover", choices=["hover", "circle", "takeoff"])
+    ap.add_argument("--config", type=int, default=0,
+                    help="0: north-star headline (Hover 2^20/GPU); 2/3/4: BASELINE.json configs[1..3]")
+    ap.add_argument("--allgather-obs", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import phoenix_drone_simulation_amd as pds
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    task = args.task
+    n = args.envs_per_gpu
+    kw = dict(observation_noise=-1, domain_randomization=-1, motor_thrust_noise=0)
+    act_center_shift = 0.0
+    if args.config == 2:
+        task, n = "hover", 65536
+    elif args.config == 3:
+        task, n = "circle", 262144
+        kw.update(use_motor_dynamics=True, domain_randomization=0.10)
+    elif args.config == 4:
+        task, n = "takeoff", 1 << 20
+        kw.update(use_ground_effect=True)
+        act_center_shift = 0.2
+    env_id = {"hover": "DroneHoverSimpleEnv-v0", "circle": "DroneCircleSimpleEnv-v0",
+              "takeoff": "DroneTakeOffSimpleEnv-v0"}[task]
+    env = pds.make(env_id, num_envs=n, device=dev, seed=0, env_id_base=rank * n, **kw)
+
+    # action ring generated once ([T, N, 4], a = HOVER_ACTION + 0.1 N(0,1)), reused cyclically
+    T = 64
+    g = torch.Generator(device=dev)
+    g.manual_seed(rank)
+    hover = -1.0 + 2.0 / 2.25
+    ring = (hover + act_center_shift) + 0.1 * torch.randn(T, n, 4, generator=g, device=dev, dtype=torch.float32)
+    gathered = torch.empty(world * n, env.obs_dim, device=dev) if (args.allgather_obs and world > 1) else None
+
+    def one_step(s):
+        out = env.step(ring[s % T])
+        if gathered is not None:
+            dist.all_gather_into_tensor(gathered, out[0])
+        return out
+
+    env.reset()
+    for s in range(args.warmup):
+        one_step(s)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    sync()
+    t0 = time.perf_counter()
+    ev0.record()  # same stream pds_step launches on (torch's current stream)
+    for s in range(args.steps):
+        one_step(args.warmup + s)
+    ev1.record()
+    sync()
+    wall = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # average launch-to-launch duration on the stream
+    if world > 1:
+        t = torch.tensor([wall], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+
+    total_envs = n * world
+    value = total_envs * args.steps / wall
+    bytes_per = env.bytes_per_env_step
+    achieved = n * bytes_per / (kernel_ms * 1e-3) / 1e9
+    if rank == 0:
+        line = {
+            "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{env_id}, {n} envs per GPU lockstep, fp32, observation noise off, "
+                                   f"domain randomisation {kw['domain_randomization']}, auto-reset on, "
+                                   f"action ring [64,N,4] = hover{act_center_shift:+.1f} + 0.1*N(0,1)"
+                                   + (", RCCL all-gather of obs" if gathered is not None else ""),
+                       "envs_per_gpu": n, "obs_dim": env.obs_dim, "bytes_per_env_step": bytes_per,
+                       "parallelism": f"env-shard x{world}, no data-path collective" if gathered is None
+                       else f"env-shard x{world} + all-gather(obs)"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "pds::step_kernel", "avg_launch_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": n * bytes_per},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                line["cpu_baseline"] = cpu_baseline(task, {k: (int(v) if isinstance(v, bool) else v) for k, v in kw.items()})
+            except Exception as e:  # the baseline is reported, never required for the GPU number
+                line["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port",
+                                        "sample": f"failed: {e}"}
+        print(json.dumps(line))
+    env.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

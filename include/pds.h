@@ -1,0 +1,169 @@
+/*
+ * pds.h -- C ABI of libpds_hip.so, the MI355X (gfx950) batched CrazyFlie SimplePhysics stepper.
+ *
+ * Drop-in boundary for ONE hot path of SvenGronauer/phoenix-drone-simulation: the per-env
+ * `env.reset()` / `env.step(action)` loop of DroneHoverSimpleEnv-v0, DroneCircleSimpleEnv-v0 and
+ * DroneTakeOffSimpleEnv-v0, replaced by a lockstep step over N independent environments whose state
+ * lives SoA in HBM.  Reference interfaces each entry point replaces (paths relative to
+ * phoenix_drone_simulation/ in the reference):
+ *
+ *   pds_default_config / pds_create  <- gym.make(id, **kwargs) -> DroneBaseEnv.__init__
+ *                                       (envs/base.py:26-153, envs/hover.py:7-63, envs/circle.py:7-77,
+ *                                        envs/takeoff.py:13-70, ids in __init__.py:8-50)
+ *   pds_reset                        <- DroneBaseEnv.reset (envs/base.py:382-431) incl.
+ *                                       task_specific_reset (hover.py:192-243, circle.py:213-277,
+ *                                       takeoff.py:179-212) and apply_domain_randomization
+ *                                       (base.py:239-296)
+ *   pds_reset_from_samples           <- same, with the np.random draws supplied by the caller
+ *                                       (parity injection; the reference draws from the global
+ *                                       numpy stream)
+ *   pds_step                         <- DroneBaseEnv.step (envs/base.py:433-475) =
+ *                                       SimplePhysics.step_forward (envs/physics.py:130-200) +
+ *                                       CrazyFlieAgent.apply_action (envs/agents.py:259-298) +
+ *                                       compute_history/reward/info/done + TimeLimit truncation
+ *   pds_get_state / pds_set_state    <- direct attribute access env.drone.{xyz,rpy,xyz_dot,rpy_dot,x,
+ *                                       last_action,...} used by simopt/ and debug/ callers
+ *   pds_destroy                      <- env.close()
+ *
+ * All pointers named `d_*` are DEVICE pointers on the handle's device; tensors are row-major fp32.
+ * Every entry point returns 0 on success or a negative PDS_E* code; pds_last_error() gives the text.
+ * Launches are asynchronous on the caller's stream (`stream` is a hipStream_t passed as void*).
+ * A handle is not thread-safe; different handles are independent; there is no global state.
+ * There is NO CPU fallback: without a HIP device pds_create fails with PDS_ENODEVICE.
+ */
+#ifndef PDS_H
+#define PDS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDS_VERSION 1
+
+#define PDS_TASK_HOVER 0   /* DroneHoverSimpleEnv-v0   */
+#define PDS_TASK_CIRCLE 1  /* DroneCircleSimpleEnv-v0  */
+#define PDS_TASK_TAKEOFF 2 /* DroneTakeOffSimpleEnv-v0 */
+
+#define PDS_OK 0
+#define PDS_EINVAL -1
+#define PDS_ENODEVICE -2
+#define PDS_EHIP -3
+#define PDS_ENOMEM -4
+#define PDS_EUNSUPPORTED -5
+
+/* Mirror of the reference's env kwargs on this path (same names, same defaults). */
+typedef struct pds_config {
+  int32_t struct_size; /* = sizeof(pds_config), set by pds_default_config */
+  int32_t task;
+  int64_t num_envs;    /* N envs stepped in lockstep on this device */
+  int64_t env_id_base; /* global id of local env 0 (multi-GPU sharding; keys the in-kernel RNG) */
+  uint64_t seed;
+  int32_t device;                    /* HIP device ordinal */
+  int32_t use_motor_dynamics;        /* first-order motor model, envs/agents.py:284-288; default 0 */
+  int32_t use_ground_effect;         /* envs/physics.py:27-58 formula as opt-in; default 0 */
+  int32_t observation_noise;         /* >0: SensorNoise path; reference default 1 */
+  int32_t aggregate_phy_steps;       /* default 1 for the *Simple envs */
+  int32_t enable_reset_distribution; /* default 1 */
+  int32_t max_episode_steps;         /* TimeLimit, default 500 */
+  int32_t auto_reset;                /* 1: envs that terminate/truncate are reset inside pds_step */
+  double domain_randomization;       /* default 0.10; <=0 disables */
+  double motor_thrust_noise;         /* default 0.05; OU sigma = 0.2*value */
+  double time_step;                  /* 1/sim_freq = 0.01 */
+  double motor_time_constant;        /* 0.080 s */
+  double penalty_action, penalty_angle, penalty_spin, penalty_terminal, penalty_velocity, ARP;
+  double target_pos[3];
+  double init_xyz[3], init_rpy[3], init_xyz_dot[3], init_rpy_dot[3];
+} pds_config;
+
+typedef struct pds_handle pds_handle;
+
+/* State fields for pds_get_state / pds_set_state: [N, width] row-major, fp32 unless noted. */
+enum pds_field {
+  PDS_F_POS = 0,         /* 3  drone.xyz */
+  PDS_F_RPY = 1,         /* 3  drone.rpy */
+  PDS_F_VEL = 2,         /* 3  drone.xyz_dot */
+  PDS_F_OMEGA = 3,       /* 3  drone.rpy_dot (body rates) */
+  PDS_F_QUAT = 4,        /* 4  drone.quaternion (derived: sign * Q(rpy); read-only) */
+  PDS_F_MOTOR_X = 5,     /* 4  drone.x */
+  PDS_F_LAST_ACTION = 6, /* 4  u(k-1): drone.last_action == action_history[-1] */
+  PDS_F_PREV_ACTION = 7, /* 4  u(k-2): action_history[-2] */
+  PDS_F_STEP_COUNT = 8,  /* 1  int32: env.step calls since reset (iteration / aggregate_phy_steps) */
+  PDS_F_QUAT_SIGN = 9,   /* 1  int32 0/1: quaternion == -Q(rpy) (only right after reset) */
+  PDS_F_REF_OFFSET = 10, /* 1  int32: Circle ref_offset */
+  PDS_F_PARAMS = 11,     /* 6  dt, m, Jxx, Jyy, Jzz, force_torque_factor_1 */
+  PDS_F_MOTOR_A = 12,    /* 4  drone.A (B = 1 - A) */
+  PDS_F_MOTOR_K = 13,    /* 4  drone.K */
+  PDS_F_OU = 14,         /* 4  thrust_noise.state */
+  PDS_F_GYRO_BIAS = 15,  /* 3  sensor_noise.gyro_bias */
+  PDS_F_GYRO_LPF = 16,   /* 3  gyro_lpf._x */
+  PDS_F_COUNT_ = 17
+};
+
+/* Layout of one row of `d_samples` for pds_reset_from_samples (the values np.random returned in
+ * the reference's draw order; see oracle/phoenix_oracle.h po_reset_sample). */
+#define PDS_SAMPLE_FLOATS 36
+#define PDS_S_POS_OFFSET 0 /* 3 */
+#define PDS_S_RPY 3        /* 3 */
+#define PDS_S_VEL 6        /* 3 */
+#define PDS_S_OMEGA 9      /* 3 */
+#define PDS_S_MOTOR_X 12   /* 4 */
+#define PDS_S_ACTION 16    /* 4 */
+#define PDS_S_DR_DT 20
+#define PDS_S_DR_M 21
+#define PDS_S_DR_J 22      /* 3 */
+#define PDS_S_DR_FTF0 25
+#define PDS_S_DR_FTF1 26
+#define PDS_S_DR_T 27      /* 4 */
+#define PDS_S_DR_T2W 31    /* 4 */
+#define PDS_S_REF_OFFSET 35
+
+int pds_version(void);
+
+/* Fill `cfg` with the reference ctor defaults of `task` (N = 1, device 0, auto_reset = 1). */
+int pds_default_config(int task, pds_config *cfg);
+
+/* Allocate the SoA state for cfg->num_envs envs on cfg->device.  State is undefined until the first
+ * pds_reset*.  *out receives the handle. */
+int pds_create(const pds_config *cfg, pds_handle **out);
+int pds_destroy(pds_handle *h);
+
+/* Observation width D = 2 * (|o| + 4): 42/40/48 noise-free, 34/40/48 with observation_noise. */
+int pds_obs_dim(const pds_handle *h);
+int64_t pds_num_envs(const pds_handle *h);
+
+/* Reset the envs with d_mask[i] != 0 (d_mask == NULL: all) from the in-kernel Philox stream keyed by
+ * (seed, env_id_base + i, reset tick); writes the reset observation [o0,u0,o0,u0] into d_obs rows of
+ * the reset envs (d_obs: [N, D]). */
+int pds_reset(pds_handle *h, const uint8_t *d_mask, float *d_obs, void *stream);
+
+/* Same, with the sampled values supplied per env: d_samples [N, PDS_SAMPLE_FLOATS]. */
+int pds_reset_from_samples(pds_handle *h, const uint8_t *d_mask, const float *d_samples,
+                           float *d_obs, void *stream);
+
+/* One lockstep env.step() for all N envs.
+ *   d_actions   [N,4] in      d_obs        [N,D] out (reset obs for envs auto-reset in this step)
+ *   d_reward    [N]   out     d_terminated [N] u8 out      d_truncated [N] u8 out
+ *   d_cost      [N]   out (info['cost'])
+ *   d_final_obs [N,D] or NULL: rows of envs that finished in this step receive their last obs. */
+int pds_step(pds_handle *h, const float *d_actions, float *d_obs, float *d_reward,
+             uint8_t *d_terminated, uint8_t *d_truncated, float *d_cost, float *d_final_obs,
+             void *stream);
+
+int pds_field_width(int field);
+int pds_get_state(pds_handle *h, int field, void *d_out, void *stream);
+int pds_set_state(pds_handle *h, int field, const void *d_in, void *stream);
+
+/* Number of reset/step ticks issued so far (the Philox counter word). */
+uint64_t pds_tick(const pds_handle *h);
+
+/* Algorithmic HBM bytes one pds_step moves per env for this configuration. */
+int pds_bytes_per_env_step(const pds_handle *h);
+
+const char *pds_last_error(const pds_handle *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PDS_H */

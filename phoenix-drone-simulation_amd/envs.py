@@ -1,0 +1,297 @@
+"""Batched `*SimpleEnv-v0` environments with the reference's gymnasium reset()/step() surface.
+
+Mirrors (same ids, kwarg names, defaults, observation layout, reward/termination/cost semantics):
+  DroneBaseEnv            phoenix_drone_simulation/envs/base.py:23-475
+  DroneHoverSimpleEnv     phoenix_drone_simulation/envs/hover.py:253-266
+  DroneCircleSimpleEnv    phoenix_drone_simulation/envs/circle.py:286-299
+  DroneTakeOffSimpleEnv   phoenix_drone_simulation/envs/takeoff.py:221-231
+  registration            phoenix_drone_simulation/__init__.py:8-50 (max_episode_steps=500)
+
+Differences that follow from batching (documented in INTEGRATION.md):
+  * `num_envs` environments advance in lockstep; tensors live on the HIP device:
+      actions [N,4] f32 -> obs [N,D] f32, reward [N] f32, terminated [N] bool, truncated [N] bool,
+      info = {'cost': [N] f32, 'final_obs': [N,D] f32 (rows valid where terminated|truncated)}
+  * the 500-step TimeLimit of the gymnasium registration is part of the env (`truncated`), and envs
+    that finish are reset inside the same step (`auto_reset=True`) from a counter-based Philox
+    stream keyed by (seed, global env id, tick) -- the reference draws from the global numpy stream.
+All computation happens in libpds_hip.so (HIP, gfx950); there is no CPU path here.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import native
+
+try:  # gymnasium is optional (absent in the build image); spaces are duck-typed otherwise
+    from gymnasium.spaces import Box as _GymBox
+except Exception:  # pragma: no cover
+    _GymBox = None
+
+
+class Box:
+    """Minimal stand-in for gymnasium.spaces.Box (shape/low/high/dtype/sample/contains)."""
+
+    def __init__(self, low, high, dtype=np.float32):
+        self.low = np.asarray(low, dtype=dtype)
+        self.high = np.asarray(high, dtype=dtype)
+        self.shape = self.low.shape
+        self.dtype = np.dtype(dtype)
+
+    def sample(self):
+        return np.random.uniform(self.low, self.high).astype(self.dtype)
+
+    def contains(self, x):
+        x = np.asarray(x)
+        return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))
+
+    def __repr__(self):
+        return f"Box({self.low.min()}, {self.high.max()}, {self.shape}, {self.dtype})"
+
+
+def _box(low, high):
+    if _GymBox is not None:
+        return _GymBox(low, high, dtype=np.float32)
+    return Box(low, high, dtype=np.float32)
+
+
+_TASKS = {"hover": native.TASK_HOVER, "circle": native.TASK_CIRCLE, "takeoff": native.TASK_TAKEOFF}
+
+
+class DroneVecEnv:
+    """N CrazyFlie SimplePhysics environments stepped in lockstep on one MI355X.
+
+    Keyword arguments are the reference's (envs/base.py:26-48, envs/hover.py:7-24); additional ones:
+    num_envs, device, seed, env_id_base (global id of local env 0 for multi-GPU sharding),
+    auto_reset, use_motor_dynamics (agents.py:284-288 branch), use_ground_effect
+    (physics.py:27-58 formula as opt-in extension), init_xyz / init_rpy / init_xyz_dot / init_rpy_dot
+    (the env.init_* attributes of envs/base.py:84-91).
+    """
+    metadata = {'render.modes': []}
+    task = None
+
+    def __init__(self, num_envs=1, device=None, seed=0, env_id_base=0, auto_reset=True,
+                 use_motor_dynamics=False, use_ground_effect=False,
+                 init_xyz=None, init_rpy=None, init_xyz_dot=None, init_rpy_dot=None,
+                 # --- reference kwargs ---
+                 aggregate_phy_steps=1, control_mode='PWM', observation_noise=1,
+                 domain_randomization=0.10, target_pos=(0., 0., 1.0), penalty_action=1e-4,
+                 penalty_angle=0., penalty_spin=None, penalty_terminal=100., penalty_velocity=None,
+                 enable_reset_distribution=True, latency=0.015, motor_time_constant=0.080,
+                 motor_thrust_noise=0.05, observation_frequency=100, observation_history_size=2,
+                 render_mode=None, debug=False, max_episode_steps=500):
+        if control_mode != 'PWM':
+            raise NotImplementedError(f"control_mode={control_mode!r}: only 'PWM' is on the accelerated path")
+        if observation_history_size != 2:
+            raise NotImplementedError("observation_history_size != 2 is not on the accelerated path")
+        if render_mode not in (None, 'rgb_array'):
+            raise NotImplementedError("rendering is out of scope (no Bullet world on this path)")
+        if int(aggregate_phy_steps) < 1:
+            raise AssertionError("aggregate_phy_steps >= 1")  # envs/base.py:104
+        if not torch.cuda.is_available():
+            raise RuntimeError("phoenix-drone-simulation_amd needs a HIP device (MI355X); there is no CPU fallback")
+        self.lib = native.load()
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError(f"device {dev} is not a HIP device")
+        self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+        cfg = native.default_config(_TASKS[self.task])
+        cfg.num_envs = int(num_envs)
+        cfg.env_id_base = int(env_id_base)
+        cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        cfg.device = self.device.index
+        cfg.use_motor_dynamics = int(bool(use_motor_dynamics))
+        cfg.use_ground_effect = int(bool(use_ground_effect))
+        cfg.observation_noise = 1 if observation_noise > 0 else 0
+        cfg.aggregate_phy_steps = int(aggregate_phy_steps)
+        cfg.enable_reset_distribution = int(bool(enable_reset_distribution))
+        cfg.max_episode_steps = int(max_episode_steps)
+        cfg.auto_reset = int(bool(auto_reset))
+        cfg.domain_randomization = float(domain_randomization)
+        cfg.motor_thrust_noise = float(motor_thrust_noise)
+        cfg.motor_time_constant = float(motor_time_constant)
+        cfg.penalty_action = float(penalty_action)
+        cfg.penalty_angle = float(penalty_angle)
+        if penalty_spin is not None:
+            cfg.penalty_spin = float(penalty_spin)
+        cfg.penalty_terminal = float(penalty_terminal)
+        if penalty_velocity is not None:
+            cfg.penalty_velocity = float(penalty_velocity)
+        for i in range(3):
+            cfg.target_pos[i] = float(target_pos[i])
+        # env.init_* attributes (envs/base.py:84-91) are mutated by simopt-style callers
+        # (simopt/pybullet.py:233-248); here they are ctor kwargs
+        for name, val in (("init_xyz", init_xyz), ("init_rpy", init_rpy),
+                          ("init_xyz_dot", init_xyz_dot), ("init_rpy_dot", init_rpy_dot)):
+            if val is not None:
+                for i in range(3):
+                    getattr(cfg, name)[i] = float(val[i])
+        self.cfg = cfg
+        self.num_envs = int(num_envs)
+        self.domain_randomization = float(domain_randomization)
+        self.observation_noise = observation_noise
+        self.enable_reset_distribution = bool(enable_reset_distribution)
+        self.aggregate_phy_steps = int(aggregate_phy_steps)
+        self._max_episode_steps = int(max_episode_steps)
+        self.render_mode = render_mode
+        self.debug = debug
+        self._handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = self.lib.pds_create(C.byref(cfg), C.byref(self._handle))
+        native.check(None, rc, "pds_create")
+        self.obs_dim = self.lib.pds_obs_dim(self._handle)
+        self.act_dim = 4
+        o_lim = 1000 * np.ones((self.obs_dim,), dtype=np.float32)  # envs/base.py:147-150
+        a_lim = np.ones((self.act_dim,), dtype=np.float32)
+        self.observation_space = self.single_observation_space = _box(-o_lim, o_lim)
+        self.action_space = self.single_action_space = _box(-a_lim, a_lim)
+        N, D = self.num_envs, self.obs_dim
+        f32 = dict(dtype=torch.float32, device=self.device)
+        # two output sets so that `o` and `next_o` of a rollout loop can be alive together
+        self._bufs = [dict(obs=torch.zeros(N, D, **f32), reward=torch.zeros(N, **f32),
+                           cost=torch.zeros(N, **f32),
+                           terminated=torch.zeros(N, dtype=torch.uint8, device=self.device),
+                           truncated=torch.zeros(N, dtype=torch.uint8, device=self.device),
+                           final_obs=torch.zeros(N, D, **f32)) for _ in range(2)]
+        self._flip = 0
+
+    # ------------------------------------------------------------------ gymnasium surface ----
+    @property
+    def unwrapped(self):
+        return self
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _next_buf(self):
+        self._flip ^= 1
+        return self._bufs[self._flip]
+
+    def reset(self, *, seed=None, options=None, mask=None):
+        """Reset all envs (or those with mask != 0).  Like the reference (envs/base.py:382-431),
+        `seed` and `options` are accepted and ignored: randomness is keyed by the ctor `seed`."""
+        b = self._next_buf()
+        m = None
+        if mask is not None:
+            m = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            b["obs"].copy_(self._bufs[self._flip ^ 1]["obs"])
+        rc = self.lib.pds_reset(self._handle, C.c_void_p(m.data_ptr()) if m is not None else None,
+                                C.c_void_p(b["obs"].data_ptr()), self._stream())
+        native.check(self._handle, rc, "pds_reset")
+        return b["obs"], {}
+
+    def reset_from_samples(self, samples, mask=None):
+        """Reset with caller-supplied draws: `samples` [N, 36] (layout native.SAMPLE_LAYOUT)."""
+        s = torch.as_tensor(samples, dtype=torch.float32, device=self.device).contiguous()
+        assert s.shape == (self.num_envs, native.SAMPLE_FLOATS)
+        b = self._next_buf()
+        m = None
+        if mask is not None:
+            m = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        rc = self.lib.pds_reset_from_samples(
+            self._handle, C.c_void_p(m.data_ptr()) if m is not None else None,
+            C.c_void_p(s.data_ptr()), C.c_void_p(b["obs"].data_ptr()), self._stream())
+        native.check(self._handle, rc, "pds_reset_from_samples")
+        return b["obs"], {}
+
+    def step(self, action):
+        a = action
+        if not (isinstance(a, torch.Tensor) and a.dtype == torch.float32 and a.device == self.device and a.is_contiguous()):
+            a = torch.as_tensor(np.asarray(action) if not isinstance(action, torch.Tensor) else action,
+                                dtype=torch.float32).to(self.device).contiguous()
+        if a.shape != (self.num_envs, 4):
+            raise ValueError(f"actions must have shape ({self.num_envs}, 4), got {tuple(a.shape)}")
+        b = self._next_buf()
+        rc = self.lib.pds_step(
+            self._handle, C.c_void_p(a.data_ptr()), C.c_void_p(b["obs"].data_ptr()),
+            C.c_void_p(b["reward"].data_ptr()), C.c_void_p(b["terminated"].data_ptr()),
+            C.c_void_p(b["truncated"].data_ptr()), C.c_void_p(b["cost"].data_ptr()),
+            C.c_void_p(b["final_obs"].data_ptr()), self._stream())
+        native.check(self._handle, rc, "pds_step")
+        info = {"cost": b["cost"], "final_obs": b["final_obs"]}
+        return b["obs"], b["reward"], b["terminated"].view(torch.bool), b["truncated"].view(torch.bool), info
+
+    def close(self):
+        if getattr(self, "_handle", None) is not None and self._handle:
+            self.lib.pds_destroy(self._handle)
+            self._handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render(self):
+        if self.render_mode == "rgb_array":
+            return np.array([])  # envs/base.py:377
+        raise NotImplementedError
+
+    # ------------------------------------------------------------------ state access ---------
+    def get_state(self, name):
+        fid = native.FIELDS[name]
+        w = self.lib.pds_field_width(fid)
+        dt = torch.int32 if name in native.INT_FIELDS else torch.float32
+        out = torch.zeros(self.num_envs, w, dtype=dt, device=self.device)
+        rc = self.lib.pds_get_state(self._handle, fid, C.c_void_p(out.data_ptr()), self._stream())
+        native.check(self._handle, rc, f"pds_get_state({name})")
+        return out
+
+    def set_state(self, name, value):
+        fid = native.FIELDS[name]
+        w = self.lib.pds_field_width(fid)
+        dt = torch.int32 if name in native.INT_FIELDS else torch.float32
+        v = torch.as_tensor(value).to(device=self.device, dtype=dt).reshape(self.num_envs, w).contiguous()
+        rc = self.lib.pds_set_state(self._handle, fid, C.c_void_p(v.data_ptr()), self._stream())
+        native.check(self._handle, rc, f"pds_set_state({name})")
+        torch.cuda.current_stream(self.device).synchronize()  # `v` may be a temporary
+
+    @property
+    def bytes_per_env_step(self):
+        return self.lib.pds_bytes_per_env_step(self._handle)
+
+    @property
+    def tick(self):
+        return int(self.lib.pds_tick(self._handle))
+
+
+class DroneHoverSimpleEnv(DroneVecEnv):
+    """envs/hover.py:253-266 (penalty_spin 1e-4, penalty_velocity 0, ARP 0)."""
+    task = "hover"
+
+
+class DroneCircleSimpleEnv(DroneVecEnv):
+    """envs/circle.py:286-299 (penalty_spin 1e-3, penalty_velocity 1e-4, ARP 1e-3)."""
+    task = "circle"
+
+
+class DroneTakeOffSimpleEnv(DroneVecEnv):
+    """envs/takeoff.py:221-231."""
+    task = "takeoff"
+
+    def __init__(self, **kwargs):
+        if kwargs.get("aggregate_phy_steps", 1) != 1:
+            raise TypeError("DroneTakeOffSimpleEnv fixes aggregate_phy_steps=1 (envs/takeoff.py:224)")
+        super().__init__(**kwargs)
+
+
+registry = {}
+
+
+def register(id, entry_point, max_episode_steps=500):
+    registry[id] = (entry_point, max_episode_steps)
+
+
+# phoenix_drone_simulation/__init__.py:8-50 (the Bullet ids are out of scope)
+register('DroneHoverSimpleEnv-v0', DroneHoverSimpleEnv, 500)
+register('DroneCircleSimpleEnv-v0', DroneCircleSimpleEnv, 500)
+register('DroneTakeOffSimpleEnv-v0', DroneTakeOffSimpleEnv, 500)
+
+
+def make(id, **kwargs):
+    """Counterpart of gym.make(id, **kwargs) (algs/iwpg/iwpg.py:72-75) returning a batched env."""
+    if id not in registry:
+        raise KeyError(f"unknown env id {id!r}; accelerated ids: {sorted(registry)}")
+    cls, max_steps = registry[id]
+    kwargs.setdefault("max_episode_steps", max_steps)
+    return cls(**kwargs)

@@ -1,0 +1,98 @@
+"""ctypes binding of the C ABI declared in include/pds.h (libpds_hip.so).
+
+The library is REQUIRED: importing works without it, but any attempt to create an environment
+raises -- there is no CPU or PyTorch fallback on the product path.
+"""
+import ctypes as C
+import os
+
+from .build import library_path
+
+TASK_HOVER, TASK_CIRCLE, TASK_TAKEOFF = 0, 1, 2
+OK, EINVAL, ENODEVICE, EHIP, ENOMEM, EUNSUPPORTED = 0, -1, -2, -3, -4, -5
+SAMPLE_FLOATS = 36
+# field ids (enum pds_field)
+FIELDS = dict(pos=0, rpy=1, vel=2, omega=3, quat=4, motor_x=5, last_action=6, prev_action=7,
+              step_count=8, quat_sign=9, ref_offset=10, params=11, motor_A=12, motor_K=13, ou=14,
+              gyro_bias=15, gyro_lpf=16)
+INT_FIELDS = ("step_count", "quat_sign", "ref_offset")
+# sample row offsets (PDS_S_*)
+SAMPLE_LAYOUT = dict(pos_offset=(0, 3), rpy=(3, 3), vel=(6, 3), omega=(9, 3), motor_x=(12, 4),
+                     action=(16, 4), dr_dt=(20, 1), dr_m=(21, 1), dr_J=(22, 3), dr_ftf0=(25, 1),
+                     dr_ftf1=(26, 1), dr_T=(27, 4), dr_t2w=(31, 4), ref_offset=(35, 1))
+
+EXPORTS = ["pds_version", "pds_default_config", "pds_create", "pds_destroy", "pds_obs_dim",
+           "pds_num_envs", "pds_reset", "pds_reset_from_samples", "pds_step", "pds_field_width",
+           "pds_get_state", "pds_set_state", "pds_tick", "pds_bytes_per_env_step", "pds_last_error"]
+
+
+class Config(C.Structure):
+    """struct pds_config (include/pds.h)."""
+    _fields_ = [
+        ("struct_size", C.c_int32), ("task", C.c_int32), ("num_envs", C.c_int64),
+        ("env_id_base", C.c_int64), ("seed", C.c_uint64),
+        ("device", C.c_int32), ("use_motor_dynamics", C.c_int32), ("use_ground_effect", C.c_int32),
+        ("observation_noise", C.c_int32), ("aggregate_phy_steps", C.c_int32),
+        ("enable_reset_distribution", C.c_int32), ("max_episode_steps", C.c_int32),
+        ("auto_reset", C.c_int32),
+        ("domain_randomization", C.c_double), ("motor_thrust_noise", C.c_double),
+        ("time_step", C.c_double), ("motor_time_constant", C.c_double),
+        ("penalty_action", C.c_double), ("penalty_angle", C.c_double), ("penalty_spin", C.c_double),
+        ("penalty_terminal", C.c_double), ("penalty_velocity", C.c_double), ("ARP", C.c_double),
+        ("target_pos", C.c_double * 3), ("init_xyz", C.c_double * 3), ("init_rpy", C.c_double * 3),
+        ("init_xyz_dot", C.c_double * 3), ("init_rpy_dot", C.c_double * 3),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """dlopen libpds_hip.so (built by build.build_library / __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). The HIP extension is required; there is no fallback path.")
+    lib = C.CDLL(path)
+    vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
+    lib.pds_version.restype = i32
+    lib.pds_default_config.argtypes = [i32, C.POINTER(Config)]
+    lib.pds_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    lib.pds_destroy.argtypes = [vp]
+    lib.pds_obs_dim.argtypes = [vp]
+    lib.pds_num_envs.argtypes = [vp]
+    lib.pds_num_envs.restype = i64
+    lib.pds_reset.argtypes = [vp, vp, vp, vp]
+    lib.pds_reset_from_samples.argtypes = [vp, vp, vp, vp, vp]
+    lib.pds_step.argtypes = [vp] + [vp] * 8
+    lib.pds_field_width.argtypes = [i32]
+    lib.pds_get_state.argtypes = [vp, i32, vp, vp]
+    lib.pds_set_state.argtypes = [vp, i32, vp, vp]
+    lib.pds_tick.argtypes = [vp]
+    lib.pds_tick.restype = C.c_uint64
+    lib.pds_bytes_per_env_step.argtypes = [vp]
+    lib.pds_last_error.argtypes = [vp]
+    lib.pds_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def default_config(task):
+    cfg = Config()
+    rc = load().pds_default_config(int(task), C.byref(cfg))
+    if rc != OK:
+        raise ValueError(f"pds_default_config({task}) -> {rc}")
+    return cfg
+
+
+def check(handle, rc, what):
+    if rc == OK:
+        return
+    msg = load().pds_last_error(handle)
+    msg = msg.decode() if msg else ""
+    exc = {EINVAL: ValueError, EUNSUPPORTED: NotImplementedError, ENOMEM: MemoryError}.get(rc, RuntimeError)
+    raise exc(f"{what} failed ({rc}): {msg}")
