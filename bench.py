@@ -37,7 +37,7 @@ def cpu_baseline(task, kw, target_seconds=12.0):
     t0 = time.perf_counter()
     orc.step(acts[0], seed=0, tick=1)
     one = time.perf_counter() - t0
-    steps = int(max(4, min(2000, target_seconds / max(one, 1e-4))))
+    steps = int(max(4, min(20000, target_seconds / max(one, 1e-4))))
     t0 = time.perf_counter()
     for s in range(steps):
         orc.step(acts[s % 8], seed=0, tick=2 + s)

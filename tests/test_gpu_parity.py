@@ -201,7 +201,9 @@ def test_lockstep_autoreset_vs_f32_oracle(task, kw):
     orc = po.OracleBatch(task, N, precision="f32", max_episode_steps=7, **okw)
     obs, _ = env.reset()
     oobs = orc.reset(seed, 0)
-    gu.assert_close(obs.cpu().numpy(), oobs, 2e-6, 2e-6, "reset obs")
+    # GPU f32 (FMA, ocml sincos) vs CPU f32 (libm): each within ~1e-6 of the f64 reference (the golden
+    # tests above), so they may differ from each other by a few 1e-6 on |omega| ~ 3 rad/s
+    gu.assert_close(obs.cpu().numpy(), oobs, 1e-5, 1e-5, "reset obs")
     rs = np.random.RandomState(0)
     bad = 0
     for t in range(T):
