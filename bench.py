@@ -58,6 +58,7 @@ def main():
                     help="0: north-star headline (Hover 2^20/GPU); 2/3/4: BASELINE.json configs[1..3]")
     ap.add_argument("--allgather-obs", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-auto-reset", action="store_true", help="diagnostic only: INVALID as a benchmark number")
     args = ap.parse_args()
 
     import torch
@@ -89,7 +90,8 @@ def main():
         act_center_shift = 0.2
     env_id = {"hover": "DroneHoverSimpleEnv-v0", "circle": "DroneCircleSimpleEnv-v0",
               "takeoff": "DroneTakeOffSimpleEnv-v0"}[task]
-    env = pds.make(env_id, num_envs=n, device=dev, seed=0, env_id_base=rank * n, **kw)
+    env = pds.make(env_id, num_envs=n, device=dev, seed=0, env_id_base=rank * n,
+                   auto_reset=not args.no_auto_reset, **kw)
 
     # action ring generated once ([T, N, 4], a = HOVER_ACTION + 0.1 N(0,1)), reused cyclically
     T = 64

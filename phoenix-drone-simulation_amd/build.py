@@ -11,7 +11,8 @@ _LIB = os.path.join(_HERE, "libpds_hip.so")
 
 
 def library_path():
-    return _LIB
+    # PDS_LIB: A/B-test another build of the same sources (profiling only)
+    return os.environ.get("PDS_LIB", _LIB)
 
 
 def _stale():

@@ -27,6 +27,8 @@ namespace pds {
 
 constexpr int kBlock = 256;  // 4 waves; each wave owns a private LDS tile (no block barrier needed)
 constexpr int kWave = 64;
+constexpr int kQueueCap = 128;   // deferred-reset queue entries per wave (LDS)
+constexpr int kBlocksPerCU = 3;  // 160 KiB LDS / (256 x 48 x 4 B + circle table)
 constexpr int kRefPoints = 300;  // envs/circle.py:48, envs/takeoff.py:43
 
 // ---- packing of the per-env counter word --------------------------------------------------------
@@ -274,13 +276,25 @@ PDS_DEV void reset_env(const Consts &k, const float2 *ref_lds, const Sample &s, 
   e.wx = R[0] * a0 + R[3] * a1 + R[6] * a2;
   e.wy = R[1] * a0 + R[4] * a1 + R[7] * a2;
   e.wz = R[2] * a0 + R[5] * a1 + R[8] * a2;
-  euler_from_quat(q, e.roll, e.pitch, e.yaw);
   e.px = px; e.py = py; e.pz = pz; e.vx = vx; e.vy = vy; e.vz = vz;
-  // the quaternion keeps the sign of Q(sampled rpy) until the first step; the state stores the
-  // wrapped Euler angles, so remember whether Q(wrapped) has the opposite sign
-  const Quat qw = quat_from_euler(e.roll, e.pitch, e.yaw);
-  const float dotp = qw.x * q.x + qw.y * q.y + qw.z * q.z + qw.w * q.w;
-  ctr = ctr_pack(0u, dotp < 0.f ? 1u : 0u, (uint32_t)ref_offset);
+  // rpy = Euler(quat) (envs/agents.py:446).  The quaternion keeps the sign of Q(sampled rpy) until
+  // the first step while the state stores the wrapped Euler angles, so remember whether Q(wrapped)
+  // has the opposite sign.
+  uint32_t sign;
+  if (fabsf(r0) < 1.55f && fabsf(r1) < 1.55f) {
+    // every sampled attitude lands here: roll/pitch inside the principal range, so
+    // Euler(Q(r,p,y)) == (r, p, y - 2 pi k) and Q flips sign once per 2 pi of yaw
+    const float kk = rintf(r2 * 0.15915494309189533577f);
+    float yw = fmaf(-kk, 6.2831854820251465f, r2);
+    yw = fmaf(kk, 1.7484555e-7f, yw);
+    e.roll = r0; e.pitch = r1; e.yaw = yw;
+    sign = ((int)kk) & 1;
+  } else {  // init_rpy overrides near / beyond gimbal lock: the general pybullet formulas
+    euler_from_quat(q, e.roll, e.pitch, e.yaw);
+    const Quat qw = quat_from_euler(e.roll, e.pitch, e.yaw);
+    sign = (qw.x * q.x + qw.y * q.y + qw.z * q.z + qw.w * q.w) < 0.f ? 1u : 0u;
+  }
+  ctr = ctr_pack(0u, sign, (uint32_t)ref_offset);
 }
 
 // one observation o (envs/agents.py:339-348 get_state; envs/circle.py:173-177; envs/takeoff.py:146-147)
@@ -322,7 +336,7 @@ PDS_DEV void flush_tile(const float *tile, float *gdst, int rows, int lane) {
 #pragma unroll
     for (int it = 0; it < (NV + kWave - 1) / kWave; ++it) {
       const int idx = it * kWave + lane;
-      if (idx < NV) dst[idx] = src[idx];
+      if (idx < NV) nt_store4(dst + idx, src[idx]);
     }
   } else {
     const int n = rows * D;
@@ -330,6 +344,36 @@ PDS_DEV void flush_tile(const float *tile, float *gdst, int rows, int lane) {
   }
 }
 
+template <int TASK, bool MOTOR, bool DR>
+PDS_DEV void drain_reset_queue(const StepArgs &a, const float2 *ref_lds, const uint32_t *queue, int qcount, int lane);
+
+// Inputs of one env-step, loaded 16 B/lane.  Kept in a struct so the persistent loop can prefetch the
+// next tile's inputs into a second register set while the current tile is being computed.
+struct Loaded {
+  float4 act, q0, q1, q2, h1, h2, mx, p0, mA, mK;
+  float2 p1;
+  uint32_t ctr;
+};
+
+template <bool MOTOR, bool DR>
+PDS_DEV void load_env(const StepArgs &a, long long ii, Loaded &L) {
+  L.act = nt_load4(a.actions + ii);  // read once per step: keep it out of the caches
+  L.q0 = st_load4(a.st.s0 + ii);
+  L.q1 = st_load4(a.st.s1 + ii);
+  L.q2 = st_load4(a.st.s2 + ii);
+  L.h1 = st_load4(a.st.hist[a.parity] + ii);      // u(k-1)
+  L.h2 = st_load4(a.st.hist[a.parity ^ 1] + ii);  // u(k-2)
+  L.ctr = a.st.ctr[ii];
+  if (MOTOR) L.mx = a.st.mx[ii];
+  if (DR) {
+    L.p0 = a.st.par0[ii];
+    L.p1 = a.st.par1[ii];
+    if (MOTOR) { L.mA = a.st.mA[ii]; L.mK = a.st.mK[ii]; }
+  }
+}
+
+// Persistent kernel: grid = (blocks that fit on the chip), every wave walks over 64-env tiles with
+// a grid stride and prefetches the next tile's inputs before computing the current one.
 template <int TASK, bool MOTOR, bool DR, bool GE>
 __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
   using L = ObsLayout<TASK, false>;
@@ -344,213 +388,300 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a) {
     for (int t = tid; t < kRefPoints; t += kBlock) ref_lds[t] = a.st.circle_ref[t];
     __syncthreads();
   }
-  const long long i = (long long)blockIdx.x * kBlock + tid;
-  const long long wave_base = (long long)blockIdx.x * kBlock + (long long)wave * kWave;
-  if (wave_base >= a.n) return;  // whole wave out of range (wave-uniform)
-  const bool active = i < a.n;
-  const long long ii = active ? i : (a.n - 1);  // clamp: tail lanes recompute the last env, stores masked
+  __shared__ uint32_t queue_all[(kBlock / kWave) * kQueueCap];
+  uint32_t *queue = queue_all + wave * kQueueCap;
+  int qcount = 0;  // wave-uniform
   float *tile = tile_all + wave * (kWave * D);
   float *row = tile + lane * D;
+  const long long ntiles = (a.n + kWave - 1) / kWave;
+  const long long tstride = (long long)gridDim.x * (kBlock / kWave);
+  long long t = (long long)blockIdx.x * (kBlock / kWave) + wave;
+  if (t >= ntiles) return;  // wave-uniform
 
-  // ---- coalesced 16 B/lane loads -------------------------------------------------------------
-  const float4 act = a.actions[ii];
-  const float4 q0 = a.st.s0[ii];
-  const float4 q1 = a.st.s1[ii];
-  const float4 q2 = a.st.s2[ii];
-  const float4 h1 = a.st.hist[a.parity][ii];      // u(k-1)
-  const float4 h2 = a.st.hist[a.parity ^ 1][ii];  // u(k-2)
-  uint32_t ctr = a.st.ctr[ii];
-  float4 mx = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (MOTOR) mx = a.st.mx[ii];
-  Params par;
-  default_params(k, par);
-  if (DR) {
-    const float4 p0 = a.st.par0[ii];
-    const float2 p1 = a.st.par1[ii];
-    par.dt = p0.x; par.m = p0.y; par.Jx = p0.z; par.Jy = p0.w; par.Jz = p1.x; par.ftf1 = p1.y;
-    if (MOTOR) {
-      const float4 A = a.st.mA[ii], K = a.st.mK[ii];
-      par.A[0] = A.x; par.A[1] = A.y; par.A[2] = A.z; par.A[3] = A.w;
-      par.K[0] = K.x; par.K[1] = K.y; par.K[2] = K.z; par.K[3] = K.w;
-    }
-  }
-  EnvRegs e{q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
-  const int step = (int)ctr_step(ctr);
-  const int ref_offset = (int)ctr_off(ctr);
-
-  // ---- o(k): rebuilt from the pre-step state instead of being re-read from HBM ------------------
-  Quat q = quat_from_euler(e.roll, e.pitch, e.yaw);
-  if (ctr_sign(ctr)) { q.x = -q.x; q.y = -q.y; q.z = -q.z; q.w = -q.w; }
+  Loaded cur, nxt;
   {
-    float tx, ty, tz;
-    target_at<TASK>(k, ref_lds, target_index<TASK>(step, k.agg, ref_offset), tx, ty, tz);
-    write_obs_half<TASK>(row, e, q, h1, tx, ty, tz, h2);
+    const long long i0 = t * kWave + lane;
+    load_env<MOTOR, DR>(a, i0 < a.n ? i0 : a.n - 1, cur);
   }
-
-  // ---- aggregate_phy_steps x SimplePhysics.step_forward (envs/base.py:457-465) -----------------
-  float xm[4] = {mx.x, mx.y, mx.z, mx.w};
-  const float av[4] = {act.x, act.y, act.z, act.w};
-  for (int sub = 0; sub < k.agg; ++sub) {
-    // CrazyFlieAgent.apply_action, envs/agents.py:259-298 (+ PWM.act envs/control.py:94-100)
-    float f[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float pwm = 30000.f + clampf(av[j], -1.f, 1.f) * 30000.f;
-      const float un = pwm / 60000.f;
-      float n;
-      if (MOTOR) {
-        xm[j] = par.A[j] * xm[j] + (1.0f - par.A[j]) * sqrtf(un);
-        n = xm[j] * xm[j];
-      } else {
-        n = un;
-      }
-      f[j] = par.K[j] * clampf(n, 0.f, 1.f);
+  for (; t < ntiles; t += tstride) {
+    const long long wave_base = t * kWave;
+    const long long i = wave_base + lane;
+    const bool active = i < a.n;
+    const long long ii = active ? i : (a.n - 1);  // tail lanes recompute the last env, stores masked
+    if (t + tstride < ntiles) {  // prefetch (wave-uniform branch)
+      const long long j = (t + tstride) * kWave + lane;
+      load_env<MOTOR, DR>(a, j < a.n ? j : a.n - 1, nxt);
     }
-    // yaw torque: sum of +-(ftf1*f_i + ftf0); ftf0 cancels (envs/agents.py:295-297)
-    const float tz_ = par.ftf1 * (-f[0] + f[1] - f[2] + f[3]);
-    float R[9];
-    matrix_from_quat(q, R);  // envs/physics.py:160 (quaternion of the PREVIOUS step)
-    if (GE) {
-      // BasePhysics.calculate_ground_effect, envs/physics.py:27-58, applied as extra per-motor
-      // thrust (envs/physics.py:117-120); branch-free per-env scale
-      const float ok = (fabsf(e.roll) < kHalfPi && fabsf(e.pitch) < kHalfPi) ? 1.f : 0.f;
-      const float ox[4] = {0.028f, -0.028f, -0.028f, 0.028f};
-      const float oy[4] = {-0.028f, -0.028f, 0.028f, 0.028f};
+
+    const float4 act = cur.act, h1 = cur.h1, h2 = cur.h2;
+    const uint32_t ctr = cur.ctr;
+    float4 mx = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (MOTOR) mx = cur.mx;
+    Params par;
+    default_params(k, par);
+    if (DR) {
+      par.dt = cur.p0.x; par.m = cur.p0.y; par.Jx = cur.p0.z; par.Jy = cur.p0.w; par.Jz = cur.p1.x; par.ftf1 = cur.p1.y;
+      if (MOTOR) {
+        par.A[0] = cur.mA.x; par.A[1] = cur.mA.y; par.A[2] = cur.mA.z; par.A[3] = cur.mA.w;
+        par.K[0] = cur.mK.x; par.K[1] = cur.mK.y; par.K[2] = cur.mK.z; par.K[3] = cur.mK.w;
+      }
+    }
+    EnvRegs e{cur.q0.x, cur.q0.y, cur.q0.z, cur.q0.w, cur.q1.x, cur.q1.y, cur.q1.z, cur.q1.w,
+              cur.q2.x, cur.q2.y, cur.q2.z, cur.q2.w};
+    const int step = (int)ctr_step(ctr);
+    const int ref_offset = (int)ctr_off(ctr);
+
+    // ---- o(k): rebuilt from the pre-step state instead of being re-read from HBM ----------------
+    Quat q = quat_from_euler(e.roll, e.pitch, e.yaw);
+    if (ctr_sign(ctr)) { q.x = -q.x; q.y = -q.y; q.z = -q.z; q.w = -q.w; }
+    {
+      float tx, ty, tz;
+      target_at<TASK>(k, ref_lds, target_index<TASK>(step, k.agg, ref_offset), tx, ty, tz);
+      write_obs_half<TASK>(row, e, q, h1, tx, ty, tz, h2);
+    }
+
+    // ---- aggregate_phy_steps x SimplePhysics.step_forward (envs/base.py:457-465) ---------------
+    float xm[4] = {mx.x, mx.y, mx.z, mx.w};
+    const float av[4] = {act.x, act.y, act.z, act.w};
+    // divisions by the per-env mass / inertia become multiplications by v_rcp_f32 results (1 ulp)
+    const float inv_m = fast_rcp(par.m), inv_Jx = fast_rcp(par.Jx), inv_Jy = fast_rcp(par.Jy), inv_Jz = fast_rcp(par.Jz);
+    for (int sub = 0; sub < k.agg; ++sub) {
+      // CrazyFlieAgent.apply_action, envs/agents.py:259-298 (+ PWM.act envs/control.py:94-100)
+      float f[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float hz = fmaxf(e.pz + (R[6] * ox[j] + R[7] * oy[j]), k.h_clip);
-        const float qq = k.prop_r / (4.f * hz);
-        f[j] = f[j] + ok * (f[j] * k.gec * (qq * qq));
-      }
-    }
-    const float thrust = ((f[0] + f[1]) + f[2]) + f[3];
-    const float Fx = R[2] * thrust, Fy = R[5] * thrust, Fz = R[8] * thrust - k.G * par.m;
-    const float tx_ = (-f[0] - f[1] + f[2] + f[3]) * k.Lq;  // envs/physics.py:167
-    const float ty_ = (-f[0] + f[1] + f[2] - f[3]) * k.Lq;  // envs/physics.py:168
-    const float Jwx = par.Jx * e.wx, Jwy = par.Jy * e.wy, Jwz = par.Jz * e.wz;
-    const float t0 = tx_ - (e.wy * Jwz - e.wz * Jwy);  // tau - w x (J w), envs/physics.py:170-171
-    const float t1 = ty_ - (e.wz * Jwx - e.wx * Jwz);
-    const float t2 = tz_ - (e.wx * Jwy - e.wy * Jwx);
-    const float dt = par.dt;
-    e.vx += dt * (Fx / par.m); e.vy += dt * (Fy / par.m); e.vz += dt * (Fz / par.m);  // :173,175
-    e.wx += dt * (t0 / par.Jx); e.wy += dt * (t1 / par.Jy); e.wz += dt * (t2 / par.Jz);  // :172,176
-    e.px += dt * e.vx; e.py += dt * e.vy; e.pz += dt * e.vz;                           // :177
-    e.roll += dt * e.wx; e.pitch += dt * e.wy; e.yaw += dt * e.wz;                     // :178
-    q = quat_from_euler(e.roll, e.pitch, e.yaw);                                       // :179
-    e.pz = fmaxf(e.pz, 0.f);                                                           // :182
-  }
-
-  // ---- task: target, done, reward, cost -----------------------------------------------------
-  float tx, ty, tz;
-  target_at<TASK>(k, ref_lds, target_index<TASK>(step + 1, k.agg, ref_offset), tx, ty, tz);
-  const float dx = e.px - tx, dy = e.py - ty, dz = e.pz - tz;
-  const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
-  bool done = false;
-  if (TASK == PDS_TASK_HOVER) {  // envs/hover.py:89-101
-    constexpr float lim = 60.f * kPi / 180.f;
-    constexpr float r2d = 180.f / kPi;
-    done = (e.pz < 0.2f) || (fabsf(e.roll) > lim) || (fabsf(e.pitch) > lim) ||
-           (fabsf(e.wx) * r2d > 300.f) || (fabsf(e.wy) * r2d > 300.f) || (fabsf(e.wz) * r2d > 300.f);
-  } else if (TASK == PDS_TASK_CIRCLE) {  // envs/circle.py:116-120
-    done = dist > 0.25f;
-  }
-  float reward;
-  {  // envs/hover.py:169-187, envs/circle.py:183-204, envs/takeoff.py:155-174
-    const float n0 = 0.5f * (clampf(act.x, -1.f, 1.f) + 1.f), n1 = 0.5f * (clampf(act.y, -1.f, 1.f) + 1.f);
-    const float n2 = 0.5f * (clampf(act.z, -1.f, 1.f) + 1.f), n3 = 0.5f * (clampf(act.w, -1.f, 1.f) + 1.f);
-    const float pen_act = k.pa * sqrtf(n0 * n0 + n1 * n1 + n2 * n2 + n3 * n3);
-    float pen_rate = 0.f;
-    if (TASK == PDS_TASK_CIRCLE) {  // a - env.last_action (previous action, envs/circle.py:186)
-      const float d0 = act.x - h1.x, d1 = act.y - h1.y, d2 = act.z - h1.z, d3 = act.w - h1.w;
-      pen_rate = k.arp * sqrtf(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
-    }
-    const float pen_rpy = k.pang * sqrtf(e.roll * e.roll + e.pitch * e.pitch + e.yaw * e.yaw);
-    const float pen_spin = k.pspin * sqrtf(e.wx * e.wx + e.wy * e.wy + e.wz * e.wz);
-    const float pen_term = done ? k.pterm : 0.f;
-    // envs/takeoff.py:165 multiplies the velocity norm by penalty_ACTION
-    const float pen_vel = (TASK == PDS_TASK_TAKEOFF ? k.pa : k.pvel) * sqrtf(e.vx * e.vx + e.vy * e.vy + e.vz * e.vz);
-    const float penalties = ((((pen_rpy + pen_rate) + pen_spin) + pen_vel) + pen_act) + pen_term;
-    reward = -dist - penalties;
-    if (TASK == PDS_TASK_TAKEOFF && e.pz < 0.08f) reward -= 1.f;  // envs/takeoff.py:172-173
-  }
-  float cost = 0.f;
-  if (TASK == PDS_TASK_HOVER) {
-    // envs/hover.py:103-129: state[10:13] is rpy_dot and state[13:16] is last_action[0:3] in the
-    // get_state layout -- reproduced as is
-    constexpr float rp_lim = 10.f * kPi / 180.f, dot_lim = 200.f * kPi / 180.f;
-    const bool c = (fabsf(e.px) > 0.10f) || (fabsf(e.py) > 0.10f) || (e.pz > 1.20f) ||
-                   (fabsf(e.roll) > rp_lim) || (fabsf(e.pitch) > rp_lim) ||
-                   (fabsf(e.wx) > 0.25f) || (fabsf(e.wy) > 0.25f) || (fabsf(e.wz) > 0.25f) ||
-                   (fabsf(act.x) > dot_lim) || (fabsf(act.y) > dot_lim) || (fabsf(act.z) > dot_lim);
-    cost = c ? 1.f : 0.f;
-  }
-  const bool trunc = (step + 1) >= k.max_steps;  // gymnasium TimeLimit, __init__.py:11
-
-  // ---- o(k+1) and u(k-1) -> second half of the row (envs/base.py:303-319) --------------------
-  write_obs_half<TASK>(row + L::O + 4, e, q, act, tx, ty, tz, h1);
-
-  uint32_t ctr_new = ctr_pack((uint32_t)(step + 1), 0u, (uint32_t)ref_offset);
-  float4 hist_new = act;
-  bool did_reset = false;
-  if (a.auto_reset && (done || trunc)) {
-    // hand the terminal observation to final_obs (strided row copy; ~1/500 of env-steps)
-    if (a.final_obs != nullptr && active) {
-      float *fo = a.final_obs + i * D;
-      for (int j = 0; j < D; ++j) fo[j] = row[j];
-    }
-    Sample s;
-    sample_philox<TASK, MOTOR, DR>(k, (uint32_t)(a.env_id_base + (unsigned long long)ii), a, s);
-    float4 u0;
-    Quat qr;
-    uint32_t c0 = ctr;
-    reset_env<TASK, MOTOR, DR>(k, ref_lds, s, e, qr, u0, mx, par, c0);
-    xm[0] = mx.x; xm[1] = mx.y; xm[2] = mx.z; xm[3] = mx.w;
-    ctr_new = c0;
-    hist_new = u0;
-    did_reset = true;
-    float rtx, rty, rtz;
-    target_at<TASK>(k, ref_lds, target_index<TASK>(0, k.agg, (int)ctr_off(c0)), rtx, rty, rtz);
-    write_obs_half<TASK>(row, e, qr, u0, rtx, rty, rtz, u0);
-    write_obs_half<TASK>(row + L::O + 4, e, qr, u0, rtx, rty, rtz, u0);
-  }
-
-  // ---- coalesced stores ------------------------------------------------------------------------
-  if (active) {
-    a.st.s0[i] = make_float4(e.px, e.py, e.pz, e.vx);
-    a.st.s1[i] = make_float4(e.vy, e.vz, e.roll, e.pitch);
-    a.st.s2[i] = make_float4(e.yaw, e.wx, e.wy, e.wz);
-    a.st.hist[a.parity ^ 1][i] = hist_new;  // overwrites u(k-2); next step's parity makes it u(k-1)
-    a.st.ctr[i] = ctr_new;
-    if (MOTOR) a.st.mx[i] = make_float4(xm[0], xm[1], xm[2], xm[3]);
-    a.reward[i] = reward;
-    a.cost[i] = cost;
-    a.term[i] = done ? 1 : 0;
-    a.trunc[i] = trunc ? 1 : 0;
-    if (did_reset) {
-      a.st.hist[a.parity][i] = hist_new;  // both ring slots hold u0 after a reset
-      if (DR) {
-        a.st.par0[i] = make_float4(par.dt, par.m, par.Jx, par.Jy);
-        a.st.par1[i] = make_float2(par.Jz, par.ftf1);
+        const float pwm = 30000.f + clampf(av[j], -1.f, 1.f) * 30000.f;
+        const float un = pwm * (1.0f / 60000.f);
+        float n;
         if (MOTOR) {
-          a.st.mA[i] = make_float4(par.A[0], par.A[1], par.A[2], par.A[3]);
-          a.st.mK[i] = make_float4(par.K[0], par.K[1], par.K[2], par.K[3]);
+          xm[j] = par.A[j] * xm[j] + (1.0f - par.A[j]) * fast_sqrt(un);
+          n = xm[j] * xm[j];
+        } else {
+          n = un;
+        }
+        f[j] = par.K[j] * clampf(n, 0.f, 1.f);
+      }
+      // yaw torque: sum of +-(ftf1*f_i + ftf0); ftf0 cancels (envs/agents.py:295-297)
+      const float tz_ = par.ftf1 * (-f[0] + f[1] - f[2] + f[3]);
+      float R[9];
+      matrix_from_quat(q, R);  // envs/physics.py:160 (quaternion of the PREVIOUS step)
+      if (GE) {
+        // BasePhysics.calculate_ground_effect, envs/physics.py:27-58, applied as extra per-motor
+        // thrust (envs/physics.py:117-120); branch-free per-env scale
+        const float ok = (fabsf(e.roll) < kHalfPi && fabsf(e.pitch) < kHalfPi) ? 1.f : 0.f;
+        const float ox[4] = {0.028f, -0.028f, -0.028f, 0.028f};
+        const float oy[4] = {-0.028f, -0.028f, 0.028f, 0.028f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float hz = fmaxf(e.pz + (R[6] * ox[j] + R[7] * oy[j]), k.h_clip);
+          const float qq = k.prop_r * fast_rcp(4.f * hz);
+          f[j] = f[j] + ok * (f[j] * k.gec * (qq * qq));
+        }
+      }
+      const float thrust = ((f[0] + f[1]) + f[2]) + f[3];
+      const float Fx = R[2] * thrust, Fy = R[5] * thrust, Fz = R[8] * thrust - k.G * par.m;
+      const float tx_ = (-f[0] - f[1] + f[2] + f[3]) * k.Lq;  // envs/physics.py:167
+      const float ty_ = (-f[0] + f[1] + f[2] - f[3]) * k.Lq;  // envs/physics.py:168
+      const float Jwx = par.Jx * e.wx, Jwy = par.Jy * e.wy, Jwz = par.Jz * e.wz;
+      const float t0 = tx_ - (e.wy * Jwz - e.wz * Jwy);  // tau - w x (J w), envs/physics.py:170-171
+      const float t1 = ty_ - (e.wz * Jwx - e.wx * Jwz);
+      const float t2 = tz_ - (e.wx * Jwy - e.wy * Jwx);
+      const float dt = par.dt;
+      e.vx += dt * (Fx * inv_m); e.vy += dt * (Fy * inv_m); e.vz += dt * (Fz * inv_m);    // :173,175
+      e.wx += dt * (t0 * inv_Jx); e.wy += dt * (t1 * inv_Jy); e.wz += dt * (t2 * inv_Jz);  // :172,176
+      e.px += dt * e.vx; e.py += dt * e.vy; e.pz += dt * e.vz;                             // :177
+      e.roll += dt * e.wx; e.pitch += dt * e.wy; e.yaw += dt * e.wz;                       // :178
+      q = quat_from_euler(e.roll, e.pitch, e.yaw);                                         // :179
+      e.pz = fmaxf(e.pz, 0.f);                                                             // :182
+    }
+
+    // ---- task: target, done, reward, cost ---------------------------------------------------
+    float tx, ty, tz;
+    target_at<TASK>(k, ref_lds, target_index<TASK>(step + 1, k.agg, ref_offset), tx, ty, tz);
+    const float dx = e.px - tx, dy = e.py - ty, dz = e.pz - tz;
+    const float dist = fast_sqrt(dx * dx + dy * dy + dz * dz);
+    bool done = false;
+    if (TASK == PDS_TASK_HOVER) {  // envs/hover.py:89-101
+      constexpr float lim = 60.f * kPi / 180.f;
+      constexpr float r2d = 180.f / kPi;
+      done = (e.pz < 0.2f) || (fabsf(e.roll) > lim) || (fabsf(e.pitch) > lim) ||
+             (fabsf(e.wx) * r2d > 300.f) || (fabsf(e.wy) * r2d > 300.f) || (fabsf(e.wz) * r2d > 300.f);
+    } else if (TASK == PDS_TASK_CIRCLE) {  // envs/circle.py:116-120
+      done = dist > 0.25f;
+    }
+    float reward;
+    {  // envs/hover.py:169-187, envs/circle.py:183-204, envs/takeoff.py:155-174
+      const float n0 = 0.5f * (clampf(act.x, -1.f, 1.f) + 1.f), n1 = 0.5f * (clampf(act.y, -1.f, 1.f) + 1.f);
+      const float n2 = 0.5f * (clampf(act.z, -1.f, 1.f) + 1.f), n3 = 0.5f * (clampf(act.w, -1.f, 1.f) + 1.f);
+      const float pen_act = k.pa * fast_sqrt(n0 * n0 + n1 * n1 + n2 * n2 + n3 * n3);
+      float pen_rate = 0.f;
+      if (TASK == PDS_TASK_CIRCLE) {  // a - env.last_action (previous action, envs/circle.py:186)
+        const float d0 = act.x - h1.x, d1 = act.y - h1.y, d2 = act.z - h1.z, d3 = act.w - h1.w;
+        pen_rate = k.arp * fast_sqrt(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
+      }
+      float pen_rpy = 0.f;
+      if (k.pang != 0.f) pen_rpy = k.pang * fast_sqrt(e.roll * e.roll + e.pitch * e.pitch + e.yaw * e.yaw);
+      const float pen_spin = k.pspin * fast_sqrt(e.wx * e.wx + e.wy * e.wy + e.wz * e.wz);
+      const float pen_term = done ? k.pterm : 0.f;
+      // envs/takeoff.py:165 multiplies the velocity norm by penalty_ACTION
+      const float pv = (TASK == PDS_TASK_TAKEOFF) ? k.pa : k.pvel;
+      float pen_vel = 0.f;
+      if (pv != 0.f) pen_vel = pv * fast_sqrt(e.vx * e.vx + e.vy * e.vy + e.vz * e.vz);
+      const float penalties = ((((pen_rpy + pen_rate) + pen_spin) + pen_vel) + pen_act) + pen_term;
+      reward = -dist - penalties;
+      if (TASK == PDS_TASK_TAKEOFF && e.pz < 0.08f) reward -= 1.f;  // envs/takeoff.py:172-173
+    }
+    float cost = 0.f;
+    if (TASK == PDS_TASK_HOVER) {
+      // envs/hover.py:103-129: state[10:13] is rpy_dot and state[13:16] is last_action[0:3] in the
+      // get_state layout -- reproduced as is
+      constexpr float rp_lim = 10.f * kPi / 180.f, dot_lim = 200.f * kPi / 180.f;
+      const bool c = (fabsf(e.px) > 0.10f) || (fabsf(e.py) > 0.10f) || (e.pz > 1.20f) ||
+                     (fabsf(e.roll) > rp_lim) || (fabsf(e.pitch) > rp_lim) ||
+                     (fabsf(e.wx) > 0.25f) || (fabsf(e.wy) > 0.25f) || (fabsf(e.wz) > 0.25f) ||
+                     (fabsf(act.x) > dot_lim) || (fabsf(act.y) > dot_lim) || (fabsf(act.z) > dot_lim);
+      cost = c ? 1.f : 0.f;
+    }
+    const bool trunc = (step + 1) >= k.max_steps;  // gymnasium TimeLimit, __init__.py:11
+
+    // ---- o(k+1) and u(k-1) -> second half of the row (envs/base.py:303-319) ------------------
+    write_obs_half<TASK>(row + L::O + 4, e, q, act, tx, ty, tz, h1);
+
+    const uint32_t ctr_new = ctr_pack((uint32_t)(step + 1), 0u, (uint32_t)ref_offset);
+    // ---- auto-reset: DEFERRED.  ~2 % of the envs finish per step under random actions, i.e. 3 of
+    // 4 waves would run the (long, transcendental-heavy) reset path for one or two live lanes.  A
+    // finished env only hands its last observation to final_obs here and queues its index in LDS;
+    // the wave resets its queued envs densely after its last tile (or when the queue fills up).
+    const bool need_reset = a.auto_reset && (done || trunc) && active;
+    {
+      unsigned long long m = __ballot(need_reset);
+      if (m != 0ull) {  // wave-uniform
+        const int pos = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (need_reset) queue[pos] = (uint32_t)i | ((uint32_t)ref_offset << 23);
+        qcount += __popcll(m);
+        if (a.final_obs != nullptr) {
+          // last observation of each finished env -> final_obs: the whole wave copies one row
+          // (D <= 64 contiguous floats) per finished env straight out of the LDS tile
+          do {
+            const int src_lane = __builtin_ctzll(m);
+            m &= m - 1ull;
+            if (lane < D) a.final_obs[(wave_base + src_lane) * D + lane] = tile[src_lane * D + lane];
+          } while (m != 0ull);
         }
       }
     }
+
+    // ---- coalesced stores ----------------------------------------------------------------------
+    if (active) {
+      st_store4(a.st.s0 + i, make_float4(e.px, e.py, e.pz, e.vx));
+      st_store4(a.st.s1 + i, make_float4(e.vy, e.vz, e.roll, e.pitch));
+      st_store4(a.st.s2 + i, make_float4(e.yaw, e.wx, e.wy, e.wz));
+      st_store4(a.st.hist[a.parity ^ 1] + i, act);  // overwrites u(k-2); next step's parity makes it u(k-1)
+      a.st.ctr[i] = ctr_new;
+      if (MOTOR) a.st.mx[i] = make_float4(xm[0], xm[1], xm[2], xm[3]);
+      nt_store(a.reward + i, reward);
+      nt_store(a.cost + i, cost);
+      nt_store(a.term + i, (uint8_t)(done ? 1 : 0));
+      nt_store(a.trunc + i, (uint8_t)(trunc ? 1 : 0));
+    }
+    // LDS rows of this wave were written by its own lanes only: wave-synchronous, no block barrier
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const long long rem = a.n - wave_base;
+    flush_tile<D>(tile, a.obs + wave_base * D, rem >= kWave ? kWave : (int)rem, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // the tile is rewritten by the next iteration
+    if (qcount > kQueueCap - kWave) {  // wave-uniform: next tile could overflow the queue
+      drain_reset_queue<TASK, MOTOR, DR>(a, ref_lds, queue, qcount, lane);
+      qcount = 0;
+    }
+    cur = nxt;
   }
-  // LDS rows of this wave were written by its own lanes only: wave-synchronous, no block barrier
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  const long long rem = a.n - wave_base;
-  flush_tile<D>(tile, a.obs + wave_base * D, rem >= kWave ? kWave : (int)rem, lane);
+  if (qcount > 0) drain_reset_queue<TASK, MOTOR, DR>(a, ref_lds, queue, qcount, lane);
 }
 
-// Explicit reset (pds_reset / pds_reset_from_samples): not a hot path, rows written directly.
+// Reset of one env, split in a pure-compute half and a store half so that the deferred auto-reset
+// drain can do its arithmetic while the wave's earlier stores are still draining.
+struct ResetOut {
+  EnvRegs e;
+  Quat q;
+  float4 u0, mx;
+  Params par;
+  uint32_t ctr;
+};
+
 template <int TASK, bool MOTOR, bool DR>
-__global__ __launch_bounds__(kBlock) void reset_kernel(const StepArgs a) {
+PDS_DEV void reset_compute(const StepArgs &a, const float2 *ref_lds, long long i, uint32_t ctr_old,
+                           const float *sample_row, ResetOut &r) {
+  Sample s;
+  if (sample_row != nullptr) sample_load(sample_row, s);
+  else sample_philox<TASK, MOTOR, DR>(a.k, (uint32_t)(a.env_id_base + (unsigned long long)i), a, s);
+  r.ctr = ctr_old;
+  reset_env<TASK, MOTOR, DR>(a.k, ref_lds, s, r.e, r.q, r.u0, r.mx, r.par, r.ctr);
+}
+
+// Writes the complete state, parameters and (optionally) the observation row [o0,u0,o0,u0]
+// (envs/base.py:417-431) of a reset env straight to HBM.  Rows are strided -> only for the explicit
+// reset kernel and the deferred auto-reset drain, never on the per-step stream.
+template <int TASK, bool MOTOR, bool DR>
+PDS_DEV void reset_store(const StepArgs &a, const float2 *ref_lds, long long i, const ResetOut &r) {
   using L = ObsLayout<TASK, false>;
   constexpr int D = L::D;
+  const EnvRegs &e = r.e;
+  a.st.s0[i] = make_float4(e.px, e.py, e.pz, e.vx);
+  a.st.s1[i] = make_float4(e.vy, e.vz, e.roll, e.pitch);
+  a.st.s2[i] = make_float4(e.yaw, e.wx, e.wy, e.wz);
+  a.st.hist[0][i] = r.u0;
+  a.st.hist[1][i] = r.u0;
+  a.st.ctr[i] = r.ctr;
+  if (MOTOR) a.st.mx[i] = r.mx;
+  if (DR) {
+    a.st.par0[i] = make_float4(r.par.dt, r.par.m, r.par.Jx, r.par.Jy);
+    a.st.par1[i] = make_float2(r.par.Jz, r.par.ftf1);
+    if (MOTOR) {
+      a.st.mA[i] = make_float4(r.par.A[0], r.par.A[1], r.par.A[2], r.par.A[3]);
+      a.st.mK[i] = make_float4(r.par.K[0], r.par.K[1], r.par.K[2], r.par.K[3]);
+    }
+  }
+  if (a.obs != nullptr) {
+    float rowbuf[D];
+    float tx, ty, tz;
+    target_at<TASK>(a.k, ref_lds, target_index<TASK>(0, a.k.agg, (int)ctr_off(r.ctr)), tx, ty, tz);
+    write_obs_half<TASK>(rowbuf, e, r.q, r.u0, tx, ty, tz, r.u0);
+    write_obs_half<TASK>(rowbuf + L::O + 4, e, r.q, r.u0, tx, ty, tz, r.u0);
+    float2 *dst = reinterpret_cast<float2 *>(a.obs + i * D);
+#pragma unroll
+    for (int j = 0; j < D / 2; ++j) dst[j] = make_float2(rowbuf[2 * j], rowbuf[2 * j + 1]);
+  }
+}
+
+// Dense pass over the envs a wave queued for auto-reset (queue entry = env index | ref_offset << 23).
+// The arithmetic touches no memory, so it overlaps with the wave's outstanding stores; those must
+// have completed (s_waitcnt vmcnt(0)) before the same addresses are overwritten.
+template <int TASK, bool MOTOR, bool DR>
+PDS_DEV void drain_reset_queue(const StepArgs &a, const float2 *ref_lds, const uint32_t *queue, int qcount, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int base = 0; base < qcount; base += kWave) {
+    const int idx = base + lane;
+    const bool on = idx < qcount;
+    ResetOut r;
+    long long i = 0;
+    if (on) {
+      const uint32_t ent = queue[idx];
+      i = (long long)(ent & 0x7FFFFFu);
+      reset_compute<TASK, MOTOR, DR>(a, ref_lds, i, ctr_pack(0u, 0u, ent >> 23), nullptr, r);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (on) reset_store<TASK, MOTOR, DR>(a, ref_lds, i, r);
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Explicit reset (pds_reset / pds_reset_from_samples): not a hot path.
+template <int TASK, bool MOTOR, bool DR>
+__global__ __launch_bounds__(kBlock) void reset_kernel(const StepArgs a) {
   __shared__ float2 ref_lds[(TASK == PDS_TASK_CIRCLE) ? kRefPoints : 1];
   if (TASK == PDS_TASK_CIRCLE) {
     for (int t = threadIdx.x; t < kRefPoints; t += kBlock) ref_lds[t] = a.st.circle_ref[t];
@@ -559,41 +690,9 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const StepArgs a) {
   const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
   if (i >= a.n) return;
   if (a.mask != nullptr && a.mask[i] == 0) return;
-  const Consts &k = a.k;
-  Sample s;
-  if (a.samples != nullptr) sample_load(a.samples + i * PDS_SAMPLE_FLOATS, s);
-  else sample_philox<TASK, MOTOR, DR>(k, (uint32_t)(a.env_id_base + (unsigned long long)i), a, s);
-  EnvRegs e;
-  Quat q;
-  float4 u0, mx;
-  Params par;
-  uint32_t ctr = a.st.ctr[i];
-  reset_env<TASK, MOTOR, DR>(k, ref_lds, s, e, q, u0, mx, par, ctr);
-  a.st.s0[i] = make_float4(e.px, e.py, e.pz, e.vx);
-  a.st.s1[i] = make_float4(e.vy, e.vz, e.roll, e.pitch);
-  a.st.s2[i] = make_float4(e.yaw, e.wx, e.wy, e.wz);
-  a.st.hist[0][i] = u0;
-  a.st.hist[1][i] = u0;
-  a.st.ctr[i] = ctr;
-  if (MOTOR) a.st.mx[i] = mx;
-  if (DR) {
-    a.st.par0[i] = make_float4(par.dt, par.m, par.Jx, par.Jy);
-    a.st.par1[i] = make_float2(par.Jz, par.ftf1);
-    if (MOTOR) {
-      a.st.mA[i] = make_float4(par.A[0], par.A[1], par.A[2], par.A[3]);
-      a.st.mK[i] = make_float4(par.K[0], par.K[1], par.K[2], par.K[3]);
-    }
-  }
-  if (a.obs != nullptr) {
-    float rowbuf[D];
-    float tx, ty, tz;
-    target_at<TASK>(k, ref_lds, target_index<TASK>(0, k.agg, (int)ctr_off(ctr)), tx, ty, tz);
-    write_obs_half<TASK>(rowbuf, e, q, u0, tx, ty, tz, u0);
-    write_obs_half<TASK>(rowbuf + L::O + 4, e, q, u0, tx, ty, tz, u0);
-    float2 *dst = reinterpret_cast<float2 *>(a.obs + i * D);
-#pragma unroll
-    for (int j = 0; j < D / 2; ++j) dst[j] = make_float2(rowbuf[2 * j], rowbuf[2 * j + 1]);
-  }
+  ResetOut r;
+  reset_compute<TASK, MOTOR, DR>(a, ref_lds, i, a.st.ctr[i], a.samples != nullptr ? a.samples + i * PDS_SAMPLE_FLOATS : nullptr, r);
+  reset_store<TASK, MOTOR, DR>(a, ref_lds, i, r);
 }
 
 // ---- state access (parity injection, checkpointing) -------------------------------------------
@@ -697,6 +796,8 @@ struct pds_handle {
   Consts k;
   float2 *d_circle_ref;
   int obs_dim;
+  int num_cus;
+  long long grid_override;
   int parity;
   uint64_t tick;
   bool was_reset;
@@ -798,7 +899,8 @@ extern "C" int pds_create(const pds_config *cfg, pds_handle **out) {
   *out = nullptr;
   if (cfg->struct_size != (int32_t)sizeof(pds_config)) { snprintf(g_create_err, sizeof(g_create_err), "pds_config size mismatch"); return PDS_EINVAL; }
   if (cfg->task < 0 || cfg->task > 2 || cfg->num_envs < 1 || cfg->aggregate_phy_steps < 1 ||
-      cfg->max_episode_steps < 1 || cfg->max_episode_steps > 65535 || cfg->time_step <= 0) {
+      cfg->max_episode_steps < 1 || cfg->max_episode_steps > 65535 || cfg->time_step <= 0 ||
+      cfg->num_envs > (1ll << 23)) {  // env index + ref_offset share a 32-bit reset-queue word
     snprintf(g_create_err, sizeof(g_create_err), "invalid pds_config");
     return PDS_EINVAL;
   }
@@ -818,6 +920,13 @@ extern "C" int pds_create(const pds_config *cfg, pds_handle **out) {
   h->cfg = *cfg;
   fill_consts(*cfg, h->k);
   h->obs_dim = obs_dim_of(*cfg);
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess || cus <= 0) cus = 256;
+    h->num_cus = cus;
+    const char *g = getenv("PDS_GRID_BLOCKS");
+    h->grid_override = g ? atoll(g) : 0;
+  }
   const size_t n = (size_t)cfg->num_envs;
   const bool motor = cfg->use_motor_dynamics != 0, dr = cfg->domain_randomization > 0;
   hipError_t e = hipSetDevice(cfg->device);
@@ -951,7 +1060,15 @@ extern "C" int pds_step(pds_handle *h, const float *d_actions, float *d_obs, flo
   a.actions = reinterpret_cast<const float4 *>(d_actions);
   a.obs = d_obs; a.reward = d_reward; a.term = d_terminated; a.trunc = d_truncated; a.cost = d_cost;
   a.final_obs = d_final_obs;
-  const dim3 grid((unsigned)((a.n + kBlock - 1) / kBlock));
+  // persistent launch: at most kBlocksPerCU resident blocks per CU (LDS-bound: 4 wave tiles of
+  // 64 x D floats per block), every wave strides over the 64-env tiles
+  const long long blocks_needed = (a.n + kBlock - 1) / kBlock;
+  // default: one 256-env block per 4 tiles (the hardware dispatcher balances blocks whose
+  // deferred-reset drains have different lengths; measured faster than a resident grid)
+  long long blocks_resident = blocks_needed;
+  if (h->grid_override > 0) blocks_resident = h->grid_override;  // PDS_GRID_BLOCKS: tuning knob
+  const dim3 grid((unsigned)(blocks_needed < blocks_resident ? blocks_needed : blocks_resident));
+  (void)kBlocksPerCU;
   const bool motor = h->cfg.use_motor_dynamics != 0, dr = h->cfg.domain_randomization > 0;
   const bool ge = h->cfg.use_ground_effect != 0;
   hipStream_t s = (hipStream_t)stream;
