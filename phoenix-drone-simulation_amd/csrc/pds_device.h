@@ -23,14 +23,14 @@ PDS_DEV void fast_sincos(float x, float &s, float &c) {
     sincosf(x, &s, &c);
     return;
   }
-  const float n = rintf(x * 0.636619772367581343f);
+  const float n = rintf(__fmul_rn(x, 0.636619772367581343f));
   float r = fmaf(n, -1.57079637050628662109375f, x);
   r = fmaf(n, 4.37113900018624283e-8f, r);
   r = fmaf(n, 1.7151245100059521e-15f, r);
   const int q = (int)n;
-  const float r2 = r * r;
-  const float sp = fmaf(r * r2, fmaf(r2, fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), r);
-  const float cp = fmaf(r2 * r2, fmaf(r2, fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f),
+  const float r2 = __fmul_rn(r, r);
+  const float sp = fmaf(__fmul_rn(r, r2), fmaf(r2, fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), r);
+  const float cp = fmaf(__fmul_rn(r2, r2), fmaf(r2, fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f),
                         fmaf(r2, -0.5f, 1.0f));
   const float ss = (q & 1) ? cp : sp;
   const float cc = (q & 1) ? sp : cp;
@@ -45,16 +45,22 @@ PDS_DEV float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); } // v_sqrt
 // formula is restated in the reference at envs/utils.py:32-56.  Call sites envs/physics.py:179.
 PDS_DEV Quat quat_from_euler(float roll, float pitch, float yaw) {
   float sr, cr, sp, cp, sy, cy;
-  fast_sincos(roll * 0.5f, sr, cr);
-  fast_sincos(pitch * 0.5f, sp, cp);
-  fast_sincos(yaw * 0.5f, sy, cy);
+  fast_sincos(__fmul_rn(roll, 0.5f), sr, cr);
+  fast_sincos(__fmul_rn(pitch, 0.5f), sp, cp);
+  fast_sincos(__fmul_rn(yaw, 0.5f), sy, cy);
+  // The operation sequence is pinned (explicit FMAs, products that must not be contracted go
+  // through __fmul_rn) so that every inlined copy produces the same bits: the o(k) half of an
+  // observation is REBUILT from the stored Euler angles in the next step and has to equal the
+  // o(k+1) half written by the previous step exactly, like the reference's history deque.
+  const float a = __fmul_rn(sr, cp), b = __fmul_rn(cr, sp), c = __fmul_rn(cr, cp), d = __fmul_rn(sr, sp);
   Quat q;
-  q.x = sr * cp * cy - cr * sp * sy;
-  q.y = cr * sp * cy + sr * cp * sy;
-  q.z = cr * cp * sy - sr * sp * cy;
-  q.w = cr * cp * cy + sr * sp * sy;
-  const float inv = __builtin_amdgcn_rsqf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
-  q.x *= inv; q.y *= inv; q.z *= inv; q.w *= inv;
+  q.x = fmaf(a, cy, -__fmul_rn(b, sy));
+  q.y = fmaf(b, cy, __fmul_rn(a, sy));
+  q.z = fmaf(c, sy, -__fmul_rn(d, cy));
+  q.w = fmaf(c, cy, __fmul_rn(d, sy));
+  const float n2 = fmaf(q.w, q.w, fmaf(q.z, q.z, fmaf(q.y, q.y, __fmul_rn(q.x, q.x))));
+  const float inv = __builtin_amdgcn_rsqf(n2);
+  q.x = __fmul_rn(q.x, inv); q.y = __fmul_rn(q.y, inv); q.z = __fmul_rn(q.z, inv); q.w = __fmul_rn(q.w, inv);
   return q;
 }
 

@@ -1,0 +1,145 @@
+"""CPU-side tests of the host logic: the C-ABI library loads and exports every symbol that
+include/pds.h declares (no compute without a GPU), the ctypes mirror of pds_config matches the C
+struct, the env ids / kwargs mirror the reference, the product path refuses to run without the
+HIP device, and the multi-GPU sharding helpers work under a world_size-2 gloo group."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "pds.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(pds_[a-z_0-9]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    import phoenix_drone_simulation_amd as pds
+    lib = pds.native.load()
+    syms = _declared_symbols()
+    assert len(syms) >= 15
+    for s in syms:
+        assert hasattr(lib, s), f"libpds_hip.so does not export {s}"
+    assert set(pds.native.EXPORTS) == set(syms)
+    assert lib.pds_version() == 1
+
+
+def test_config_struct_mirror_and_defaults():
+    """pds_default_config reproduces the reference ctor defaults (envs/base.py:26-48,
+    envs/hover.py:7-45, envs/circle.py:7-34, envs/takeoff.py:13-41)."""
+    import phoenix_drone_simulation_amd as pds
+    for task, spin, vel, arp, z0 in ((0, 1e-4, 0.0, 0.0, 1.0), (1, 1e-3, 1e-4, 1e-3, 1.0),
+                                     (2, 1e-4, 0.0, 0.0, float(np.float32(0.0125)))):
+        c = pds.native.default_config(task)
+        assert c.struct_size == C.sizeof(pds.native.Config)
+        assert (c.task, c.num_envs, c.aggregate_phy_steps, c.max_episode_steps) == (task, 1, 1, 500)
+        assert (c.observation_noise, c.enable_reset_distribution, c.auto_reset) == (1, 1, 1)
+        assert c.domain_randomization == 0.10 and c.motor_thrust_noise == 0.05
+        assert c.time_step == 0.01 and c.motor_time_constant == 0.08
+        assert (c.penalty_action, c.penalty_angle, c.penalty_terminal) == (1e-4, 0.0, 100.0)
+        assert (c.penalty_spin, c.penalty_velocity, c.ARP) == (spin, vel, arp)
+        assert list(c.target_pos) == [0.0, 0.0, 1.0] and list(c.init_xyz) == [0.0, 0.0, z0]
+    assert pds.native.load().pds_default_config(7, C.byref(pds.native.Config())) == pds.native.EINVAL
+
+
+def test_field_widths():
+    import phoenix_drone_simulation_amd as pds
+    lib = pds.native.load()
+    want = dict(pos=3, rpy=3, vel=3, omega=3, quat=4, motor_x=4, last_action=4, prev_action=4,
+                step_count=1, quat_sign=1, ref_offset=1, params=6, motor_A=4, motor_K=4, ou=4,
+                gyro_bias=3, gyro_lpf=3)
+    for name, w in want.items():
+        assert lib.pds_field_width(pds.native.FIELDS[name]) == w
+    assert lib.pds_field_width(99) == pds.native.EINVAL
+
+
+def test_registry_mirrors_reference_ids():
+    import phoenix_drone_simulation_amd as pds
+    assert sorted(pds.registry) == ["DroneCircleSimpleEnv-v0", "DroneHoverSimpleEnv-v0",
+                                    "DroneTakeOffSimpleEnv-v0"]
+    assert all(v[1] == 500 for v in pds.registry.values())  # __init__.py:11,27,43
+    with pytest.raises(KeyError):
+        pds.make("DroneHoverBulletEnv-v0")
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_no_silent_cpu_fallback():
+    """Without a HIP device the product path must fail loudly, at the Python and at the C level."""
+    import phoenix_drone_simulation_amd as pds
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pds.make("DroneHoverSimpleEnv-v0", num_envs=8)
+    cfg = pds.native.default_config(0)
+    cfg.observation_noise = 0
+    cfg.motor_thrust_noise = 0.0
+    h = C.c_void_p()
+    rc = pds.native.load().pds_create(C.byref(cfg), C.byref(h))
+    assert rc == pds.native.ENODEVICE and not h
+    assert b"no CPU fallback" in pds.native.load().pds_last_error(None)
+
+
+def test_product_never_imports_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    pkg = os.path.join(ROOT, "phoenix-drone-simulation_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "phoenix_oracle" not in txt or f.endswith((".hip", ".h")) and "oracle/phoenix_oracle" in txt, f
+                assert "from oracle" not in txt and "import oracle" not in txt, f
+    out = subprocess.run(["nm", "-D", os.path.join(pkg, "libpds_hip.so")], capture_output=True, text=True).stdout
+    assert "po_" not in out
+
+
+def test_shard_range_partitions_exactly():
+    from phoenix_drone_simulation_amd import shard_range
+    for total, world in ((8388608, 8), (1000, 3), (7, 8), (1, 1)):
+        spans = [shard_range(total, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == total
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)
+
+
+_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+import phoenix_drone_simulation_amd as pds
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+total, D = {total}, 42
+a, b = pds.shard_range(total, rank, world)
+# each rank "observes" its global env ids; gathered tensor must be ordered by global env id
+obs = (torch.arange(a, b, dtype=torch.float32)[:, None] * 100 + torch.arange(D, dtype=torch.float32)[None])
+full = pds.all_gather_obs(obs)
+want = (torch.arange(total, dtype=torch.float32)[:, None] * 100 + torch.arange(D, dtype=torch.float32)[None])
+assert full.shape == (total, D) and torch.equal(full, want), rank
+from phoenix_drone_simulation_amd.sharding import max_over_ranks
+assert max_over_ranks(float(rank + 1), torch.device("cpu")) == float(world)
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+@pytest.mark.parametrize("total", [64, 65])
+def test_all_gather_obs_world2_gloo(total, tmp_path):
+    """N>1 path on CPU: 2 processes, gloo, equal and ragged shards."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT, total=total))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + total), WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"rank {r} ok" in o
