@@ -135,6 +135,13 @@ def main():
     value = total_envs * args.steps / wall
     bytes_per = env.bytes_per_env_step
     achieved = n * bytes_per / (kernel_ms * 1e-3) / 1e9
+    # HBM bytes per launch measured with the PMC counters (separate rocprofv3 passes,
+    # profiles/run_profile.sh) for exactly this workload; null for workloads that were not profiled
+    traffic = None
+    if args.config == 0 and task == "hover" and n == (1 << 20) and not args.no_auto_reset:
+        tf = os.path.join(ROOT, "profiles", "r01_traffic_headline.json")
+        if os.path.exists(tf):
+            traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
     if rank == 0:
         line = {
             "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
@@ -149,7 +156,7 @@ def main():
                        "parallelism": f"env-shard x{world}, no data-path collective" if gathered is None
                        else f"env-shard x{world} + all-gather(obs)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "pds::step_kernel", "avg_launch_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": n * bytes_per},
         }

@@ -14,5 +14,5 @@ ARGS="$REPO/bench.py --steps 100 --warmup 10 --no-cpu-baseline ${BENCH_ARGS:-}"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $ARGS > "$OUT/bench_trace.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 $ARGS > "$OUT/bench_pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 $ARGS > "$OUT/bench_pmc_write.log" 2>&1
-cd "$REPO" && python3 profiles/summarize.py "$OUT" > "$OUT/summary_$TAG.md" 2>&1
+cd "$REPO" && python3 profiles/summarize.py "$OUT" "$OUT/traffic_$TAG.json" > "$OUT/summary_$TAG.md" 2>&1
 cat "$OUT/summary_$TAG.md"
