@@ -98,12 +98,13 @@ enum pds_field {
   PDS_F_OU = 14,         /* 4  thrust_noise.state */
   PDS_F_GYRO_BIAS = 15,  /* 3  sensor_noise.gyro_bias */
   PDS_F_GYRO_LPF = 16,   /* 3  gyro_lpf._x */
-  PDS_F_COUNT_ = 17
+  PDS_F_NOISY_OBS = 17,  /* 10 observation_history[-1][0:10]: noisy xyz, quaternion, velocity */
+  PDS_F_COUNT_ = 18
 };
 
 /* Layout of one row of `d_samples` for pds_reset_from_samples (the values np.random returned in
  * the reference's draw order; see oracle/phoenix_oracle.h po_reset_sample). */
-#define PDS_SAMPLE_FLOATS 36
+#define PDS_SAMPLE_FLOATS 84
 #define PDS_S_POS_OFFSET 0 /* 3 */
 #define PDS_S_RPY 3        /* 3 */
 #define PDS_S_VEL 6        /* 3 */
@@ -118,6 +119,30 @@ enum pds_field {
 #define PDS_S_DR_T 27      /* 4 */
 #define PDS_S_DR_T2W 31    /* 4 */
 #define PDS_S_REF_OFFSET 35
+/* standard variates of the two SensorNoise.add_noise calls inside reset() (envs/base.py:419,429);
+ * each call: PDS_N_OBS_* layout below (24 floats).  Only read when observation_noise > 0. */
+#define PDS_S_NOISE_CALL0 36
+#define PDS_S_NOISE_CALL1 60
+
+/* Layout of one row of `d_variates` for pds_step_with_variates: the STANDARD variates (z ~ N(0,1),
+ * u ~ U[0,1)) one env.step() consumes, in the reference's draw order restricted to the draws whose
+ * value reaches the state or the observation (aggregate_phy_steps == 1):
+ *   OUNoise.noise (envs/utils.py:106) | first add_noise call (envs/base.py:464, only its gyro part
+ *   survives) | second add_noise call (envs/base.py:468 -> compute_history) */
+#define PDS_NOISE_FLOATS 37
+#define PDS_N_OU 0        /* 4 z */
+#define PDS_N_A_BIAS 4    /* 3 z  gyro bias random walk   (envs/sensors.py:130) */
+#define PDS_N_A_RW 7      /* 3 z  gyro_random_walk term   (envs/sensors.py:133) */
+#define PDS_N_A_TO 10     /* 3 z  turn-on-bias term       (envs/sensors.py:134) */
+#define PDS_N_OBS 13      /* second call, 24 floats: */
+#define PDS_N_OBS_POS_Z 0  /* 3 z */
+#define PDS_N_OBS_POS_U 3  /* 3 u */
+#define PDS_N_OBS_VEL_Z 6  /* 3 z */
+#define PDS_N_OBS_BIAS 9   /* 3 z */
+#define PDS_N_OBS_RW 12    /* 3 z */
+#define PDS_N_OBS_TO 15    /* 3 z */
+#define PDS_N_OBS_TH_Z 18  /* 3 z */
+#define PDS_N_OBS_TH_U 21  /* 3 u */
 
 int pds_version(void);
 
@@ -150,6 +175,13 @@ int pds_reset_from_samples(pds_handle *h, const uint8_t *d_mask, const float *d_
 int pds_step(pds_handle *h, const float *d_actions, float *d_obs, float *d_reward,
              uint8_t *d_terminated, uint8_t *d_truncated, float *d_cost, float *d_final_obs,
              void *stream);
+
+/* pds_step with the noise variates supplied by the caller (parity injection for the stochastic
+ * parts: OU thrust noise, SensorNoise): d_variates [N, PDS_NOISE_FLOATS].  The reference draws them
+ * from the global numpy stream (envs/utils.py:106, envs/sensors.py:84-134). */
+int pds_step_with_variates(pds_handle *h, const float *d_actions, const float *d_variates, float *d_obs,
+                           float *d_reward, uint8_t *d_terminated, uint8_t *d_truncated, float *d_cost,
+                           float *d_final_obs, void *stream);
 
 int pds_field_width(int field);
 int pds_get_state(pds_handle *h, int field, void *d_out, void *stream);

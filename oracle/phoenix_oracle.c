@@ -108,10 +108,10 @@ void po_default_config(int task, po_config *c) {
 /* Philox4x32-10 (Salmon et al., SC'11).  This is the in-kernel RNG of the NEW framework (the
  * reference uses the global numpy MT19937 stream, which cannot be reproduced for 2^20 lockstep
  * envs); the oracle restates it so the GPU reset sampling can be checked draw for draw. */
-void po_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+void po_philox4x32(const uint32_t ctr[4], const uint32_t key[2], int rounds, uint32_t out[4]) {
   uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
   uint32_t k0 = key[0], k1 = key[1];
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < rounds; ++r) {
     uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
     uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
@@ -122,6 +122,10 @@ void po_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+void po_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  po_philox4x32(ctr, key, 10, out);
 }
 
 int po_max_threads(void) {
@@ -690,6 +694,65 @@ void SUF(po_philox_reset_sample)(const po_config *c, uint64_t seed, uint64_t env
 #undef DRV
 }
 
+/* In-kernel NOISE streams of the new framework (Philox4x32-7; block ids as in csrc/pds_reset.h),
+ * laid out in the reference's numpy draw order so that the restated SensorNoise / OUNoise code
+ * above consumes them unchanged.  Draws whose value never reaches the state or the observation
+ * (position / velocity / angle noise of the discarded add_noise call, accelerometer noise) are not
+ * generated by the kernel; they are filled with neutral values here. */
+#define PO_BLK_RESET_NOISE 32u
+#define PO_BLK_OBS_NOISE 64u
+#define PO_BLK_SUB_NOISE 128u
+
+static void philox_words(uint64_t seed, uint64_t env_id, uint64_t tick, uint32_t blk0, int nblk, uint32_t *w) {
+  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  for (int b = 0; b < nblk; ++b) {
+    uint32_t ctr[4] = {(uint32_t)env_id, (uint32_t)tick, (uint32_t)(tick >> 32), blk0 + (uint32_t)b};
+    po_philox4x32(ctr, key, 7, w + 4 * b);
+  }
+}
+
+/* one add_noise call that reaches the observation: 6 blocks -> z[24] (numpy order: pos3 vel3 bias3
+ * rw3 to3 theta3 acc6), u[9] (pos3 vel3 theta3) */
+static void obs_call_streams(uint64_t seed, uint64_t env_id, uint64_t tick, uint32_t blk0, double *z, double *u) {
+  uint32_t w[24];
+  philox_words(seed, env_id, tick, blk0, 6, w);
+  REAL n[18];
+  for (int p = 0; p < 9; ++p) box_muller(w[2 * p], w[2 * p + 1], &n[2 * p], &n[2 * p + 1]);
+  /* kernel order: pos_z vel_z bias rw to th_z  == numpy order of the first 18 normals */
+  for (int i = 0; i < 18; ++i) z[i] = (double)n[i];
+  for (int i = 18; i < 24; ++i) z[i] = 0;
+  for (int i = 0; i < 3; ++i) { u[i] = (double)u01(w[18 + i]); u[3 + i] = 0.5; u[6 + i] = (double)u01(w[21 + i]); }
+}
+
+/* streams of one env.step() (aggregate_phy_steps sub-steps): per sub-step OU z4 + discarded call
+ * (z24, u9); then the observing call (z24, u9) */
+static void step_streams(const po_config *c, uint64_t seed, uint64_t env_id, uint64_t tick, double *z, double *u,
+                         int *nz, int *nu) {
+  int iz = 0, iu = 0;
+  const int on = c->observation_noise > 0;
+  for (int sub = 0; sub < c->aggregate_phy_steps; ++sub) {
+    uint32_t w[16];
+    philox_words(seed, env_id, tick, PO_BLK_SUB_NOISE + 4u * (uint32_t)sub, on ? 4 : 1, w);
+    REAL n[14];
+    for (int i = 0; i < 14; ++i) n[i] = 0;
+    box_muller(w[0], w[1], &n[0], &n[1]);
+    box_muller(w[2], w[3], &n[2], &n[3]);
+    if (on) for (int p = 2; p < 7; ++p) box_muller(w[2 * p], w[2 * p + 1], &n[2 * p], &n[2 * p + 1]);
+    for (int i = 0; i < 4; ++i) z[iz++] = (double)n[i];             /* OUNoise randn(4) */
+    if (on) {
+      for (int i = 0; i < 6; ++i) z[iz++] = 0;                      /* pos, vel (discarded) */
+      for (int i = 0; i < 9; ++i) z[iz++] = (double)n[4 + i];       /* bias, rw, turn-on */
+      for (int i = 0; i < 9; ++i) z[iz++] = 0;                      /* theta, acc (discarded) */
+      for (int i = 0; i < 9; ++i) u[iu++] = 0.5;
+    }
+  }
+  if (on) {
+    obs_call_streams(seed, env_id, tick, PO_BLK_OBS_NOISE, z + iz, u + iu);
+    iz += 24; iu += 9;
+  }
+  *nz = iz; *nu = iu;
+}
+
 /* Batched drivers (OpenMP over envs) -- the `cpu_baseline` leg of bench.py and the lockstep
  * auto-reset semantics the HIP path is compared with: an env that terminates or truncates in this
  * step hands its last observation to final_obs and is reset in the same call. */
@@ -702,7 +765,14 @@ void SUF(po_reset_batch)(const po_config *c, ENV *envs, int64_t n, REAL *obs, ui
   for (int64_t i = 0; i < n; ++i) {
     po_reset_sample s;
     SUF(po_philox_reset_sample)(c, seed, (uint64_t)i, tick, &s);
-    SUF(po_reset)(c, &envs[i], &s, 0, obs + i * D);
+    double z[48], u[18];
+    po_rng rng = {z, u, 0, 0, 0, 0};
+    if (c->observation_noise > 0) {
+      obs_call_streams(seed, (uint64_t)i, tick, PO_BLK_RESET_NOISE, z, u);
+      obs_call_streams(seed, (uint64_t)i, tick, PO_BLK_RESET_NOISE + 6u, z + 24, u + 9);
+      rng.nz = 48; rng.nu = 18;
+    }
+    SUF(po_reset)(c, &envs[i], &s, &rng, obs + i * D);
   }
   (void)nthreads;
 }
@@ -716,14 +786,28 @@ void SUF(po_step_batch)(const po_config *c, ENV *envs, int64_t n, const REAL *ac
 #endif
   for (int64_t i = 0; i < n; ++i) {
     int32_t term, trunc;
-    SUF(po_step)(c, &envs[i], actions + 4 * i, 0, obs + i * D, &reward[i], &term, &trunc, &cost[i]);
+    double z[4 * 28 + 24], u[4 * 9 + 9];
+    po_rng rng = {z, u, 0, 0, 0, 0};
+    if (c->observation_noise > 0 || c->motor_thrust_noise > 0) {
+      int nz = 0, nu = 0;
+      step_streams(c, seed, (uint64_t)i, tick, z, u, &nz, &nu);
+      rng.nz = nz; rng.nu = nu;
+    }
+    SUF(po_step)(c, &envs[i], actions + 4 * i, &rng, obs + i * D, &reward[i], &term, &trunc, &cost[i]);
     terminated[i] = (uint8_t)term;
     truncated[i] = (uint8_t)trunc;
     if (auto_reset && (term || trunc)) {
       if (final_obs) memcpy(final_obs + i * D, obs + i * D, sizeof(REAL) * D);
       po_reset_sample s;
       SUF(po_philox_reset_sample)(c, seed, (uint64_t)i, tick, &s);
-      SUF(po_reset)(c, &envs[i], &s, 0, obs + i * D);
+      double zr[48], ur[18];
+      po_rng rr = {zr, ur, 0, 0, 0, 0};
+      if (c->observation_noise > 0) {
+        obs_call_streams(seed, (uint64_t)i, tick, PO_BLK_RESET_NOISE, zr, ur);
+        obs_call_streams(seed, (uint64_t)i, tick, PO_BLK_RESET_NOISE + 6u, zr + 24, ur + 9);
+        rr.nz = 48; rr.nu = 18;
+      }
+      SUF(po_reset)(c, &envs[i], &s, &rr, obs + i * D);
     }
   }
   (void)nthreads;

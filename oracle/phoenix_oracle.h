@@ -122,6 +122,7 @@ PO_DECL(_f32, float)
 
 void po_default_config(int task, po_config *c);
 void po_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void po_philox4x32(const uint32_t ctr[4], const uint32_t key[2], int rounds, uint32_t out[4]);
 int po_max_threads(void);
 
 /* model constants (envs/assets/cf21x_sys_eq.urdf:10,16-17; envs/agents.py:142-156) */

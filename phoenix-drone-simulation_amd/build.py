@@ -1,13 +1,20 @@
-"""Build libpds_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Build libpds_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+Four translation units (the host API + one per task, each instantiating 32 step / 8 reset kernel
+variants) are compiled in parallel and linked into one shared library."""
+import concurrent.futures
 import os
 import shutil
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SRC = os.path.join(_HERE, "csrc", "pds_kernels.hip")
-_DEPS = [_SRC, os.path.join(_HERE, "csrc", "pds_device.h"),
-         os.path.join(_HERE, "..", "include", "pds.h")]
+_CSRC = os.path.join(_HERE, "csrc")
+_UNITS = ["pds_api.hip", "pds_task_hover.hip", "pds_task_circle.hip", "pds_task_takeoff.hip"]
+_HEADERS = ["pds_device.h", "pds_types.h", "pds_reset.h", "pds_step.h"]
+_DEPS = [os.path.join(_CSRC, f) for f in _UNITS + _HEADERS] + [os.path.join(_HERE, "..", "include", "pds.h")]
 _LIB = os.path.join(_HERE, "libpds_hip.so")
+_OBJ = os.path.join(_HERE, "build")
+_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"]
 
 
 def library_path():
@@ -15,24 +22,39 @@ def library_path():
     return os.environ.get("PDS_LIB", _LIB)
 
 
-def _stale():
-    if not os.path.exists(_LIB):
+def _stale(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(_LIB)
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in _DEPS)
+    t = os.path.getmtime(target)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -shared -fPIC csrc/pds_kernels.hip -> libpds_hip.so"""
-    if not force and not _stale():
-        return _LIB
+def build_library(force=False, verbose=False, extra_flags=(), out=None):
+    """hipcc --offload-arch=gfx950 -c csrc/*.hip (in parallel) -> link libpds_hip.so"""
+    out = out or _LIB
+    if not force and not extra_flags and not _stale(out, _DEPS):
+        return out
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libpds_hip.so (there is no CPU fallback)")
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",
-           "-o", _LIB + ".tmp", _SRC]
+    os.makedirs(_OBJ, exist_ok=True)
+    tag = "".join(c if c.isalnum() else "_" for c in "".join(extra_flags))
+    objs = [os.path.join(_OBJ, os.path.splitext(u)[0] + tag + ".o") for u in _UNITS]
+
+    def compile_unit(pair):
+        unit, obj = pair
+        if not force and not _stale(obj, _DEPS):
+            return
+        cmd = [hipcc] + _FLAGS + list(extra_flags) + ["-c", os.path.join(_CSRC, unit), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(compile_unit, zip(_UNITS, objs)))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out + ".tmp"] + objs
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    os.replace(_LIB + ".tmp", _LIB)
-    return _LIB
+    os.replace(out + ".tmp", out)
+    return out

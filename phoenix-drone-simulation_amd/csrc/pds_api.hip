@@ -1,0 +1,475 @@
+// pds_api.hip -- host side of libpds_hip.so: the C ABI of include/pds.h (+ the state pack/unpack
+// kernel behind pds_get_state / pds_set_state).  The fused step / reset kernels live in pds_step.h /
+// pds_reset.h and are instantiated per task in pds_task_{hover,circle,takeoff}.hip.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "pds_types.h"
+
+namespace pds {
+
+// ---- state access (parity injection, checkpointing) -------------------------------------------
+struct FieldArgs {
+  DevState st;
+  Consts k;
+  void *user;
+  long long n;
+  int field;
+  int parity;
+  int set;
+  int has_motor, has_dr, has_tn, has_on;
+};
+
+__global__ __launch_bounds__(kBlock) void field_kernel(const FieldArgs a) {
+  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= a.n) return;
+  float *uf = reinterpret_cast<float *>(a.user);
+  int32_t *ui = reinterpret_cast<int32_t *>(a.user);
+  float4 q0 = a.st.s0[i], q1 = a.st.s1[i], q2 = a.st.s2[i];
+  const uint32_t c = a.st.ctr[i];
+  switch (a.field) {
+    case PDS_F_POS:
+      if (a.set) { q0.x = uf[3 * i]; q0.y = uf[3 * i + 1]; q0.z = uf[3 * i + 2]; a.st.s0[i] = q0; }
+      else { uf[3 * i] = q0.x; uf[3 * i + 1] = q0.y; uf[3 * i + 2] = q0.z; }
+      break;
+    case PDS_F_VEL:
+      if (a.set) { q0.w = uf[3 * i]; q1.x = uf[3 * i + 1]; q1.y = uf[3 * i + 2]; a.st.s0[i] = q0; a.st.s1[i] = q1; }
+      else { uf[3 * i] = q0.w; uf[3 * i + 1] = q1.x; uf[3 * i + 2] = q1.y; }
+      break;
+    case PDS_F_RPY:
+      if (a.set) { q1.z = uf[3 * i]; q1.w = uf[3 * i + 1]; q2.x = uf[3 * i + 2]; a.st.s1[i] = q1; a.st.s2[i] = q2; }
+      else { uf[3 * i] = q1.z; uf[3 * i + 1] = q1.w; uf[3 * i + 2] = q2.x; }
+      break;
+    case PDS_F_OMEGA:
+      if (a.set) { q2.y = uf[3 * i]; q2.z = uf[3 * i + 1]; q2.w = uf[3 * i + 2]; a.st.s2[i] = q2; }
+      else { uf[3 * i] = q2.y; uf[3 * i + 1] = q2.z; uf[3 * i + 2] = q2.w; }
+      break;
+    case PDS_F_QUAT:
+      if (!a.set) {
+        const Quat q = quat_from_euler(q1.z, q1.w, q2.x);
+        const float sgn = ctr_sign(c) ? -1.f : 1.f;
+        uf[4 * i] = sgn * q.x; uf[4 * i + 1] = sgn * q.y; uf[4 * i + 2] = sgn * q.z; uf[4 * i + 3] = sgn * q.w;
+      }
+      break;
+    case PDS_F_MOTOR_X:
+    case PDS_F_LAST_ACTION:
+    case PDS_F_PREV_ACTION:
+    case PDS_F_MOTOR_A:
+    case PDS_F_MOTOR_K:
+    case PDS_F_OU: {
+      float4 *arr = nullptr;
+      float4 dflt = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a.field == PDS_F_MOTOR_X) arr = a.has_motor ? a.st.mx : nullptr;
+      else if (a.field == PDS_F_LAST_ACTION) arr = a.st.hist[a.parity];
+      else if (a.field == PDS_F_PREV_ACTION) arr = a.st.hist[a.parity ^ 1];
+      else if (a.field == PDS_F_OU) arr = a.has_tn ? a.st.ou : nullptr;
+      else if (a.field == PDS_F_MOTOR_A) { arr = (a.has_motor && a.has_dr) ? a.st.mA : nullptr; dflt = make_float4(a.k.A, a.k.A, a.k.A, a.k.A); }
+      else { arr = (a.has_motor && a.has_dr) ? a.st.mK : nullptr; dflt = make_float4(a.k.K, a.k.K, a.k.K, a.k.K); }
+      if (a.set) { if (arr) arr[i] = make_float4(uf[4 * i], uf[4 * i + 1], uf[4 * i + 2], uf[4 * i + 3]); }
+      else { const float4 v = arr ? arr[i] : dflt; uf[4 * i] = v.x; uf[4 * i + 1] = v.y; uf[4 * i + 2] = v.z; uf[4 * i + 3] = v.w; }
+      break;
+    }
+    case PDS_F_STEP_COUNT:
+      if (a.set) a.st.ctr[i] = ctr_pack((uint32_t)ui[i] & 0xFFFFu, ctr_sign(c), ctr_off(c));
+      else ui[i] = (int32_t)ctr_step(c);
+      break;
+    case PDS_F_QUAT_SIGN:
+      if (a.set) a.st.ctr[i] = ctr_pack(ctr_step(c), ui[i] ? 1u : 0u, ctr_off(c));
+      else ui[i] = (int32_t)ctr_sign(c);
+      break;
+    case PDS_F_REF_OFFSET:
+      if (a.set) a.st.ctr[i] = ctr_pack(ctr_step(c), ctr_sign(c), (uint32_t)ui[i] % 300u);
+      else ui[i] = (int32_t)ctr_off(c);
+      break;
+    case PDS_F_PARAMS:
+      if (a.has_dr) {
+        if (a.set) {
+          a.st.par0[i] = make_float4(uf[6 * i], uf[6 * i + 1], uf[6 * i + 2], uf[6 * i + 3]);
+          a.st.par1[i] = make_float2(uf[6 * i + 4], uf[6 * i + 5]);
+        } else {
+          const float4 p0 = a.st.par0[i]; const float2 p1 = a.st.par1[i];
+          uf[6 * i] = p0.x; uf[6 * i + 1] = p0.y; uf[6 * i + 2] = p0.z; uf[6 * i + 3] = p0.w; uf[6 * i + 4] = p1.x; uf[6 * i + 5] = p1.y;
+        }
+      } else if (!a.set) {
+        uf[6 * i] = a.k.dt; uf[6 * i + 1] = a.k.m; uf[6 * i + 2] = a.k.Jx; uf[6 * i + 3] = a.k.Jy; uf[6 * i + 4] = a.k.Jz; uf[6 * i + 5] = a.k.ftf1;
+      }
+      break;
+    case PDS_F_GYRO_BIAS:
+    case PDS_F_GYRO_LPF:
+      if (a.has_on) {
+        float4 n0 = a.st.nz0[i]; float2 n1 = a.st.nz1[i];
+        if (a.field == PDS_F_GYRO_BIAS) {
+          if (a.set) { n0.x = uf[3 * i]; n0.y = uf[3 * i + 1]; n0.z = uf[3 * i + 2]; a.st.nz0[i] = n0; }
+          else { uf[3 * i] = n0.x; uf[3 * i + 1] = n0.y; uf[3 * i + 2] = n0.z; }
+        } else {
+          if (a.set) { n0.w = uf[3 * i]; n1.x = uf[3 * i + 1]; n1.y = uf[3 * i + 2]; a.st.nz0[i] = n0; a.st.nz1[i] = n1; }
+          else { uf[3 * i] = n0.w; uf[3 * i + 1] = n1.x; uf[3 * i + 2] = n1.y; }
+        }
+      } else if (!a.set) { uf[3 * i] = 0.f; uf[3 * i + 1] = 0.f; uf[3 * i + 2] = 0.f; }
+      break;
+    case PDS_F_NOISY_OBS:
+      if (a.has_on) {
+        if (a.set) {
+          a.st.oh0[i] = make_float4(uf[10 * i], uf[10 * i + 1], uf[10 * i + 2], uf[10 * i + 3]);
+          a.st.oh1[i] = make_float4(uf[10 * i + 4], uf[10 * i + 5], uf[10 * i + 6], uf[10 * i + 7]);
+          a.st.oh2[i] = make_float2(uf[10 * i + 8], uf[10 * i + 9]);
+        } else {
+          const float4 o0 = a.st.oh0[i], o1 = a.st.oh1[i]; const float2 o2 = a.st.oh2[i];
+          uf[10 * i] = o0.x; uf[10 * i + 1] = o0.y; uf[10 * i + 2] = o0.z; uf[10 * i + 3] = o0.w;
+          uf[10 * i + 4] = o1.x; uf[10 * i + 5] = o1.y; uf[10 * i + 6] = o1.z; uf[10 * i + 7] = o1.w;
+          uf[10 * i + 8] = o2.x; uf[10 * i + 9] = o2.y;
+        }
+      } else if (!a.set) {
+        for (int j = 0; j < 10; ++j) uf[10 * i + j] = 0.f;
+      }
+      break;
+    default: break;
+  }
+}
+
+}  // namespace pds
+
+// =================================================================================================
+// the C ABI of include/pds.h
+// =================================================================================================
+using namespace pds;
+
+struct pds_handle {
+  pds_config cfg;
+  DevState st;
+  Consts k;
+  LaunchFlags flags;
+  float2 *d_circle_ref;
+  int obs_dim;
+  int num_cus;
+  long long grid_override;
+  int parity;
+  uint64_t tick;
+  bool was_reset;
+  char err[512];
+};
+
+static int fail(pds_handle *h, int code, const char *fmt, ...) {
+  if (h) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(h->err, sizeof(h->err), fmt, ap);
+    va_end(ap);
+  }
+  return code;
+}
+
+static thread_local char g_create_err[512] = "";
+
+#define PDS_HIP(h, call)                                                                        \
+  do {                                                                                          \
+    hipError_t e_ = (call);                                                                     \
+    if (e_ != hipSuccess) return fail(h, PDS_EHIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+extern "C" int pds_version(void) { return PDS_VERSION; }
+
+// ctor defaults: envs/base.py:26-48, envs/hover.py:7-45, envs/circle.py:7-61, envs/takeoff.py:13-56
+extern "C" int pds_default_config(int task, pds_config *c) {
+  if (!c || task < 0 || task > 2) return PDS_EINVAL;
+  memset(c, 0, sizeof(*c));
+  c->struct_size = (int32_t)sizeof(pds_config);
+  c->task = task;
+  c->num_envs = 1;
+  c->env_id_base = 0;
+  c->seed = 0;
+  c->device = 0;
+  c->use_motor_dynamics = 0;
+  c->use_ground_effect = 0;
+  c->observation_noise = 1;
+  c->aggregate_phy_steps = 1;
+  c->enable_reset_distribution = 1;
+  c->max_episode_steps = 500;
+  c->auto_reset = 1;
+  c->domain_randomization = 0.10;
+  c->motor_thrust_noise = 0.05;
+  c->time_step = 1.0 / 100.0;
+  c->motor_time_constant = 0.080;
+  c->penalty_action = 1e-4;
+  c->penalty_angle = 0.0;
+  c->penalty_spin = (task == PDS_TASK_CIRCLE) ? 1e-3 : 1e-4;
+  c->penalty_terminal = 100.0;
+  c->penalty_velocity = (task == PDS_TASK_CIRCLE) ? 1e-4 : 0.0;
+  c->ARP = (task == PDS_TASK_CIRCLE) ? 1e-3 : 0.0;
+  c->target_pos[2] = 1.0;
+  c->init_xyz[2] = (task == PDS_TASK_TAKEOFF) ? (double)0.0125f : 1.0;
+  return PDS_OK;
+}
+
+static void fill_consts(const pds_config &c, Consts &k) {
+  // envs/assets/cf21x_sys_eq.urdf:10,16-17 and envs/agents.py:138-156
+  const double M = 0.027, L = 0.0397, T2W = 2.25, IXX = 1.7e-5, IYY = 1.7e-5, IZZ = 2.9e-5;
+  const double KF = 3.16e-10, GEC = 11.36859, PR = 2.31348e-2, FTF1 = 5.96e-3, G = 9.81;
+  const double MAX_THRUST = G * M * T2W / 4;
+  const double MAX_RPM = sqrt((T2W * G * M) / (4 * MAX_THRUST));
+  memset(&k, 0, sizeof(k));
+  k.K = (float)MAX_THRUST; k.G = (float)G; k.m = (float)M;
+  k.Jx = (float)IXX; k.Jy = (float)IYY; k.Jz = (float)IZZ; k.ftf1 = (float)FTF1;
+  k.Lq = (float)(L / sqrt(2.0));
+  k.dt = (float)c.time_step;
+  k.A = (float)(1.0 - c.time_step / c.motor_time_constant);
+  k.hover_x = (float)sqrt(1 / T2W);
+  k.hover_action = (float)(2 * 1 / T2W - 1);
+  k.gec = (float)GEC; k.prop_r = (float)PR;
+  k.h_clip = (float)(0.25 * PR * sqrt((15 * MAX_RPM * MAX_RPM * KF * GEC) / MAX_THRUST));
+  k.t2w = (float)T2W; k.mtc = (float)c.motor_time_constant;
+  k.M_nom = (float)M; k.Jx_nom = (float)IXX; k.Jy_nom = (float)IYY; k.Jz_nom = (float)IZZ;
+  k.ftf1_nom = (float)FTF1; k.dt_nom = (float)c.time_step;
+  k.pa = (float)c.penalty_action; k.pang = (float)c.penalty_angle; k.pspin = (float)c.penalty_spin;
+  k.pterm = (float)c.penalty_terminal; k.pvel = (float)c.penalty_velocity; k.arp = (float)c.ARP;
+  for (int i = 0; i < 3; ++i) {
+    k.target[i] = (float)c.target_pos[i];
+    k.init_xyz[i] = (float)c.init_xyz[i]; k.init_rpy[i] = (float)c.init_rpy[i];
+    k.init_vel[i] = (float)c.init_xyz_dot[i]; k.init_w[i] = (float)c.init_rpy_dot[i];
+  }
+  k.dr = (float)(c.domain_randomization > 0 ? c.domain_randomization : 0.0);
+  // OUNoise(sigma = 0.2 * motor_thrust_noise), envs/agents.py:206
+  k.ou_sigma = (float)(0.2 * (c.motor_thrust_noise > 0 ? c.motor_thrust_noise : 0.0));
+  // SensorNoise defaults, envs/sensors.py:14-23; gyro model envs/sensors.py:124-128 with
+  // dt = 1/sim_freq (envs/hover.py:143)
+  const double D2R = M_PI / 180.0, dt = c.time_step;
+  k.pos_std = 0.002f; k.pos_unif = 0.001f; k.vel_std = 0.01f;
+  k.q_std = (float)(0.1 * D2R); k.q_unif = (float)(0.05 * D2R);
+  const double gnd = 0.000175, corr = 1000.0;
+  const double sigma_g_d = gnd / sqrt(dt);
+  k.gyro_sb = (float)sqrt(-(sigma_g_d * sigma_g_d) * (corr / 2) * (exp(-2 * dt / corr) - 1));
+  k.gyro_pi = (float)exp(-dt / corr);
+  k.gyro_rw = 0.0105f;
+  k.gyro_to = (float)(5 * D2R);
+  k.agg = c.aggregate_phy_steps; k.max_steps = c.max_episode_steps;
+  k.reset_dist = c.enable_reset_distribution ? 1 : 0;
+}
+
+static int obs_dim_of(const pds_config &c) {
+  const bool noisy = c.observation_noise > 0;
+  const int o = noisy ? (c.task == PDS_TASK_HOVER ? 13 : (c.task == PDS_TASK_CIRCLE ? 16 : 20))
+                      : (c.task == PDS_TASK_HOVER ? 17 : (c.task == PDS_TASK_CIRCLE ? 16 : 20));
+  return 2 * (o + 4);
+}
+
+extern "C" int pds_create(const pds_config *cfg, pds_handle **out) {
+  if (!cfg || !out) return PDS_EINVAL;
+  *out = nullptr;
+  if (cfg->struct_size != (int32_t)sizeof(pds_config)) { snprintf(g_create_err, sizeof(g_create_err), "pds_config size mismatch"); return PDS_EINVAL; }
+  if (cfg->task < 0 || cfg->task > 2 || cfg->num_envs < 1 || cfg->aggregate_phy_steps < 1 ||
+      cfg->max_episode_steps < 1 || cfg->max_episode_steps > 65535 || cfg->time_step <= 0 ||
+      cfg->num_envs > (1ll << 23)) {  // env index + ref_offset share a 32-bit reset-queue word
+    snprintf(g_create_err, sizeof(g_create_err), "invalid pds_config");
+    return PDS_EINVAL;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device >= ndev) {
+    snprintf(g_create_err, sizeof(g_create_err), "no HIP device %d (found %d); there is no CPU fallback", cfg->device, ndev);
+    return PDS_ENODEVICE;
+  }
+  pds_handle *h = new (std::nothrow) pds_handle();
+  if (!h) return PDS_ENOMEM;
+  memset(h, 0, sizeof(*h));
+  h->cfg = *cfg;
+  fill_consts(*cfg, h->k);
+  h->obs_dim = obs_dim_of(*cfg);
+  h->flags.motor = cfg->use_motor_dynamics != 0;
+  h->flags.dr = cfg->domain_randomization > 0;
+  h->flags.ge = cfg->use_ground_effect != 0;
+  h->flags.tn = cfg->motor_thrust_noise > 0;
+  h->flags.on = cfg->observation_noise > 0;
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess || cus <= 0) cus = 256;
+    h->num_cus = cus;
+    const char *g = getenv("PDS_GRID_BLOCKS");
+    h->grid_override = g ? atoll(g) : 0;
+  }
+  const size_t n = (size_t)cfg->num_envs;
+  const LaunchFlags &f = h->flags;
+  hipError_t e = hipSetDevice(cfg->device);
+  auto alloc = [&](void **p, size_t bytes) { if (e == hipSuccess) { e = hipMalloc(p, bytes); if (e == hipSuccess) e = hipMemset(*p, 0, bytes); } };
+  alloc((void **)&h->st.s0, n * 16); alloc((void **)&h->st.s1, n * 16); alloc((void **)&h->st.s2, n * 16);
+  alloc((void **)&h->st.hist[0], n * 16); alloc((void **)&h->st.hist[1], n * 16);
+  alloc((void **)&h->st.ctr, n * 4);
+  if (f.motor) alloc((void **)&h->st.mx, n * 16);
+  if (f.dr) { alloc((void **)&h->st.par0, n * 16); alloc((void **)&h->st.par1, n * 8); }
+  if (f.dr && f.motor) { alloc((void **)&h->st.mA, n * 16); alloc((void **)&h->st.mK, n * 16); }
+  if (f.tn) alloc((void **)&h->st.ou, n * 16);
+  if (f.on) {
+    alloc((void **)&h->st.nz0, n * 16); alloc((void **)&h->st.nz1, n * 8);
+    alloc((void **)&h->st.oh0, n * 16); alloc((void **)&h->st.oh1, n * 16); alloc((void **)&h->st.oh2, n * 8);
+  }
+  alloc((void **)&h->d_circle_ref, kRefPoints * sizeof(float2));
+  if (e == hipSuccess) {
+    float2 ref[kRefPoints];  // envs/circle.py:45-56
+    for (int t = 0; t < kRefPoints; ++t) {
+      const double ts = 2 * M_PI * (double)t / kRefPoints;
+      ref[t].x = (float)(0.25 * (1 - cos(ts)));
+      ref[t].y = (float)(0.25 * sin(ts));
+    }
+    e = hipMemcpy(h->d_circle_ref, ref, sizeof(ref), hipMemcpyHostToDevice);
+  }
+  h->st.circle_ref = h->d_circle_ref;
+  if (e != hipSuccess) {
+    snprintf(g_create_err, sizeof(g_create_err), "allocation of %zu envs failed: %s", n, hipGetErrorString(e));
+    pds_destroy(h);
+    return e == hipErrorOutOfMemory ? PDS_ENOMEM : PDS_EHIP;
+  }
+  *out = h;
+  return PDS_OK;
+}
+
+extern "C" int pds_destroy(pds_handle *h) {
+  if (!h) return PDS_OK;
+  (void)hipSetDevice(h->cfg.device);
+  void *ptrs[] = {h->st.s0, h->st.s1, h->st.s2, h->st.hist[0], h->st.hist[1], h->st.ctr, h->st.mx,
+                  h->st.par0, h->st.par1, h->st.mA, h->st.mK, h->st.ou, h->st.nz0, h->st.nz1,
+                  h->st.oh0, h->st.oh1, h->st.oh2, h->d_circle_ref};
+  for (void *p : ptrs) if (p) (void)hipFree(p);
+  delete h;
+  return PDS_OK;
+}
+
+extern "C" int pds_obs_dim(const pds_handle *h) { return h ? h->obs_dim : PDS_EINVAL; }
+extern "C" int64_t pds_num_envs(const pds_handle *h) { return h ? h->cfg.num_envs : PDS_EINVAL; }
+extern "C" uint64_t pds_tick(const pds_handle *h) { return h ? h->tick : 0; }
+extern "C" const char *pds_last_error(const pds_handle *h) { return h ? h->err : g_create_err; }
+
+// read action 16 + dyn state 48 + action history 32 + counter 4; write dyn state 48
+// + newest history slot 16 + counter 4 + reward 4 + cost 4 + terminated 1 + truncated 1; obs 4*D;
+// DR params +24; motor PT1: x R+W 32 (+ A, K 32 when randomised); OU state R+W 32; gyro bias +
+// low-pass R+W 48; kept noisy observation (10 floats) R+W 80.
+extern "C" int pds_bytes_per_env_step(const pds_handle *h) {
+  if (!h) return PDS_EINVAL;
+  int b = 100 + 78 + 4 * h->obs_dim;
+  const LaunchFlags &f = h->flags;
+  if (f.dr) b += 24;
+  if (f.motor) b += 32;
+  if (f.motor && f.dr) b += 32;
+  if (f.tn) b += 32;
+  if (f.on) b += 48 + 80;
+  return b;
+}
+
+static void base_args(pds_handle *h, StepArgs &a) {
+  memset(&a, 0, sizeof(a));
+  a.st = h->st;
+  a.k = h->k;
+  a.n = h->cfg.num_envs;
+  a.env_id_base = (unsigned long long)h->cfg.env_id_base;
+  a.seed_lo = (uint32_t)h->cfg.seed; a.seed_hi = (uint32_t)(h->cfg.seed >> 32);
+  a.tick_lo = (uint32_t)h->tick; a.tick_hi = (uint32_t)(h->tick >> 32);
+  a.parity = h->parity;
+  a.auto_reset = h->cfg.auto_reset;
+}
+
+static int do_reset(pds_handle *h, const uint8_t *d_mask, const float *d_samples, float *d_obs, void *stream) {
+  if (!h) return PDS_EINVAL;
+  PDS_HIP(h, hipSetDevice(h->cfg.device));
+  StepArgs a;
+  base_args(h, a);
+  a.mask = d_mask; a.samples = d_samples; a.obs = d_obs;
+  const dim3 grid((unsigned)((a.n + kBlock - 1) / kBlock));
+  hipStream_t s = (hipStream_t)stream;
+  switch (h->cfg.task) {
+    case PDS_TASK_HOVER: launch_reset_hover(h->flags, grid, s, a); break;
+    case PDS_TASK_CIRCLE: launch_reset_circle(h->flags, grid, s, a); break;
+    default: launch_reset_takeoff(h->flags, grid, s, a); break;
+  }
+  PDS_HIP(h, hipGetLastError());
+  h->tick += 1;
+  h->was_reset = true;
+  return PDS_OK;
+}
+
+extern "C" int pds_reset(pds_handle *h, const uint8_t *d_mask, float *d_obs, void *stream) {
+  return do_reset(h, d_mask, nullptr, d_obs, stream);
+}
+
+extern "C" int pds_reset_from_samples(pds_handle *h, const uint8_t *d_mask, const float *d_samples,
+                                      float *d_obs, void *stream) {
+  if (h && !d_samples) return fail(h, PDS_EINVAL, "pds_reset_from_samples: d_samples is NULL");
+  return do_reset(h, d_mask, d_samples, d_obs, stream);
+}
+
+extern "C" int pds_step_with_variates(pds_handle *h, const float *d_actions, const float *d_variates,
+                                      float *d_obs, float *d_reward, uint8_t *d_terminated,
+                                      uint8_t *d_truncated, float *d_cost, float *d_final_obs, void *stream) {
+  if (!h) return PDS_EINVAL;
+  if (!d_actions || !d_obs || !d_reward || !d_terminated || !d_truncated || !d_cost)
+    return fail(h, PDS_EINVAL, "pds_step: NULL tensor pointer");
+  if ((((uintptr_t)d_actions) | ((uintptr_t)d_obs)) & 15u)
+    return fail(h, PDS_EINVAL, "pds_step: d_actions and d_obs must be 16-byte aligned");
+  if (!h->was_reset) return fail(h, PDS_EINVAL, "pds_step before pds_reset");
+  if (d_variates && h->cfg.aggregate_phy_steps != 1)
+    return fail(h, PDS_EUNSUPPORTED, "injected noise variates need aggregate_phy_steps == 1");
+  PDS_HIP(h, hipSetDevice(h->cfg.device));
+  StepArgs a;
+  base_args(h, a);
+  a.actions = reinterpret_cast<const float4 *>(d_actions);
+  a.obs = d_obs; a.reward = d_reward; a.term = d_terminated; a.trunc = d_truncated; a.cost = d_cost;
+  a.final_obs = d_final_obs;
+  a.noise = d_variates;
+  // default: one 256-env block per 4 tiles (the hardware dispatcher balances blocks whose
+  // deferred-reset drains have different lengths; measured faster than a resident grid).
+  // PDS_GRID_BLOCKS caps the grid (the kernel is a grid-stride loop): tuning knob.
+  const long long blocks_needed = (a.n + kBlock - 1) / kBlock;
+  long long blocks = blocks_needed;
+  if (h->grid_override > 0 && h->grid_override < blocks) blocks = h->grid_override;
+  const dim3 grid((unsigned)blocks);
+  hipStream_t s = (hipStream_t)stream;
+  switch (h->cfg.task) {
+    case PDS_TASK_HOVER: launch_step_hover(h->flags, grid, s, a); break;
+    case PDS_TASK_CIRCLE: launch_step_circle(h->flags, grid, s, a); break;
+    default: launch_step_takeoff(h->flags, grid, s, a); break;
+  }
+  PDS_HIP(h, hipGetLastError());
+  h->parity ^= 1;
+  h->tick += 1;
+  return PDS_OK;
+}
+
+extern "C" int pds_step(pds_handle *h, const float *d_actions, float *d_obs, float *d_reward,
+                        uint8_t *d_terminated, uint8_t *d_truncated, float *d_cost, float *d_final_obs,
+                        void *stream) {
+  return pds_step_with_variates(h, d_actions, nullptr, d_obs, d_reward, d_terminated, d_truncated, d_cost,
+                                d_final_obs, stream);
+}
+
+extern "C" int pds_field_width(int field) {
+  switch (field) {
+    case PDS_F_POS: case PDS_F_RPY: case PDS_F_VEL: case PDS_F_OMEGA: case PDS_F_GYRO_BIAS: case PDS_F_GYRO_LPF: return 3;
+    case PDS_F_QUAT: case PDS_F_MOTOR_X: case PDS_F_LAST_ACTION: case PDS_F_PREV_ACTION: case PDS_F_MOTOR_A:
+    case PDS_F_MOTOR_K: case PDS_F_OU: return 4;
+    case PDS_F_STEP_COUNT: case PDS_F_QUAT_SIGN: case PDS_F_REF_OFFSET: return 1;
+    case PDS_F_PARAMS: return 6;
+    case PDS_F_NOISY_OBS: return 10;
+    default: return PDS_EINVAL;
+  }
+}
+
+static int do_field(pds_handle *h, int field, void *d_ptr, int set, void *stream) {
+  if (!h) return PDS_EINVAL;
+  if (!d_ptr || pds_field_width(field) < 0) return fail(h, PDS_EINVAL, "bad field %d or NULL pointer", field);
+  if (set && field == PDS_F_QUAT) return fail(h, PDS_EINVAL, "PDS_F_QUAT is derived (set PDS_F_RPY / PDS_F_QUAT_SIGN)");
+  PDS_HIP(h, hipSetDevice(h->cfg.device));
+  FieldArgs a;
+  memset(&a, 0, sizeof(a));
+  a.st = h->st; a.k = h->k; a.user = d_ptr; a.n = h->cfg.num_envs; a.field = field; a.parity = h->parity; a.set = set;
+  a.has_motor = h->flags.motor; a.has_dr = h->flags.dr; a.has_tn = h->flags.tn; a.has_on = h->flags.on;
+  const dim3 grid((unsigned)((a.n + kBlock - 1) / kBlock));
+  hipLaunchKernelGGL(field_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, a);
+  PDS_HIP(h, hipGetLastError());
+  if (set) h->was_reset = true;
+  return PDS_OK;
+}
+
+extern "C" int pds_get_state(pds_handle *h, int field, void *d_out, void *stream) { return do_field(h, field, d_out, 0, stream); }
+extern "C" int pds_set_state(pds_handle *h, int field, const void *d_in, void *stream) { return do_field(h, field, const_cast<void *>(d_in), 1, stream); }

@@ -97,9 +97,10 @@ PDS_DEV void euler_from_quat(const Quat q, float &roll, float &pitch, float &yaw
 // CPU by oracle/phoenix_oracle.c po_philox4x32_10 / po_philox_reset_sample.
 struct U4 { uint32_t x, y, z, w; };
 
-PDS_DEV U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+template <int ROUNDS>
+PDS_DEV U4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < ROUNDS; ++r) {
     const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
     const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
     const uint32_t n0 = hi1 ^ c1 ^ k0;
@@ -108,6 +109,16 @@ PDS_DEV U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uin
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
   return U4{c0, c1, c2, c3};
+}
+
+// reset sampling: the standard 10 rounds
+PDS_DEV U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+  return philox4x32<10>(c0, c1, c2, c3, k0, k1);
+}
+// per-step sensor / thrust noise (10 blocks per env-step): 7 rounds, the smallest Philox4x32 variant
+// that passes BigCrush (Salmon et al., SC'11, table 2)
+PDS_DEV U4 philox4x32_7(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+  return philox4x32<7>(c0, c1, c2, c3, k0, k1);
 }
 
 PDS_DEV float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }

@@ -1,0 +1,441 @@
+// pds_reset.h -- sampling, sensor-noise and reset device functions (gfx950 only).
+//
+// Reference (paths relative to phoenix_drone_simulation/): envs/base.py:239-296,382-431,
+// envs/hover.py:192-243, envs/circle.py:213-277, envs/takeoff.py:179-212, envs/agents.py:208-224,
+// 377-386,434-453, envs/sensors.py:75-134, envs/utils.py:59-108.
+#pragma once
+#include "pds_types.h"
+
+namespace pds {
+
+// Philox block ids (counter word 3) -- the RNG contract restated by oracle/phoenix_oracle.c
+constexpr uint32_t kBlkReset = 0;        // 0..8   reset distribution + domain randomisation (10 rounds)
+constexpr uint32_t kBlkResetNoise = 32;  // 32..43 two add_noise calls inside reset (7 rounds)
+constexpr uint32_t kBlkObsNoise = 64;    // 64..69 the add_noise call that produces o(k+1) (7 rounds)
+constexpr uint32_t kBlkSubNoise = 128;   // 128+4*sub+{0..3}: OU + the discarded add_noise call (7 rounds)
+
+// In-kernel reset sampler; restated draw for draw by oracle/phoenix_oracle.c
+// po_philox_reset_sample.  Ranges: envs/hover.py:201-228, envs/circle.py:225-257,
+// envs/takeoff.py:186-191, envs/base.py:250-287.
+template <class V>
+PDS_DEV void sample_philox(const Consts &k, uint32_t env_id, const StepArgs &a, Sample &s) {
+  constexpr int TASK = V::TASK;
+  constexpr float D2R = kPi / 180.f;
+  float pos_lim, rp_lim, yaw_lim, vel_lim, w_lim, wz_lim;
+  if (TASK == PDS_TASK_HOVER) {
+    pos_lim = 0.25f; rp_lim = kPi / 6.f; yaw_lim = 2.f * kPi; vel_lim = 0.1f; w_lim = 200.f * D2R; wz_lim = 20.f * D2R;
+  } else if (TASK == PDS_TASK_CIRCLE) {
+    pos_lim = 0.05f; rp_lim = 20.f * D2R; yaw_lim = 0.1f * kPi; vel_lim = 0.1f; w_lim = 50.f * D2R; wz_lim = 20.f * D2R;
+  } else {
+    pos_lim = 0.25f; rp_lim = 0.f; yaw_lim = kPi; vel_lim = 0.f; w_lim = 0.f; wz_lim = 0.f;
+  }
+  const U4 r0 = philox4x32_10(env_id, a.tick_lo, a.tick_hi, 0u, a.seed_lo, a.seed_hi);
+  const U4 r1 = philox4x32_10(env_id, a.tick_lo, a.tick_hi, 1u, a.seed_lo, a.seed_hi);
+  s.pos[0] = urange(r0.x, -pos_lim, pos_lim);
+  s.pos[1] = urange(r0.y, -pos_lim, pos_lim);
+  s.pos[2] = (TASK == PDS_TASK_TAKEOFF) ? 0.f : urange(r0.z, -pos_lim, pos_lim);
+  s.rpy[0] = urange(r0.w, -rp_lim, rp_lim);
+  s.rpy[1] = urange(r1.x, -rp_lim, rp_lim);
+  s.rpy[2] = urange(r1.y, -yaw_lim, yaw_lim);
+  s.vel[0] = urange(r1.z, -vel_lim, vel_lim);
+  s.vel[1] = urange(r1.w, -vel_lim, vel_lim);
+  if (TASK != PDS_TASK_TAKEOFF) {
+    const U4 r2 = philox4x32_10(env_id, a.tick_lo, a.tick_hi, 2u, a.seed_lo, a.seed_hi);
+    const U4 r3 = philox4x32_10(env_id, a.tick_lo, a.tick_hi, 3u, a.seed_lo, a.seed_hi);
+    const U4 r4 = philox4x32_10(env_id, a.tick_lo, a.tick_hi, 4u, a.seed_lo, a.seed_hi);
+    s.vel[2] = urange(r2.x, -vel_lim, vel_lim);
+    s.w[0] = urange(r2.y, -w_lim, w_lim);
+    s.w[1] = urange(r2.z, -w_lim, w_lim);
+    s.w[2] = urange(r2.w, -wz_lim, wz_lim);
+    float z[8];
+    box_muller(r3.x, r3.y, z[0], z[1]);
+    box_muller(r3.z, r3.w, z[2], z[3]);
+    box_muller(r4.x, r4.y, z[4], z[5]);
+    box_muller(r4.z, r4.w, z[6], z[7]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s.mx[i] = k.hover_x + 0.02f * z[i];
+      s.act[i] = k.hover_action + 0.02f * z[4 + i];
+    }
+  } else {
+    s.vel[2] = 0.f; s.w[0] = s.w[1] = s.w[2] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s.mx[i] = 0.f; s.act[i] = 0.f; }
+  }
+  s.ref_offset = 0;
+  if (V::DR || TASK == PDS_TASK_CIRCLE) {
+    const float f = k.dr;
+    const U4 r5 = philox4x32_10(env_id, a.tick_lo, a.tick_hi, 5u, a.seed_lo, a.seed_hi);
+    const U4 r6 = philox4x32_10(env_id, a.tick_lo, a.tick_hi, 6u, a.seed_lo, a.seed_hi);
+#define PDS_DRV(x, d) urange((x), (d) - f * (d), (d) + f * (d))
+    s.dt = PDS_DRV(r5.x, k.dt_nom);
+    s.m = PDS_DRV(r5.y, k.M_nom);
+    s.J[0] = PDS_DRV(r5.z, k.Jx_nom);
+    s.J[1] = PDS_DRV(r5.w, k.Jy_nom);
+    s.J[2] = PDS_DRV(r6.x, k.Jz_nom);
+    s.ftf1 = PDS_DRV(r6.z, k.ftf1_nom);
+    s.ref_offset = (int)__umulhi(r6.w, 300u);
+    if (V::MOTOR && V::DR) {
+      const U4 r7 = philox4x32_10(env_id, a.tick_lo, a.tick_hi, 7u, a.seed_lo, a.seed_hi);
+      const U4 r8 = philox4x32_10(env_id, a.tick_lo, a.tick_hi, 8u, a.seed_lo, a.seed_hi);
+      s.T[0] = PDS_DRV(r7.x, k.mtc); s.T[1] = PDS_DRV(r7.y, k.mtc);
+      s.T[2] = PDS_DRV(r7.z, k.mtc); s.T[3] = PDS_DRV(r7.w, k.mtc);
+      s.t2w[0] = PDS_DRV(r8.x, k.t2w); s.t2w[1] = PDS_DRV(r8.y, k.t2w);
+      s.t2w[2] = PDS_DRV(r8.z, k.t2w); s.t2w[3] = PDS_DRV(r8.w, k.t2w);
+    }
+#undef PDS_DRV
+  }
+}
+
+PDS_DEV void sample_load(const float *row, Sample &s) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    s.pos[i] = row[PDS_S_POS_OFFSET + i]; s.rpy[i] = row[PDS_S_RPY + i];
+    s.vel[i] = row[PDS_S_VEL + i]; s.w[i] = row[PDS_S_OMEGA + i]; s.J[i] = row[PDS_S_DR_J + i];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    s.mx[i] = row[PDS_S_MOTOR_X + i]; s.act[i] = row[PDS_S_ACTION + i];
+    s.T[i] = row[PDS_S_DR_T + i]; s.t2w[i] = row[PDS_S_DR_T2W + i];
+  }
+  s.dt = row[PDS_S_DR_DT]; s.m = row[PDS_S_DR_M]; s.ftf1 = row[PDS_S_DR_FTF1];
+  s.ref_offset = (int)row[PDS_S_REF_OFFSET];
+}
+
+// ---- sensor noise -------------------------------------------------------------------------------
+// 24 standard variates of one add_noise call from six Philox blocks: words 0..17 -> 18 normals
+// (9 Box-Muller pairs), words 18..23 -> 6 uniforms.
+PDS_DEV void obs_noise_philox(uint32_t env_id, const StepArgs &a, uint32_t blk0, ObsNoise &n) {
+  uint32_t w[24];
+#pragma unroll
+  for (int b = 0; b < 6; ++b) {
+    const U4 r = philox4x32_7(env_id, a.tick_lo, a.tick_hi, blk0 + (uint32_t)b, a.seed_lo, a.seed_hi);
+    w[4 * b] = r.x; w[4 * b + 1] = r.y; w[4 * b + 2] = r.z; w[4 * b + 3] = r.w;
+  }
+  float z[18];
+#pragma unroll
+  for (int p = 0; p < 9; ++p) box_muller(w[2 * p], w[2 * p + 1], z[2 * p], z[2 * p + 1]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    n.pos_z[i] = z[i]; n.vel_z[i] = z[3 + i]; n.bias_z[i] = z[6 + i];
+    n.rw_z[i] = z[9 + i]; n.to_z[i] = z[12 + i]; n.th_z[i] = z[15 + i];
+    n.pos_u[i] = u01(w[18 + i]); n.th_u[i] = u01(w[21 + i]);
+  }
+}
+
+PDS_DEV void obs_noise_load(const float *p, ObsNoise &n) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    n.pos_z[i] = p[PDS_N_OBS_POS_Z + i]; n.pos_u[i] = p[PDS_N_OBS_POS_U + i];
+    n.vel_z[i] = p[PDS_N_OBS_VEL_Z + i]; n.bias_z[i] = p[PDS_N_OBS_BIAS + i];
+    n.rw_z[i] = p[PDS_N_OBS_RW + i]; n.to_z[i] = p[PDS_N_OBS_TO + i];
+    n.th_z[i] = p[PDS_N_OBS_TH_Z + i]; n.th_u[i] = p[PDS_N_OBS_TH_U + i];
+  }
+}
+
+// SensorNoise.add_noise_to_omega (envs/sensors.py:121-134) followed by the gyro low-pass
+// LowPassFilter.apply with T_s/T = 0.5 (envs/base.py:109-110, envs/utils.py:76-79).
+PDS_DEV void gyro_update(const Consts &k, const EnvRegs &e, const float bz[3], const float rz[3],
+                         const float tz[3], NoiseState &ns) {
+  const float w[3] = {e.wx, e.wy, e.wz};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    ns.bias[i] = k.gyro_pi * ns.bias[i] + k.gyro_sb * bz[i];
+    const float om = ((w[i] + ns.bias[i]) + k.gyro_rw * rz[i]) + k.gyro_to * tz[i];
+    ns.lpf[i] = 0.5f * ns.lpf[i] + 0.5f * om;
+  }
+}
+
+// SensorNoise.add_noise (envs/sensors.py:75-118) on the true state + quaternion of the noisy
+// Euler angles (envs/hover.py:146); updates gyro bias / low-pass, returns the noisy observation.
+PDS_DEV void sensor_observe(const Consts &k, const EnvRegs &e, const ObsNoise &n, NoiseState &ns, NoisyObs &o) {
+  const float p[3] = {e.px, e.py, e.pz}, v[3] = {e.vx, e.vy, e.vz}, r[3] = {e.roll, e.pitch, e.yaw};
+  float pn[3], vn[3], rn[3];
+  const float lo[3] = {-kPi, -kHalfPi, -kPi}, hi[3] = {kPi, kHalfPi, kPi};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    pn[i] = p[i] + (k.pos_std * n.pos_z[i] + (-k.pos_unif + (2.f * k.pos_unif) * n.pos_u[i]));
+    vn[i] = v[i] + k.vel_std * n.vel_z[i];
+    rn[i] = clampf(r[i] + (k.q_std * n.th_z[i] + (-k.q_unif + (2.f * k.q_unif) * n.th_u[i])), lo[i], hi[i]);
+  }
+  gyro_update(k, e, n.bias_z, n.rw_z, n.to_z, ns);
+  const Quat q = quat_from_euler(rn[0], rn[1], rn[2]);
+  o.x = pn[0]; o.y = pn[1]; o.z = pn[2];
+  o.qx = q.x; o.qy = q.y; o.qz = q.z; o.qw = q.w;
+  o.vx = vn[0]; o.vy = vn[1]; o.vz = vn[2];
+}
+
+// ---- observation rows ---------------------------------------------------------------------------
+// noise-free o (envs/agents.py:339-348 get_state; envs/circle.py:173-177; envs/takeoff.py:146-147)
+template <int TASK>
+PDS_DEV void write_obs_half(float *row, const EnvRegs &e, const Quat &q, const float4 &last_action,
+                            float tx, float ty, float tz, const float4 &hist_action) {
+  int n = 0;
+  row[n++] = e.px; row[n++] = e.py; row[n++] = e.pz;
+  row[n++] = q.x; row[n++] = q.y; row[n++] = q.z; row[n++] = q.w;
+  row[n++] = e.vx; row[n++] = e.vy; row[n++] = e.vz;
+  row[n++] = e.wx; row[n++] = e.wy; row[n++] = e.wz;
+  if (TASK != PDS_TASK_CIRCLE) {
+    row[n++] = last_action.x; row[n++] = last_action.y; row[n++] = last_action.z; row[n++] = last_action.w;
+  }
+  if (TASK != PDS_TASK_HOVER) {
+    row[n++] = tx - e.px; row[n++] = ty - e.py; row[n++] = tz - e.pz;
+  }
+  row[n++] = hist_action.x; row[n++] = hist_action.y; row[n++] = hist_action.z; row[n++] = hist_action.w;
+}
+
+// noisy o (envs/hover.py:133-159, envs/circle.py:135-171, envs/takeoff.py:113-143):
+// [xyz_n, Q(rpy_n), vel_n, lpf(omega_n) (, last_action: TakeOff) (, target - xyz_n: Circle/TakeOff)]
+template <int TASK>
+PDS_DEV void write_noisy_half(float *row, const NoisyObs &o, const float lpf[3], const float4 &last_action,
+                              float tx, float ty, float tz, const float4 &hist_action) {
+  int n = 0;
+  row[n++] = o.x; row[n++] = o.y; row[n++] = o.z;
+  row[n++] = o.qx; row[n++] = o.qy; row[n++] = o.qz; row[n++] = o.qw;
+  row[n++] = o.vx; row[n++] = o.vy; row[n++] = o.vz;
+  row[n++] = lpf[0]; row[n++] = lpf[1]; row[n++] = lpf[2];
+  if (TASK == PDS_TASK_TAKEOFF) {
+    row[n++] = last_action.x; row[n++] = last_action.y; row[n++] = last_action.z; row[n++] = last_action.w;
+  }
+  if (TASK != PDS_TASK_HOVER) {
+    row[n++] = tx - o.x; row[n++] = ty - o.y; row[n++] = tz - o.z;
+  }
+  row[n++] = hist_action.x; row[n++] = hist_action.y; row[n++] = hist_action.z; row[n++] = hist_action.w;
+}
+
+// ---- reset ----------------------------------------------------------------------------------------
+// DroneBaseEnv.reset (envs/base.py:382-431) for one env: task_specific_reset, domain
+// randomisation, the Bullet pose/velocity round trip of update_information
+// (envs/agents.py:434-453: rpy = Euler(quat), omega = R^T R^T omega_sampled).
+template <class V>
+PDS_DEV void reset_env(const Consts &k, const float2 *ref_lds, const Sample &s, EnvRegs &e, Quat &q,
+                       float4 &u0, float4 &mx, Params &par, uint32_t &ctr) {
+  constexpr int TASK = V::TASK;
+  float px = k.init_xyz[0], py = k.init_xyz[1], pz = k.init_xyz[2];
+  float vx = k.init_vel[0], vy = k.init_vel[1], vz = k.init_vel[2];
+  float w0 = k.init_w[0], w1 = k.init_w[1], w2 = k.init_w[2];
+  float r0 = k.init_rpy[0], r1 = k.init_rpy[1], r2 = k.init_rpy[2];
+  int ref_offset = (TASK == PDS_TASK_CIRCLE) ? (int)ctr_off(ctr) : 0;  // kept when no reset distribution
+  u0 = make_float4(0.f, 0.f, 0.f, 0.f);  // drone.reset(): envs/agents.py:380-386
+  mx = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (k.reset_dist) {
+    if (TASK == PDS_TASK_HOVER) {  // envs/hover.py:201-229
+      px += s.pos[0]; py += s.pos[1]; pz += s.pos[2];
+      r0 = s.rpy[0]; r1 = s.rpy[1]; r2 = s.rpy[2];
+      vx += s.vel[0]; vy += s.vel[1]; vz += s.vel[2];
+      w0 += s.w[0]; w1 += s.w[1]; w2 = s.w[2];
+    } else if (TASK == PDS_TASK_CIRCLE) {  // envs/circle.py:225-257
+      ref_offset = s.ref_offset;
+      float tx, ty, tz;
+      target_at<TASK>(k, ref_lds, ref_offset, tx, ty, tz);
+      px = tx + s.pos[0]; py = ty + s.pos[1]; pz = tz + s.pos[2];
+      r0 = s.rpy[0]; r1 = s.rpy[1]; r2 = s.rpy[2];
+      vx += s.vel[0]; vy += s.vel[1]; vz += s.vel[2];
+      w0 = s.w[0]; w1 = s.w[1]; w2 = s.w[2];
+    } else {  // envs/takeoff.py:186-191
+      px += s.pos[0]; py += s.pos[1];
+      r0 = 0.f; r1 = 0.f; r2 = s.rpy[2];
+    }
+    if (TASK != PDS_TASK_TAKEOFF) {
+      mx = make_float4(s.mx[0], s.mx[1], s.mx[2], s.mx[3]);
+      u0 = make_float4(clampf(s.act[0], -1.f, 1.f), clampf(s.act[1], -1.f, 1.f),
+                       clampf(s.act[2], -1.f, 1.f), clampf(s.act[3], -1.f, 1.f));
+    }
+  }
+  if (TASK == PDS_TASK_TAKEOFF) {  // envs/takeoff.py:209-212 (unconditional)
+    mx = make_float4(0.f, 0.f, 0.f, 0.f);
+    u0 = make_float4(-1.f, -1.f, -1.f, -1.f);
+  }
+  default_params(k, par);
+  if (V::DR) {  // envs/base.py:259-287
+    par.dt = s.dt; par.m = s.m; par.Jx = s.J[0]; par.Jy = s.J[1]; par.Jz = s.J[2]; par.ftf1 = s.ftf1;
+    if (V::MOTOR) {  // envs/agents.py:208-224 (K uses the hard-coded 0.028)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float T = fmaxf(s.T[i], par.dt);
+        par.A[i] = 1.0f - par.dt / T;
+        par.K[i] = 0.028f * k.G * s.t2w[i] / 4.0f;
+      }
+    }
+  }
+  q = quat_from_euler(r0, r1, r2);
+  float R[9];
+  matrix_from_quat(q, R);
+  // bc.resetBaseVelocity(R^T w) then update_information: R^T (R^T w)
+  const float a0 = R[0] * w0 + R[3] * w1 + R[6] * w2;
+  const float a1 = R[1] * w0 + R[4] * w1 + R[7] * w2;
+  const float a2 = R[2] * w0 + R[5] * w1 + R[8] * w2;
+  e.wx = R[0] * a0 + R[3] * a1 + R[6] * a2;
+  e.wy = R[1] * a0 + R[4] * a1 + R[7] * a2;
+  e.wz = R[2] * a0 + R[5] * a1 + R[8] * a2;
+  e.px = px; e.py = py; e.pz = pz; e.vx = vx; e.vy = vy; e.vz = vz;
+  // rpy = Euler(quat) (envs/agents.py:446).  The quaternion keeps the sign of Q(sampled rpy) until
+  // the first step while the state stores the wrapped Euler angles, so remember whether Q(wrapped)
+  // has the opposite sign.
+  uint32_t sign;
+  if (fabsf(r0) < 1.55f && fabsf(r1) < 1.55f) {
+    // every sampled attitude lands here: roll/pitch inside the principal range, so
+    // Euler(Q(r,p,y)) == (r, p, y - 2 pi k) and Q flips sign once per 2 pi of yaw
+    const float kk = rintf(r2 * 0.15915494309189533577f);
+    float yw = fmaf(-kk, 6.2831854820251465f, r2);
+    yw = fmaf(kk, 1.7484555e-7f, yw);
+    e.roll = r0; e.pitch = r1; e.yaw = yw;
+    sign = ((int)kk) & 1;
+  } else {  // init_rpy overrides near / beyond gimbal lock: the general pybullet formulas
+    euler_from_quat(q, e.roll, e.pitch, e.yaw);
+    const Quat qw = quat_from_euler(e.roll, e.pitch, e.yaw);
+    sign = (qw.x * q.x + qw.y * q.y + qw.z * q.z + qw.w * q.w) < 0.f ? 1u : 0u;
+  }
+  ctr = ctr_pack(0u, sign, (uint32_t)ref_offset);
+}
+
+// Result of one reset, split in a pure-compute half and a store half so that the deferred
+// auto-reset drain can do its arithmetic while the wave's earlier stores are still draining.
+struct ResetOut {
+  EnvRegs e;
+  Quat q;
+  float4 u0, mx;
+  Params par;
+  uint32_t ctr;
+  NoiseState ns;     // ON: gyro bias / low-pass after the two observation calls of reset
+  NoisyObs oa, ob;   // ON: the two noisy observations (history fill / compute_history)
+  float lpf_a[3];    // ON: filtered gyro of the first one
+};
+
+// `stale_w`: drone.rpy_dot BEFORE the reset -- the reference re-initialises the gyro low-pass with
+// it (envs/base.py:411 runs before update_information); `bias`: persisting gyro bias.
+template <class V>
+PDS_DEV void reset_compute(const StepArgs &a, const float2 *ref_lds, long long i, uint32_t ctr_old,
+                           const float *sample_row, const float stale_w[3], const float bias[3], ResetOut &r) {
+  Sample s;
+  const uint32_t env_id = (uint32_t)(a.env_id_base + (unsigned long long)i);
+  if (sample_row != nullptr) sample_load(sample_row, s);
+  else sample_philox<V>(a.k, env_id, a, s);
+  r.ctr = ctr_old;
+  reset_env<V>(a.k, ref_lds, s, r.e, r.q, r.u0, r.mx, r.par, r.ctr);
+  if (V::ON) {
+    ObsNoise n0, n1;
+    if (sample_row != nullptr) {
+      obs_noise_load(sample_row + PDS_S_NOISE_CALL0, n0);
+      obs_noise_load(sample_row + PDS_S_NOISE_CALL1, n1);
+    } else {
+      obs_noise_philox(env_id, a, kBlkResetNoise, n0);
+      obs_noise_philox(env_id, a, kBlkResetNoise + 6u, n1);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { r.ns.lpf[j] = stale_w[j]; r.ns.bias[j] = bias[j]; }
+    sensor_observe(a.k, r.e, n0, r.ns, r.oa);   // obs = compute_observation(), envs/base.py:419
+#pragma unroll
+    for (int j = 0; j < 3; ++j) r.lpf_a[j] = r.ns.lpf[j];
+    sensor_observe(a.k, r.e, n1, r.ns, r.ob);   // compute_history(), envs/base.py:429
+  }
+}
+
+// Writes the complete state, parameters and (optionally) the observation row [o0,u0,o0',u0]
+// (envs/base.py:417-431) of a reset env straight to HBM.  Rows are strided -> only for the explicit
+// reset kernel and the deferred auto-reset drain, never on the per-step stream.
+template <class V>
+PDS_DEV void reset_store(const StepArgs &a, const float2 *ref_lds, long long i, const ResetOut &r) {
+  constexpr int TASK = V::TASK;
+  constexpr int D = V::D;
+  const EnvRegs &e = r.e;
+  a.st.s0[i] = make_float4(e.px, e.py, e.pz, e.vx);
+  a.st.s1[i] = make_float4(e.vy, e.vz, e.roll, e.pitch);
+  a.st.s2[i] = make_float4(e.yaw, e.wx, e.wy, e.wz);
+  a.st.hist[0][i] = r.u0;
+  a.st.hist[1][i] = r.u0;
+  a.st.ctr[i] = r.ctr;
+  if (V::MOTOR) a.st.mx[i] = r.mx;
+  if (V::DR) {
+    a.st.par0[i] = make_float4(r.par.dt, r.par.m, r.par.Jx, r.par.Jy);
+    a.st.par1[i] = make_float2(r.par.Jz, r.par.ftf1);
+    if (V::MOTOR) {
+      a.st.mA[i] = make_float4(r.par.A[0], r.par.A[1], r.par.A[2], r.par.A[3]);
+      a.st.mK[i] = make_float4(r.par.K[0], r.par.K[1], r.par.K[2], r.par.K[3]);
+    }
+  }
+  if (V::ON) {
+    a.st.nz0[i] = make_float4(r.ns.bias[0], r.ns.bias[1], r.ns.bias[2], r.ns.lpf[0]);
+    a.st.nz1[i] = make_float2(r.ns.lpf[1], r.ns.lpf[2]);
+    a.st.oh0[i] = make_float4(r.ob.x, r.ob.y, r.ob.z, r.ob.qx);
+    a.st.oh1[i] = make_float4(r.ob.qy, r.ob.qz, r.ob.qw, r.ob.vx);
+    a.st.oh2[i] = make_float2(r.ob.vy, r.ob.vz);
+  }
+  if (a.obs != nullptr) {
+    float rowbuf[D];
+    float tx, ty, tz;
+    target_at<TASK>(a.k, ref_lds, target_index<TASK>(0, a.k.agg, (int)ctr_off(r.ctr)), tx, ty, tz);
+    if (V::ON) {
+      write_noisy_half<TASK>(rowbuf, r.oa, r.lpf_a, r.u0, tx, ty, tz, r.u0);
+      write_noisy_half<TASK>(rowbuf + V::O + 4, r.ob, r.ns.lpf, r.u0, tx, ty, tz, r.u0);
+    } else {
+      write_obs_half<TASK>(rowbuf, e, r.q, r.u0, tx, ty, tz, r.u0);
+      write_obs_half<TASK>(rowbuf + V::O + 4, e, r.q, r.u0, tx, ty, tz, r.u0);
+    }
+    float2 *dst = reinterpret_cast<float2 *>(a.obs + i * D);
+#pragma unroll
+    for (int j = 0; j < D / 2; ++j) dst[j] = make_float2(rowbuf[2 * j], rowbuf[2 * j + 1]);
+  }
+}
+
+// Dense pass over the envs a wave queued for auto-reset (queue entry = env index | ref_offset << 23).
+// Without observation noise the arithmetic touches no memory, so it overlaps with the wave's
+// outstanding stores; those must have completed (s_waitcnt vmcnt(0)) before the same addresses are
+// overwritten.  With observation noise the reset needs the terminal body rates and the gyro bias the
+// wave has just stored, so the wait comes first.
+template <class V>
+PDS_DEV void drain_reset_queue(const StepArgs &a, const float2 *ref_lds, const uint32_t *queue, int qcount, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int base = 0; base < qcount; base += kWave) {
+    const int idx = base + lane;
+    const bool on = idx < qcount;
+    ResetOut r;
+    long long i = 0;
+    uint32_t ent = 0;
+    if (on) {
+      ent = queue[idx];
+      i = (long long)(ent & 0x7FFFFFu);
+    }
+    float stale_w[3] = {0.f, 0.f, 0.f}, bias[3] = {0.f, 0.f, 0.f};
+    if (V::ON) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (on) {
+        const float4 q2 = a.st.s2[i];
+        const float4 nz = a.st.nz0[i];
+        stale_w[0] = q2.y; stale_w[1] = q2.z; stale_w[2] = q2.w;
+        bias[0] = nz.x; bias[1] = nz.y; bias[2] = nz.z;
+      }
+    }
+    if (on) reset_compute<V>(a, ref_lds, i, ctr_pack(0u, 0u, ent >> 23), nullptr, stale_w, bias, r);
+    if (!V::ON) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (on) reset_store<V>(a, ref_lds, i, r);
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Explicit reset (pds_reset / pds_reset_from_samples): not a hot path.
+template <class V>
+__global__ __launch_bounds__(kBlock) void reset_kernel(const StepArgs a) {
+  __shared__ float2 ref_lds[(V::TASK == PDS_TASK_CIRCLE) ? kRefPoints : 1];
+  if (V::TASK == PDS_TASK_CIRCLE) {
+    for (int t = threadIdx.x; t < kRefPoints; t += kBlock) ref_lds[t] = a.st.circle_ref[t];
+    __syncthreads();
+  }
+  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= a.n) return;
+  if (a.mask != nullptr && a.mask[i] == 0) return;
+  float stale_w[3] = {0.f, 0.f, 0.f}, bias[3] = {0.f, 0.f, 0.f};
+  if (V::ON) {
+    const float4 q2 = a.st.s2[i];
+    const float4 nz = a.st.nz0[i];
+    stale_w[0] = q2.y; stale_w[1] = q2.z; stale_w[2] = q2.w;
+    bias[0] = nz.x; bias[1] = nz.y; bias[2] = nz.z;
+  }
+  ResetOut r;
+  reset_compute<V>(a, ref_lds, i, a.st.ctr[i], a.samples != nullptr ? a.samples + i * PDS_SAMPLE_FLOATS : nullptr,
+                   stale_w, bias, r);
+  reset_store<V>(a, ref_lds, i, r);
+}
+
+}  // namespace pds

@@ -1,0 +1,164 @@
+// pds_types.h -- data layout shared by the kernels and the host side of libpds_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pds.h"
+#include "pds_device.h"
+
+namespace pds {
+
+constexpr int kBlock = 256;      // 4 waves; each wave owns a private LDS tile (no block barrier needed)
+constexpr int kWave = 64;
+constexpr int kQueueCap = 128;   // deferred-reset queue entries per wave (LDS)
+constexpr int kRefPoints = 300;  // envs/circle.py:48, envs/takeoff.py:43
+
+// ---- packing of the per-env counter word --------------------------------------------------------
+// bits 0..15 env.step calls since reset | bit 16 quaternion == -Q(rpy) | bits 17..25 Circle ref_offset
+PDS_DEV uint32_t ctr_pack(uint32_t step, uint32_t sign, uint32_t off) { return step | (sign << 16) | (off << 17); }
+PDS_DEV uint32_t ctr_step(uint32_t c) { return c & 0xFFFFu; }
+PDS_DEV uint32_t ctr_sign(uint32_t c) { return (c >> 16) & 1u; }
+PDS_DEV uint32_t ctr_off(uint32_t c) { return (c >> 17) & 0x1FFu; }
+
+// ---- SoA state in HBM (one float4 "quad" per env and array => 16 B/lane coalesced streams) ------
+struct DevState {
+  float4 *s0;       // px py pz vx
+  float4 *s1;       // vy vz roll pitch
+  float4 *s2;       // yaw wx wy wz
+  float4 *hist[2];  // action ring: slot `parity` = u(k-1), slot `parity^1` = u(k-2)
+  uint32_t *ctr;
+  float4 *mx;       // motor state x[4]                 (use_motor_dynamics)
+  float4 *par0;     // dt m Jxx Jyy                     (domain_randomization)
+  float2 *par1;     // Jzz ftf1                         (domain_randomization)
+  float4 *mA;       // per-motor A (B = 1-A)            (domain_randomization & motor)
+  float4 *mK;       // per-motor K                      (domain_randomization & motor)
+  float4 *ou;       // OU thrust-noise state            (motor_thrust_noise > 0)
+  float4 *nz0;      // gyro_bias xyz, gyro_lpf x        (observation_noise > 0)
+  float2 *nz1;      // gyro_lpf y z                     (observation_noise > 0)
+  float4 *oh0;      // noisy o(k): x y z qx             (observation_noise > 0; a noisy observation
+  float4 *oh1;      //             qy qz qw vx           cannot be rebuilt from the true state, so the
+  float2 *oh2;      //             vy vz                 history half is kept)
+  const float2 *circle_ref;  // [300] (x, y) of the reference circle, z = 1
+};
+
+struct Consts {
+  // model (envs/assets/cf21x_sys_eq.urdf:10,16-17; envs/agents.py:138-156)
+  float K, G, m, Jx, Jy, Jz, ftf1, Lq, dt, A, hover_x, hover_action;
+  float gec, prop_r, h_clip, t2w, mtc, M_nom, Jx_nom, Jy_nom, Jz_nom, ftf1_nom, dt_nom;
+  // task
+  float pa, pang, pspin, pterm, pvel, arp;
+  float target[3];
+  float init_xyz[3], init_rpy[3], init_vel[3], init_w[3];
+  float dr;
+  // noise (envs/utils.py:85-108 OUNoise; envs/sensors.py:14-27 SensorNoise defaults; rotorS gyro model
+  // constants of sensors.py:124-128 evaluated on the host in double for dt = 1/sim_freq)
+  float ou_sigma, pos_std, pos_unif, vel_std, q_std, q_unif, gyro_pi, gyro_sb, gyro_rw, gyro_to;
+  int agg, max_steps, reset_dist;
+};
+
+struct StepArgs {
+  DevState st;
+  Consts k;
+  const float4 *actions;
+  float *obs;
+  float *reward;
+  uint8_t *term;
+  uint8_t *trunc;
+  float *cost;
+  float *final_obs;
+  const uint8_t *mask;   // reset kernel only
+  const float *samples;  // reset kernel only (injected draws) or nullptr
+  const float *noise;    // step kernel: injected standard variates [N, PDS_NOISE_FLOATS] or nullptr
+  long long n;
+  unsigned long long env_id_base;
+  uint32_t seed_lo, seed_hi, tick_lo, tick_hi;
+  int parity;
+  int auto_reset;
+};
+
+// Compile-time variant of the fused step: task and feature flags.
+template <int TASK_, bool MOTOR_, bool DR_, bool GE_, bool TN_, bool ON_>
+struct Variant {
+  static constexpr int TASK = TASK_;
+  static constexpr bool MOTOR = MOTOR_;  // first-order motor model (envs/agents.py:284-288)
+  static constexpr bool DR = DR_;        // per-env dt, m, J, ftf1 (, A, K)
+  static constexpr bool GE = GE_;        // ground effect (envs/physics.py:27-58, opt-in)
+  static constexpr bool TN = TN_;        // OU thrust noise (envs/utils.py:104-108)
+  static constexpr bool ON = ON_;        // SensorNoise + gyro low-pass (envs/sensors.py:75-134)
+  // |o|: envs/hover.py:131-163, envs/circle.py:128-177, envs/takeoff.py:107-149
+  static constexpr int O = ON_ ? (TASK_ == PDS_TASK_HOVER ? 13 : (TASK_ == PDS_TASK_CIRCLE ? 16 : 20))
+                               : (TASK_ == PDS_TASK_HOVER ? 17 : (TASK_ == PDS_TASK_CIRCLE ? 16 : 20));
+  static constexpr int D = 2 * (O + 4);
+};
+
+struct EnvRegs {
+  float px, py, pz, vx, vy, vz, roll, pitch, yaw, wx, wy, wz;
+};
+
+struct Params {  // per-env physical parameters (constants unless domain randomisation is on)
+  float dt, m, Jx, Jy, Jz, ftf1;
+  float A[4], K[4];
+};
+
+// standard variates of one SensorNoise.add_noise call that reach the observation
+// (envs/sensors.py:75-134); layout == PDS_N_OBS_* / the B part of a noise row
+struct ObsNoise {
+  float pos_z[3], pos_u[3], vel_z[3], bias_z[3], rw_z[3], to_z[3], th_z[3], th_u[3];
+};
+
+// what a noisy observation keeps besides the filtered gyro (which lives in the low-pass state)
+struct NoisyObs {
+  float x, y, z, qx, qy, qz, qw, vx, vy, vz;
+};
+
+struct NoiseState {
+  float ou[4];
+  float bias[3];
+  float lpf[3];
+};
+
+struct Sample {  // one reset() worth of draws, reference order (see include/pds.h PDS_S_*)
+  float pos[3], rpy[3], vel[3], w[3], mx[4], act[4];
+  float dt, m, J[3], ftf1, T[4], t2w[4];
+  int ref_offset;
+};
+
+PDS_DEV void default_params(const Consts &k, Params &p) {
+  p.dt = k.dt; p.m = k.m; p.Jx = k.Jx; p.Jy = k.Jy; p.Jz = k.Jz; p.ftf1 = k.ftf1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { p.A[i] = k.A; p.K[i] = k.K; }
+}
+
+// Reference trajectories: envs/circle.py:45-56 (table staged per block in LDS),
+// envs/takeoff.py:43-47 (z = k/300).
+template <int TASK>
+PDS_DEV void target_at(const Consts &k, const float2 *ref_lds, int t, float &tx, float &ty, float &tz) {
+  if (TASK == PDS_TASK_CIRCLE) {
+    const float2 r = ref_lds[t];
+    tx = r.x; ty = r.y; tz = 1.0f;
+  } else if (TASK == PDS_TASK_TAKEOFF) {
+    tx = 0.f; ty = 0.f; tz = (float)t / 300.0f;
+  } else {
+    tx = k.target[0]; ty = k.target[1]; tz = k.target[2];
+  }
+}
+
+template <int TASK>
+PDS_DEV int target_index(int step, int agg, int ref_offset) {
+  if (TASK == PDS_TASK_CIRCLE) return (step + ref_offset) % kRefPoints;  // envs/circle.py:130
+  if (TASK == PDS_TASK_TAKEOFF) return min(step * agg, kRefPoints - 1);  // envs/takeoff.py:108
+  return 0;
+}
+
+// ---- host-side launch interface of the per-task translation units -------------------------------
+struct LaunchFlags {
+  bool motor, dr, ge, tn, on;
+};
+void launch_step_hover(const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
+void launch_step_circle(const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
+void launch_step_takeoff(const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
+void launch_reset_hover(const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
+void launch_reset_circle(const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
+void launch_reset_takeoff(const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
+
+}  // namespace pds

@@ -194,7 +194,10 @@ class DroneVecEnv:
         native.check(self._handle, rc, "pds_reset_from_samples")
         return b["obs"], {}
 
-    def step(self, action):
+    def step(self, action, noise_variates=None):
+        """env.step(action).  `noise_variates` [N, 37] (native.STEP_NOISE_LAYOUT) replaces the in-kernel
+        Philox draws of the OU thrust noise / SensorNoise with caller-supplied standard variates
+        (parity tests replay the reference's numpy draws this way)."""
         a = action
         if not (isinstance(a, torch.Tensor) and a.dtype == torch.float32 and a.device == self.device and a.is_contiguous()):
             a = torch.as_tensor(np.asarray(action) if not isinstance(action, torch.Tensor) else action,
@@ -202,8 +205,13 @@ class DroneVecEnv:
         if a.shape != (self.num_envs, 4):
             raise ValueError(f"actions must have shape ({self.num_envs}, 4), got {tuple(a.shape)}")
         b = self._next_buf()
-        rc = self.lib.pds_step(
-            self._handle, C.c_void_p(a.data_ptr()), C.c_void_p(b["obs"].data_ptr()),
+        nv = None
+        if noise_variates is not None:
+            nv = torch.as_tensor(noise_variates, dtype=torch.float32).to(self.device).contiguous()
+            assert nv.shape == (self.num_envs, native.NOISE_FLOATS)
+        rc = self.lib.pds_step_with_variates(
+            self._handle, C.c_void_p(a.data_ptr()), C.c_void_p(nv.data_ptr()) if nv is not None else None,
+            C.c_void_p(b["obs"].data_ptr()),
             C.c_void_p(b["reward"].data_ptr()), C.c_void_p(b["terminated"].data_ptr()),
             C.c_void_p(b["truncated"].data_ptr()), C.c_void_p(b["cost"].data_ptr()),
             C.c_void_p(b["final_obs"].data_ptr()), self._stream())

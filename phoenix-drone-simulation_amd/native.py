@@ -10,19 +10,26 @@ from .build import library_path
 
 TASK_HOVER, TASK_CIRCLE, TASK_TAKEOFF = 0, 1, 2
 OK, EINVAL, ENODEVICE, EHIP, ENOMEM, EUNSUPPORTED = 0, -1, -2, -3, -4, -5
-SAMPLE_FLOATS = 36
+SAMPLE_FLOATS = 84
+NOISE_FLOATS = 37
 # field ids (enum pds_field)
 FIELDS = dict(pos=0, rpy=1, vel=2, omega=3, quat=4, motor_x=5, last_action=6, prev_action=7,
               step_count=8, quat_sign=9, ref_offset=10, params=11, motor_A=12, motor_K=13, ou=14,
-              gyro_bias=15, gyro_lpf=16)
+              gyro_bias=15, gyro_lpf=16, noisy_obs=17)
 INT_FIELDS = ("step_count", "quat_sign", "ref_offset")
 # sample row offsets (PDS_S_*)
 SAMPLE_LAYOUT = dict(pos_offset=(0, 3), rpy=(3, 3), vel=(6, 3), omega=(9, 3), motor_x=(12, 4),
                      action=(16, 4), dr_dt=(20, 1), dr_m=(21, 1), dr_J=(22, 3), dr_ftf0=(25, 1),
-                     dr_ftf1=(26, 1), dr_T=(27, 4), dr_t2w=(31, 4), ref_offset=(35, 1))
+                     dr_ftf1=(26, 1), dr_T=(27, 4), dr_t2w=(31, 4), ref_offset=(35, 1),
+                     noise_call0=(36, 24), noise_call1=(60, 24))
+# one add_noise call (PDS_N_OBS_*): offsets inside its 24 floats
+OBS_NOISE_LAYOUT = dict(pos_z=0, pos_u=3, vel_z=6, bias_z=9, rw_z=12, to_z=15, th_z=18, th_u=21)
+# step noise row (PDS_N_*)
+STEP_NOISE_LAYOUT = dict(ou=0, a_bias=4, a_rw=7, a_to=10, obs=13)
 
 EXPORTS = ["pds_version", "pds_default_config", "pds_create", "pds_destroy", "pds_obs_dim",
-           "pds_num_envs", "pds_reset", "pds_reset_from_samples", "pds_step", "pds_field_width",
+           "pds_num_envs", "pds_reset", "pds_reset_from_samples", "pds_step", "pds_step_with_variates",
+           "pds_field_width",
            "pds_get_state", "pds_set_state", "pds_tick", "pds_bytes_per_env_step", "pds_last_error"]
 
 
@@ -69,6 +76,7 @@ def load():
     lib.pds_reset.argtypes = [vp, vp, vp, vp]
     lib.pds_reset_from_samples.argtypes = [vp, vp, vp, vp, vp]
     lib.pds_step.argtypes = [vp] + [vp] * 8
+    lib.pds_step_with_variates.argtypes = [vp] + [vp] * 9
     lib.pds_field_width.argtypes = [i32]
     lib.pds_get_state.argtypes = [vp, i32, vp, vp]
     lib.pds_set_state.argtypes = [vp, i32, vp, vp]

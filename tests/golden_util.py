@@ -76,3 +76,59 @@ def assert_close(a, b, rtol, atol, what=""):
         i = int(np.argmax(err - tol))
         raise AssertionError(f"{what}: max violation at flat index {i}: got {a.reshape(-1)[i]!r} "
                              f"want {b.reshape(-1)[i]!r} (err {err.reshape(-1)[i]:.3e}, tol {tol.reshape(-1)[i]:.3e})")
+
+
+# ---- stochastic scenarios: map the reference's recorded numpy streams onto the kernel's layouts ----
+# Per add_noise call the reference draws z: pos3 vel3 bias3 rw3 turn_on3 theta3 acc6 (24) and
+# u: pos3 vel3 theta3 (9)  (envs/sensors.py:75-134); per env.step(): OU randn(4) + two calls
+# (envs/base.py:461-468); per reset(): two calls (envs/base.py:419,429).
+Z_CALL, U_CALL = 24, 9
+
+
+def _obs_call_variates(z, u):
+    """24 kernel-order variates (PDS_N_OBS_*) of one add_noise call from its numpy-order draws."""
+    out = np.zeros(24)
+    out[0:3] = z[0:3]      # pos z
+    out[3:6] = u[0:3]      # pos u
+    out[6:9] = z[3:6]      # vel z
+    out[9:12] = z[6:9]     # gyro bias z
+    out[12:15] = z[9:12]   # random-walk z
+    out[15:18] = z[12:15]  # turn-on z
+    out[18:21] = z[15:18]  # theta z
+    out[21:24] = u[6:9]    # theta u
+    return out
+
+
+def noisy(g):
+    return g.kwargs.get("observation_noise", 1) > 0
+
+
+def episode_streams(g, ep):
+    z0, z1 = int(g["z_off"][ep]) + int(g["z_skip"][ep]), int(g["z_off"][ep + 1])
+    u0, u1 = int(g["u_off"][ep]) + int(g["u_skip"][ep]), int(g["u_off"][ep + 1])
+    return g["z"][z0:z1], g["u"][u0:u1]
+
+
+def reset_noise_variates(g, ep):
+    """[48]: the two add_noise calls of reset() (PDS_S_NOISE_CALL0/1)."""
+    z, u = episode_streams(g, ep)
+    if not noisy(g):
+        return np.zeros(48)
+    return np.concatenate([_obs_call_variates(z[0:24], u[0:9]), _obs_call_variates(z[24:48], u[9:18])])
+
+
+def step_noise_variates(g, ep, t):
+    """[37]: OU z4 | gyro part of the discarded call (bias3 rw3 to3) | the observing call (24)."""
+    z, u = episode_streams(g, ep)
+    out = np.zeros(37)
+    if noisy(g):
+        zs, us = 2 * Z_CALL + t * (4 + 2 * Z_CALL), 2 * U_CALL + t * 2 * U_CALL
+        out[0:4] = z[zs:zs + 4]
+        za = z[zs + 4:zs + 4 + Z_CALL]
+        out[4:13] = za[6:15]
+        zb = z[zs + 4 + Z_CALL:zs + 4 + 2 * Z_CALL]
+        ub = u[us + U_CALL:us + 2 * U_CALL]
+        out[13:37] = _obs_call_variates(zb, ub)
+    else:
+        out[0:4] = z[4 * t:4 * t + 4]
+    return out
