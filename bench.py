@@ -55,7 +55,8 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=1 << 20)
     ap.add_argument("--task", default="hover", choices=["hover", "circle", "takeoff"])
     ap.add_argument("--config", type=int, default=0,
-                    help="0: north-star headline (Hover 2^20/GPU); 2/3/4: BASELINE.json configs[1..3]")
+                    help="0: north-star headline (Hover 2^20/GPU); 2/3/4: BASELINE.json configs[1..3]; "
+                         "6: Hover 2^20 with the reference's default noise + DR")
     ap.add_argument("--allgather-obs", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-auto-reset", action="store_true", help="diagnostic only: INVALID as a benchmark number")
@@ -88,6 +89,9 @@ def main():
         task, n = "takeoff", 1 << 20
         kw.update(use_ground_effect=True)
         act_center_shift = 0.2
+    elif args.config == 6:  # the reference's DEFAULT env config: sensor + thrust noise, 10 % DR
+        task, n = "hover", 1 << 20
+        kw = dict(observation_noise=1, domain_randomization=0.10, motor_thrust_noise=0.05)
     env_id = {"hover": "DroneHoverSimpleEnv-v0", "circle": "DroneCircleSimpleEnv-v0",
               "takeoff": "DroneTakeOffSimpleEnv-v0"}[task]
     env = pds.make(env_id, num_envs=n, device=dev, seed=0, env_id_base=rank * n,
@@ -148,7 +152,8 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{env_id}, {n} envs per GPU lockstep, fp32, observation noise off, "
+            "config": {"workload": f"{env_id}, {n} envs per GPU lockstep, fp32, observation noise "
+                                   f"{'on' if kw['observation_noise'] > 0 else 'off'}, thrust noise {kw['motor_thrust_noise']}, "
                                    f"domain randomisation {kw['domain_randomization']}, auto-reset on, "
                                    f"action ring [64,N,4] = hover{act_center_shift:+.1f} + 0.1*N(0,1)"
                                    + (", RCCL all-gather of obs" if gathered is not None else ""),

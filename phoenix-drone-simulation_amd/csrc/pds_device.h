@@ -16,17 +16,19 @@ struct Quat { float x, y, z, w; };
 
 // sin/cos for the half-angle arguments of the step: 3-term Cody-Waite reduction by pi/2 with FMA
 // (valid far beyond any angle an episode can reach) + cephes-style minimax kernels on [-pi/4, pi/4].
-// Max abs error 9.3e-8 for |x| <= 1e5 (checked against double on 28 M samples); larger or
-// non-finite arguments take the library path.  ~22 VALU instructions instead of ocml's sincosf.
+// Max abs error 9.3e-8 for |x| <= 1e5 (checked against double on 28 M samples) and the reduction
+// stays exact up to |x| ~ 2.6e7 (n = rint(x 2/pi) < 2^24); a half angle that large needs body rates
+// above 1e4 rad/s for a whole episode, i.e. a state that has already overflowed.  Non-finite
+// arguments give NaN like the library.  Branch-free, ~25 VALU instructions; ocml's sincosf with its
+// Payne-Hanek path cost 12 branches and ~3000 lines of code per kernel.
 PDS_DEV void fast_sincos(float x, float &s, float &c) {
-  if (__builtin_expect(!(fabsf(x) < 1.0e5f), 0)) {
-    sincosf(x, &s, &c);
-    return;
-  }
   const float n = rintf(__fmul_rn(x, 0.636619772367581343f));
   float r = fmaf(n, -1.57079637050628662109375f, x);
   r = fmaf(n, 4.37113900018624283e-8f, r);
   r = fmaf(n, 1.7151245100059521e-15f, r);
+  // beyond |x| ~ 2.6e7 the reduction is no longer exact: keep the polynomial argument in range so
+  // that a state that has already diverged still yields a point on the unit circle (1 instruction)
+  r = __builtin_amdgcn_fmed3f(r, -0.7855f, 0.7855f);
   const int q = (int)n;
   const float r2 = __fmul_rn(r, r);
   const float sp = fmaf(__fmul_rn(r, r2), fmaf(r2, fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), r);
@@ -101,6 +103,8 @@ template <int ROUNDS>
 PDS_DEV U4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {
+    // separate hi / lo multiplies: measured faster than one v_mad_u64_u32 per product on gfx950
+    // (noisy Hover step 138 us vs 170 us)
     const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
     const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
     const uint32_t n0 = hi1 ^ c1 ^ k0;

@@ -14,11 +14,40 @@ constexpr uint32_t kBlkResetNoise = 32;  // 32..43 two add_noise calls inside re
 constexpr uint32_t kBlkObsNoise = 64;    // 64..69 the add_noise call that produces o(k+1) (7 rounds)
 constexpr uint32_t kBlkSubNoise = 128;   // 128+4*sub+{0..3}: OU + the discarded add_noise call (7 rounds)
 
+// Where the Philox words of a reset come from: computed on the spot by the resetting thread
+// (explicit reset kernel), or read back from an LDS scratch that the whole wave filled
+// cooperatively (deferred auto-reset drain: one block per lane instead of 5-21 blocks in a row on
+// the one or two lanes that own a finished env).
+constexpr int kResetBlocks = 9;        // reset distribution + domain randomisation
+constexpr int kResetNoiseBlocks = 12;  // two add_noise calls
+constexpr int kScratchBlocks = kResetBlocks + kResetNoiseBlocks;
+
+struct DirectWords {
+  uint32_t env_id, tick_lo, tick_hi, seed_lo, seed_hi;
+  PDS_DEV U4 reset_block(uint32_t b) const { return philox4x32_10(env_id, tick_lo, tick_hi, kBlkReset + b, seed_lo, seed_hi); }
+  PDS_DEV U4 noise_block(uint32_t b) const { return philox4x32_7(env_id, tick_lo, tick_hi, kBlkResetNoise + b, seed_lo, seed_hi); }
+};
+struct LdsWords {
+  const U4 *slot;  // [kScratchBlocks]
+  PDS_DEV U4 reset_block(uint32_t b) const { return slot[b]; }
+  PDS_DEV U4 noise_block(uint32_t b) const { return slot[kResetBlocks + b]; }
+};
+
+// which of the 21 blocks a variant consumes (the cooperative fill skips the others)
+template <class V>
+PDS_DEV constexpr bool block_needed(int j) {
+  if (j >= kResetBlocks) return V::ON;
+  if (j <= 1) return true;
+  if (j <= 4) return V::TASK != PDS_TASK_TAKEOFF;
+  if (j <= 6) return V::DR || V::TASK == PDS_TASK_CIRCLE;
+  return V::MOTOR && V::DR;
+}
+
 // In-kernel reset sampler; restated draw for draw by oracle/phoenix_oracle.c
 // po_philox_reset_sample.  Ranges: envs/hover.py:201-228, envs/circle.py:225-257,
 // envs/takeoff.py:186-191, envs/base.py:250-287.
-template <class V>
-PDS_DEV void sample_philox(const Consts &k, uint32_t env_id, const StepArgs &a, Sample &s) {
+template <class V, class SRC>
+PDS_DEV void sample_philox(const Consts &k, const SRC &src, Sample &s) {
   constexpr int TASK = V::TASK;
   constexpr float D2R = kPi / 180.f;
   float pos_lim, rp_lim, yaw_lim, vel_lim, w_lim, wz_lim;
@@ -29,8 +58,8 @@ PDS_DEV void sample_philox(const Consts &k, uint32_t env_id, const StepArgs &a, 
   } else {
     pos_lim = 0.25f; rp_lim = 0.f; yaw_lim = kPi; vel_lim = 0.f; w_lim = 0.f; wz_lim = 0.f;
   }
-  const U4 r0 = philox4x32_10(env_id, a.tick_lo, a.tick_hi, 0u, a.seed_lo, a.seed_hi);
-  const U4 r1 = philox4x32_10(env_id, a.tick_lo, a.tick_hi, 1u, a.seed_lo, a.seed_hi);
+  const U4 r0 = src.reset_block(0u);
+  const U4 r1 = src.reset_block(1u);
   s.pos[0] = urange(r0.x, -pos_lim, pos_lim);
   s.pos[1] = urange(r0.y, -pos_lim, pos_lim);
   s.pos[2] = (TASK == PDS_TASK_TAKEOFF) ? 0.f : urange(r0.z, -pos_lim, pos_lim);
@@ -40,9 +69,9 @@ PDS_DEV void sample_philox(const Consts &k, uint32_t env_id, const StepArgs &a, 
   s.vel[0] = urange(r1.z, -vel_lim, vel_lim);
   s.vel[1] = urange(r1.w, -vel_lim, vel_lim);
   if (TASK != PDS_TASK_TAKEOFF) {
-    const U4 r2 = philox4x32_10(env_id, a.tick_lo, a.tick_hi, 2u, a.seed_lo, a.seed_hi);
-    const U4 r3 = philox4x32_10(env_id, a.tick_lo, a.tick_hi, 3u, a.seed_lo, a.seed_hi);
-    const U4 r4 = philox4x32_10(env_id, a.tick_lo, a.tick_hi, 4u, a.seed_lo, a.seed_hi);
+    const U4 r2 = src.reset_block(2u);
+    const U4 r3 = src.reset_block(3u);
+    const U4 r4 = src.reset_block(4u);
     s.vel[2] = urange(r2.x, -vel_lim, vel_lim);
     s.w[0] = urange(r2.y, -w_lim, w_lim);
     s.w[1] = urange(r2.z, -w_lim, w_lim);
@@ -65,8 +94,8 @@ PDS_DEV void sample_philox(const Consts &k, uint32_t env_id, const StepArgs &a, 
   s.ref_offset = 0;
   if (V::DR || TASK == PDS_TASK_CIRCLE) {
     const float f = k.dr;
-    const U4 r5 = philox4x32_10(env_id, a.tick_lo, a.tick_hi, 5u, a.seed_lo, a.seed_hi);
-    const U4 r6 = philox4x32_10(env_id, a.tick_lo, a.tick_hi, 6u, a.seed_lo, a.seed_hi);
+    const U4 r5 = src.reset_block(5u);
+    const U4 r6 = src.reset_block(6u);
 #define PDS_DRV(x, d) urange((x), (d) - f * (d), (d) + f * (d))
     s.dt = PDS_DRV(r5.x, k.dt_nom);
     s.m = PDS_DRV(r5.y, k.M_nom);
@@ -76,8 +105,8 @@ PDS_DEV void sample_philox(const Consts &k, uint32_t env_id, const StepArgs &a, 
     s.ftf1 = PDS_DRV(r6.z, k.ftf1_nom);
     s.ref_offset = (int)__umulhi(r6.w, 300u);
     if (V::MOTOR && V::DR) {
-      const U4 r7 = philox4x32_10(env_id, a.tick_lo, a.tick_hi, 7u, a.seed_lo, a.seed_hi);
-      const U4 r8 = philox4x32_10(env_id, a.tick_lo, a.tick_hi, 8u, a.seed_lo, a.seed_hi);
+      const U4 r7 = src.reset_block(7u);
+      const U4 r8 = src.reset_block(8u);
       s.T[0] = PDS_DRV(r7.x, k.mtc); s.T[1] = PDS_DRV(r7.y, k.mtc);
       s.T[2] = PDS_DRV(r7.z, k.mtc); s.T[3] = PDS_DRV(r7.w, k.mtc);
       s.t2w[0] = PDS_DRV(r8.x, k.t2w); s.t2w[1] = PDS_DRV(r8.y, k.t2w);
@@ -105,13 +134,7 @@ PDS_DEV void sample_load(const float *row, Sample &s) {
 // ---- sensor noise -------------------------------------------------------------------------------
 // 24 standard variates of one add_noise call from six Philox blocks: words 0..17 -> 18 normals
 // (9 Box-Muller pairs), words 18..23 -> 6 uniforms.
-PDS_DEV void obs_noise_philox(uint32_t env_id, const StepArgs &a, uint32_t blk0, ObsNoise &n) {
-  uint32_t w[24];
-#pragma unroll
-  for (int b = 0; b < 6; ++b) {
-    const U4 r = philox4x32_7(env_id, a.tick_lo, a.tick_hi, blk0 + (uint32_t)b, a.seed_lo, a.seed_hi);
-    w[4 * b] = r.x; w[4 * b + 1] = r.y; w[4 * b + 2] = r.z; w[4 * b + 3] = r.w;
-  }
+PDS_DEV void obs_noise_from_words(const uint32_t w[24], ObsNoise &n) {
   float z[18];
 #pragma unroll
   for (int p = 0; p < 9; ++p) box_muller(w[2 * p], w[2 * p + 1], z[2 * p], z[2 * p + 1]);
@@ -121,6 +144,27 @@ PDS_DEV void obs_noise_philox(uint32_t env_id, const StepArgs &a, uint32_t blk0,
     n.rw_z[i] = z[9 + i]; n.to_z[i] = z[12 + i]; n.th_z[i] = z[15 + i];
     n.pos_u[i] = u01(w[18 + i]); n.th_u[i] = u01(w[21 + i]);
   }
+}
+
+PDS_DEV void obs_noise_philox(uint32_t env_id, const StepArgs &a, uint32_t blk0, ObsNoise &n) {
+  uint32_t w[24];
+#pragma unroll
+  for (int b = 0; b < 6; ++b) {
+    const U4 r = philox4x32_7(env_id, a.tick_lo, a.tick_hi, blk0 + (uint32_t)b, a.seed_lo, a.seed_hi);
+    w[4 * b] = r.x; w[4 * b + 1] = r.y; w[4 * b + 2] = r.z; w[4 * b + 3] = r.w;
+  }
+  obs_noise_from_words(w, n);
+}
+
+template <class SRC>
+PDS_DEV void obs_noise_reset(const SRC &src, int call, ObsNoise &n) {
+  uint32_t w[24];
+#pragma unroll
+  for (int b = 0; b < 6; ++b) {
+    const U4 r = src.noise_block((uint32_t)(6 * call + b));
+    w[4 * b] = r.x; w[4 * b + 1] = r.y; w[4 * b + 2] = r.z; w[4 * b + 3] = r.w;
+  }
+  obs_noise_from_words(w, n);
 }
 
 PDS_DEV void obs_noise_load(const float *p, ObsNoise &n) {
@@ -304,13 +348,12 @@ struct ResetOut {
 
 // `stale_w`: drone.rpy_dot BEFORE the reset -- the reference re-initialises the gyro low-pass with
 // it (envs/base.py:411 runs before update_information); `bias`: persisting gyro bias.
-template <class V>
-PDS_DEV void reset_compute(const StepArgs &a, const float2 *ref_lds, long long i, uint32_t ctr_old,
+template <class V, class SRC>
+PDS_DEV void reset_compute(const StepArgs &a, const float2 *ref_lds, const SRC &src, uint32_t ctr_old,
                            const float *sample_row, const float stale_w[3], const float bias[3], ResetOut &r) {
   Sample s;
-  const uint32_t env_id = (uint32_t)(a.env_id_base + (unsigned long long)i);
   if (sample_row != nullptr) sample_load(sample_row, s);
-  else sample_philox<V>(a.k, env_id, a, s);
+  else sample_philox<V>(a.k, src, s);
   r.ctr = ctr_old;
   reset_env<V>(a.k, ref_lds, s, r.e, r.q, r.u0, r.mx, r.par, r.ctr);
   if (V::ON) {
@@ -319,8 +362,8 @@ PDS_DEV void reset_compute(const StepArgs &a, const float2 *ref_lds, long long i
       obs_noise_load(sample_row + PDS_S_NOISE_CALL0, n0);
       obs_noise_load(sample_row + PDS_S_NOISE_CALL1, n1);
     } else {
-      obs_noise_philox(env_id, a, kBlkResetNoise, n0);
-      obs_noise_philox(env_id, a, kBlkResetNoise + 6u, n1);
+      obs_noise_reset(src, 0, n0);
+      obs_noise_reset(src, 1, n1);
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) { r.ns.lpf[j] = stale_w[j]; r.ns.bias[j] = bias[j]; }
@@ -378,40 +421,66 @@ PDS_DEV void reset_store(const StepArgs &a, const float2 *ref_lds, long long i, 
   }
 }
 
-// Dense pass over the envs a wave queued for auto-reset (queue entry = env index | ref_offset << 23).
-// Without observation noise the arithmetic touches no memory, so it overlaps with the wave's
-// outstanding stores; those must have completed (s_waitcnt vmcnt(0)) before the same addresses are
-// overwritten.  With observation noise the reset needs the terminal body rates and the gyro bias the
-// wave has just stored, so the wait comes first.
+// Pass over the envs a wave queued for auto-reset (queue entry = env index | ref_offset << 23).
+// Groups of 8 lanes serve one queued env: every lane computes one (or a few) of the env's Philox
+// blocks into an LDS scratch (the wave's observation tile, free after its flush), then the group's
+// first lane assembles the sample from the scratch and finishes the reset.  Without observation
+// noise the arithmetic touches no global memory, so it overlaps with the wave's outstanding stores;
+// those must have completed (s_waitcnt vmcnt(0)) before the same addresses are overwritten.  With
+// observation noise the reset needs the terminal body rates and the gyro bias the wave has just
+// stored, so the wait comes first.
+constexpr int kLanesPerReset = 8;
+constexpr int kResetsPerPass = kWave / kLanesPerReset;
+
 template <class V>
-PDS_DEV void drain_reset_queue(const StepArgs &a, const float2 *ref_lds, const uint32_t *queue, int qcount, int lane) {
+PDS_DEV void drain_reset_queue(const StepArgs &a, const float2 *ref_lds, const uint32_t *queue, int qcount,
+                               int lane, float *tile) {
+  static_assert(kResetsPerPass * kScratchBlocks * 16 <= kWave * V::D * 4, "scratch must fit in the wave's tile");
+  U4 *scratch = reinterpret_cast<U4 *>(tile);
+  const int g = lane / kLanesPerReset, b = lane % kLanesPerReset;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  for (int base = 0; base < qcount; base += kWave) {
-    const int idx = base + lane;
+  for (int base = 0; base < qcount; base += kResetsPerPass) {
+    const int idx = base + g;
     const bool on = idx < qcount;
-    ResetOut r;
-    long long i = 0;
     uint32_t ent = 0;
+    if (on) ent = queue[idx];
+    const long long i = (long long)(ent & 0x7FFFFFu);
+    const uint32_t env_id = (uint32_t)(a.env_id_base + (unsigned long long)i);
     if (on) {
-      ent = queue[idx];
-      i = (long long)(ent & 0x7FFFFFu);
+      const DirectWords dw{env_id, a.tick_lo, a.tick_hi, a.seed_lo, a.seed_hi};
+#pragma unroll
+      for (int jj = 0; jj < (kScratchBlocks + kLanesPerReset - 1) / kLanesPerReset; ++jj) {
+        const int j = jj * kLanesPerReset + b;
+        bool need = false;
+#pragma unroll
+        for (int c = 0; c < kScratchBlocks; ++c) need = need || (c == j && block_needed<V>(c));
+        if (need) scratch[g * kScratchBlocks + j] = (j < kResetBlocks) ? dw.reset_block((uint32_t)j) : dw.noise_block((uint32_t)(j - kResetBlocks));
+      }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const bool owner = on && b == 0;
+    ResetOut r;
     float stale_w[3] = {0.f, 0.f, 0.f}, bias[3] = {0.f, 0.f, 0.f};
     if (V::ON) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (on) {
+      if (owner) {
         const float4 q2 = a.st.s2[i];
         const float4 nz = a.st.nz0[i];
         stale_w[0] = q2.y; stale_w[1] = q2.z; stale_w[2] = q2.w;
         bias[0] = nz.x; bias[1] = nz.y; bias[2] = nz.z;
       }
     }
-    if (on) reset_compute<V>(a, ref_lds, i, ctr_pack(0u, 0u, ent >> 23), nullptr, stale_w, bias, r);
+    if (owner) {
+      const LdsWords lw{scratch + g * kScratchBlocks};
+      reset_compute<V>(a, ref_lds, lw, ctr_pack(0u, 0u, ent >> 23), nullptr, stale_w, bias, r);
+    }
     if (!V::ON) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (on) reset_store<V>(a, ref_lds, i, r);
+    if (owner) reset_store<V>(a, ref_lds, i, r);
+    __builtin_amdgcn_wave_barrier();  // scratch is refilled by the next pass
   }
-  __builtin_amdgcn_wave_barrier();
 }
 
 // Explicit reset (pds_reset / pds_reset_from_samples): not a hot path.
@@ -433,7 +502,8 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const StepArgs a) {
     bias[0] = nz.x; bias[1] = nz.y; bias[2] = nz.z;
   }
   ResetOut r;
-  reset_compute<V>(a, ref_lds, i, a.st.ctr[i], a.samples != nullptr ? a.samples + i * PDS_SAMPLE_FLOATS : nullptr,
+  const DirectWords dw{(uint32_t)(a.env_id_base + (unsigned long long)i), a.tick_lo, a.tick_hi, a.seed_lo, a.seed_hi};
+  reset_compute<V>(a, ref_lds, dw, a.st.ctr[i], a.samples != nullptr ? a.samples + i * PDS_SAMPLE_FLOATS : nullptr,
                    stale_w, bias, r);
   reset_store<V>(a, ref_lds, i, r);
 }
