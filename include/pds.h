@@ -195,6 +195,18 @@ int pds_bytes_per_env_step(const pds_handle *h);
 
 const char *pds_last_error(const pds_handle *h);
 
+/* ---- caller-side helper: GAE over a lockstep rollout ----------------------
+ * Replaces core.Buffer.finish_path / calculate_adv_and_value_targets (algs/core.py:461-533, one
+ * scipy lfilter per finished path) for a [T, N] rollout: d_rew, d_val [T,N] f32; d_terminated,
+ * d_truncated [T,N] u8 (the flags pds_step returned); d_final_val [T,N] = V(final_obs) read where
+ * truncated (may be NULL); d_last_val [N] = V(o_T).  rew_scale = 1/(ret_std + eps) with clipping to
+ * +-rew_clip (use_reward_scaling) or 0 for raw rewards.  Outputs [T,N]: advantages, value targets,
+ * discounted returns.  Runs on the current device, asynchronously on `stream`. */
+int pds_gae(const float *d_rew, const float *d_val, const uint8_t *d_terminated, const uint8_t *d_truncated,
+            const float *d_final_val, const float *d_last_val, float gamma, float lam, float rew_scale,
+            float rew_clip, int64_t T, int64_t N, float *d_adv, float *d_target_v, float *d_disc_ret,
+            void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,3 +14,9 @@ class Box:
     def contains(self, x):
         x = np.asarray(x)
         return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))
+
+
+class Discrete:
+    def __init__(self, n):
+        self.n = n
+        self.shape = ()

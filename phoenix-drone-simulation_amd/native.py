@@ -30,7 +30,7 @@ STEP_NOISE_LAYOUT = dict(ou=0, a_bias=4, a_rw=7, a_to=10, obs=13)
 EXPORTS = ["pds_version", "pds_default_config", "pds_create", "pds_destroy", "pds_obs_dim",
            "pds_num_envs", "pds_reset", "pds_reset_from_samples", "pds_step", "pds_step_with_variates",
            "pds_field_width",
-           "pds_get_state", "pds_set_state", "pds_tick", "pds_bytes_per_env_step", "pds_last_error"]
+           "pds_get_state", "pds_set_state", "pds_tick", "pds_bytes_per_env_step", "pds_last_error", "pds_gae"]
 
 
 class Config(C.Structure):
@@ -85,6 +85,7 @@ def load():
     lib.pds_bytes_per_env_step.argtypes = [vp]
     lib.pds_last_error.argtypes = [vp]
     lib.pds_last_error.restype = C.c_char_p
+    lib.pds_gae.argtypes = [vp] * 6 + [C.c_float] * 4 + [i64, i64] + [vp] * 4
     _lib = lib
     return lib
 

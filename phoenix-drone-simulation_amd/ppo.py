@@ -1,0 +1,331 @@
+"""On-device PPO for the batched envs: the CALLER of the hot path.
+
+Mirrors the reference trainer on the path `train.py --alg ppo` (same hyper-parameter names and
+defaults, same state_dict keys, same update order), re-shaped for a lockstep [T, N] rollout:
+
+  IWPGAlgorithm.roll_out / update / update_value_net / update_policy_net   algs/iwpg/iwpg.py:350-485
+  ProximalPolicyOptimizationAlgorithm.compute_loss_pi                      algs/ppo/ppo.py:22-40
+  ActorCritic, MLPGaussianActor, MLPCritic                                 algs/core.py:226-412
+  Buffer.finish_path / calculate_adv_and_value_targets (GAE)               algs/core.py:461-533
+  OnlineMeanStd (Chan parallel update)                                     utils/online_mean_std.py:6-95
+  mpi_avg_grads (per-parameter Allreduce)                                  utils/mpi_tools.py:30-36
+
+MI355X-first differences: all tensors stay in HBM; GAE is one HIP kernel over [T, N] (pds_gae)
+instead of one scipy lfilter per path; ranks = GPUs, gradients are averaged with ONE flattened
+all-reduce per optimiser step over RCCL instead of one MPI Allreduce per parameter tensor; envs that
+finish are auto-reset inside pds_step and bootstrap from `final_obs`.
+PyTorch is used for what it is good at here: the two tiny MLPs and Adam.
+"""
+import ctypes as C
+import math
+import time
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import native
+
+
+class OnlineMeanStd(nn.Module):
+    """utils/online_mean_std.py:6-95 with identical parameter names (mean, std, count)."""
+
+    def __init__(self, epsilon=1e-5, shape=()):
+        super().__init__()
+        self.mean = nn.Parameter(torch.zeros(*shape), requires_grad=False)
+        self.std = nn.Parameter(torch.ones(*shape), requires_grad=False)
+        self.count = nn.Parameter(torch.zeros(1), requires_grad=False)
+        self.eps = epsilon
+        self.bound = 10
+        self.shape = shape
+
+    def forward(self, x, subtract_mean=True, clip=False):
+        y = (x - self.mean) / (self.std + self.eps) if subtract_mean else x / (self.std + self.eps)
+        return torch.clamp(y, -self.bound, self.bound) if clip else y
+
+    @torch.no_grad()
+    def update(self, x):
+        """Chan et al. parallel update; batch statistics are averaged over ranks (equal batch sizes)."""
+        if self.shape[0] == 1:
+            x = x.reshape(-1, 1)
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        n_B = x.shape[0] * world
+        n_A = self.count.clone()
+        n_AB = self.count + n_B
+        batch_mean = torch.mean(x, dim=0)
+        if world > 1:
+            dist.all_reduce(batch_mean)
+            batch_mean /= world
+        delta = batch_mean - self.mean
+        mean_new = self.mean + delta * n_B / n_AB
+        batch_var = torch.mean((x - mean_new) ** 2, dim=0)
+        if world > 1:
+            dist.all_reduce(batch_var)
+            batch_var /= world
+        M2_AB = n_A * torch.square(self.std) + n_B * batch_var + delta ** 2 * (n_A * n_B / n_AB)
+        self.mean.data = mean_new
+        self.count.data = n_AB
+        self.std.data = torch.sqrt(M2_AB / n_AB)
+
+
+def _mlp(sizes, activation):
+    act = {"relu": nn.ReLU, "tanh": nn.Tanh, "identity": nn.Identity, "sigmoid": nn.Sigmoid,
+           "softplus": nn.Softplus}[activation]
+    layers = []
+    for j in range(len(sizes) - 1):
+        lin = nn.Linear(sizes[j], sizes[j + 1])
+        nn.init.kaiming_uniform_(lin.weight, a=math.sqrt(5))  # algs/core.py initialize_layer default
+        layers += [lin, act() if j < len(sizes) - 2 else nn.Identity()]
+    return nn.Sequential(*layers)
+
+
+class GaussianActor(nn.Module):
+    """MLPGaussianActor (algs/core.py:226-290): state-independent log_std, annealed 0.5 -> 0.01."""
+
+    def __init__(self, obs_dim, act_dim, hidden_sizes=(50, 50), activation="relu"):
+        super().__init__()
+        self.log_std = nn.Parameter(torch.full((act_dim,), math.log(0.5)), requires_grad=False)
+        self.net = _mlp([obs_dim] + list(hidden_sizes) + [act_dim], activation)
+
+    def dist(self, obs):
+        return torch.distributions.Normal(self.net(obs), torch.exp(self.log_std))
+
+    def forward(self, obs, act=None):
+        d = self.dist(obs)
+        return d, (d.log_prob(act).sum(-1) if act is not None else None)
+
+    def set_log_std(self, frac):
+        self.log_std.data.fill_(math.log(0.499 * frac + 0.01))  # algs/core.py:268-276
+
+
+class Critic(nn.Module):
+    def __init__(self, obs_dim, hidden_sizes=(64, 64), activation="tanh"):
+        super().__init__()
+        self.net = _mlp([obs_dim] + list(hidden_sizes) + [1], activation)
+
+    def forward(self, obs):
+        return torch.squeeze(self.net(obs), -1)
+
+
+class ActorCritic(nn.Module):
+    """algs/core.py:313-412; state_dict keys are the reference's (obs_oms.*, pi.log_std, pi.net.*,
+    v.net.*, ret_oms.*), so `torch_save/model.pt` checkpoints interchange."""
+
+    def __init__(self, obs_dim, act_dim, ac_kwargs=None, use_standardized_obs=True, use_scaled_rewards=True):
+        super().__init__()
+        ac_kwargs = ac_kwargs or {"pi": {"hidden_sizes": (50, 50), "activation": "relu"},
+                                  "val": {"hidden_sizes": (64, 64), "activation": "tanh"}}
+        self.obs_oms = OnlineMeanStd(shape=(obs_dim,)) if use_standardized_obs else None
+        self.pi = GaussianActor(obs_dim, act_dim, **ac_kwargs["pi"])
+        self.v = Critic(obs_dim, **ac_kwargs["val"])
+        self.ret_oms = OnlineMeanStd(shape=(1,)) if use_scaled_rewards else None
+
+    @torch.no_grad()
+    def step(self, obs):
+        """(action, value, log_prob) for raw observations [N, D] (algs/core.py:370-393)."""
+        if self.obs_oms is not None:
+            obs = self.obs_oms(obs)
+        v = self.v(obs)
+        d = self.pi.dist(obs)
+        a = d.sample() if self.training else d.mean
+        return a, v, d.log_prob(a).sum(-1)
+
+    @torch.no_grad()
+    def value(self, obs):
+        return self.v(self.obs_oms(obs) if self.obs_oms is not None else obs)
+
+    def update(self, frac):
+        self.pi.set_log_std(1 - frac)
+
+
+def ppo_loss(ac, data, clip_ratio=0.2, entropy_coef=0.0):
+    """algs/ppo/ppo.py:22-40."""
+    d, logp = ac.pi(data["obs"], data["act"])
+    ratio = torch.exp(logp - data["log_p"])
+    clip_adv = data["adv"] * torch.clamp(ratio, 1 - clip_ratio, 1 + clip_ratio)
+    loss = -(torch.min(ratio * data["adv"], clip_adv)).mean()
+    loss = loss - entropy_coef * d.entropy().mean()
+    info = dict(kl=(0.5 * (d.mean - data["act"]) ** 2 / d.stddev ** 2).mean(), ent=d.entropy().mean(),
+                ratio=ratio.mean())
+    return loss, info
+
+
+def value_loss(ac, obs, ret):
+    """IWPGAlgorithm.compute_loss_v."""
+    return ((ac.v(obs) - ret) ** 2).mean()
+
+
+def gae(rew, val, terminated, truncated, final_val, last_val, gamma, lam, rew_scale=0.0, rew_clip=10.0):
+    """pds_gae on [T, N] device tensors -> (adv, target_v, discounted_ret)."""
+    T, N = rew.shape
+    out = [torch.empty_like(rew) for _ in range(3)]
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+    rc = native.load().pds_gae(p(rew.contiguous()), p(val.contiguous()), p(terminated.contiguous()),
+                               p(truncated.contiguous()), p(final_val), p(last_val.contiguous()),
+                               C.c_float(gamma), C.c_float(lam), C.c_float(rew_scale), C.c_float(rew_clip),
+                               T, N, p(out[0]), p(out[1]), p(out[2]),
+                               C.c_void_p(torch.cuda.current_stream(rew.device).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"pds_gae failed ({rc})")
+    return out
+
+
+def avg_grads(module):
+    """mpi_avg_grads (utils/mpi_tools.py:30-36) as ONE flattened RCCL all-reduce."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    grads = [p.grad for p in module.parameters() if p.grad is not None]
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat)
+    flat /= dist.get_world_size()
+    off = 0
+    for g in grads:
+        g.copy_(flat[off:off + g.numel()].view_as(g))
+        off += g.numel()
+
+
+class PPOTrainer:
+    """IWPGAlgorithm + PPO loss on a DroneVecEnv.  steps_per_epoch = rollout_len * env.num_envs per rank."""
+
+    def __init__(self, env, rollout_len=32, epochs=300, gamma=0.99, lam=0.95, clip_ratio=0.2,
+                 entropy_coef=0.01, use_entropy=False, pi_lr=3e-4, vf_lr=1e-3, train_pi_iterations=80,
+                 train_v_iterations=5, num_mini_batches=16, target_kl=0.01, use_kl_early_stopping=False,
+                 use_linear_lr_decay=True, use_exploration_noise_anneal=True, use_reward_scaling=True,
+                 use_standardized_obs=True, use_max_grad_norm=False, max_grad_norm=0.5, ac_kwargs=None,
+                 seed=0):
+        self.env, self.T, self.N = env, int(rollout_len), env.num_envs
+        self.epochs, self.gamma, self.lam, self.clip_ratio = epochs, gamma, lam, clip_ratio
+        self.entropy_coef = entropy_coef if use_entropy else 0.0
+        self.train_pi_iterations, self.train_v_iterations = train_pi_iterations, train_v_iterations
+        self.num_mini_batches, self.target_kl = num_mini_batches, target_kl
+        self.use_kl_early_stopping, self.use_linear_lr_decay = use_kl_early_stopping, use_linear_lr_decay
+        self.use_exploration_noise_anneal, self.use_reward_scaling = use_exploration_noise_anneal, use_reward_scaling
+        self.use_standardized_obs, self.use_max_grad_norm, self.max_grad_norm = use_standardized_obs, use_max_grad_norm, max_grad_norm
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        torch.manual_seed(seed + 10000 * rank)  # algs/iwpg/iwpg.py:124-127
+        dev = env.device
+        self.ac = ActorCritic(env.obs_dim, env.act_dim, ac_kwargs, use_standardized_obs, use_reward_scaling).to(dev)
+        if dist.is_initialized() and dist.get_world_size() > 1:  # sync_params, utils/mpi_tools.py:39-44
+            for p in self.ac.parameters():
+                dist.broadcast(p.data, 0)
+        self.pi_opt = torch.optim.Adam(self.ac.pi.net.parameters(), lr=pi_lr)
+        self.vf_opt = torch.optim.Adam(self.ac.v.parameters(), lr=vf_lr)
+        self.scheduler = torch.optim.lr_scheduler.LambdaLR(self.pi_opt, lambda e: 1 - e / epochs) if use_linear_lr_decay else None
+        T, N, D = self.T, self.N, env.obs_dim
+        f = dict(device=dev, dtype=torch.float32)
+        self.obs_buf = torch.zeros(T, N, D, **f)
+        self.act_buf = torch.zeros(T, N, 4, **f)
+        self.rew_buf, self.val_buf, self.logp_buf, self.fval_buf = (torch.zeros(T, N, **f) for _ in range(4))
+        self.term_buf = torch.zeros(T, N, device=dev, dtype=torch.uint8)
+        self.trunc_buf = torch.zeros(T, N, device=dev, dtype=torch.uint8)
+        self.ep_ret = torch.zeros(N, **f)
+        self.ep_len = torch.zeros(N, **f)
+        self.obs, _ = env.reset()
+        self.epoch = 0
+        self.log = []
+
+    def roll_out(self):
+        """algs/iwpg/iwpg.py:350-385 over all envs at once.  Returns per-epoch episode statistics."""
+        self.ac.train()
+        o = self.obs
+        done_ret, done_len, done_cnt = 0.0, 0.0, 0.0
+        stats = torch.zeros(3, device=o.device)
+        for t in range(self.T):
+            a, v, logp = self.ac.step(o)
+            next_o, r, term, trunc, info = self.env.step(a)
+            self.obs_buf[t].copy_(o); self.act_buf[t].copy_(a)
+            self.rew_buf[t].copy_(r); self.val_buf[t].copy_(v); self.logp_buf[t].copy_(logp)
+            self.term_buf[t].copy_(term.view(torch.uint8)); self.trunc_buf[t].copy_(trunc.view(torch.uint8))
+            # V(final obs) for the TimeLimit bootstrap; evaluated for every row to stay sync-free
+            # (rows of envs that did not finish are ignored by pds_gae)
+            self.fval_buf[t].copy_(self.ac.value(info["final_obs"]))
+            self.ep_ret += r
+            self.ep_len += 1
+            done = term | trunc
+            stats += torch.stack([(self.ep_ret * done).sum(), (self.ep_len * done).sum(), done.sum().float()])
+            self.ep_ret = torch.where(done, torch.zeros_like(self.ep_ret), self.ep_ret)
+            self.ep_len = torch.where(done, torch.zeros_like(self.ep_len), self.ep_len)
+            o = next_o
+        self.obs = o
+        self.last_val = self.ac.value(o)
+        return stats
+
+    def update(self):
+        """algs/iwpg/iwpg.py:398-485."""
+        ac, T, N = self.ac, self.T, self.N
+        scale = 0.0
+        if self.use_reward_scaling:
+            scale = float(1.0 / (ac.ret_oms.std.item() + ac.ret_oms.eps))
+        adv, target_v, disc_ret = gae(self.rew_buf, self.val_buf, self.term_buf, self.trunc_buf, self.fval_buf,
+                                      self.last_val, self.gamma, self.lam, scale, float(ac.ret_oms.bound if ac.ret_oms else 10))
+        raw_obs = self.obs_buf.reshape(T * N, -1)
+        obs = ac.obs_oms(raw_obs) if self.use_standardized_obs else raw_obs  # pre_process_data
+        data = dict(obs=obs, act=self.act_buf.reshape(T * N, -1), adv=adv.reshape(-1),
+                    log_p=self.logp_buf.reshape(-1), target_v=target_v.reshape(-1))
+        # ---- value net: train_v_iterations x num_mini_batches shuffled mini-batches
+        B = T * N
+        mbs = B // self.num_mini_batches
+        loss_v_before = value_loss(ac, data["obs"], data["target_v"]).item()
+        for _ in range(self.train_v_iterations):
+            perm = torch.randperm(B, device=obs.device)
+            for s in range(0, mbs * self.num_mini_batches, mbs):
+                idx = perm[s:s + mbs]
+                self.vf_opt.zero_grad()
+                lv = value_loss(ac, data["obs"][idx], data["target_v"][idx])
+                lv.backward()
+                avg_grads(ac.v)
+                self.vf_opt.step()
+        # ---- policy net: full-batch PPO-clip steps
+        with torch.no_grad():
+            loss_pi_before, _ = ppo_loss(ac, data, self.clip_ratio, self.entropy_coef)
+            p_dist = ac.pi.dist(data["obs"])
+        stop_iter = self.train_pi_iterations
+        for i in range(self.train_pi_iterations):
+            self.pi_opt.zero_grad()
+            loss_pi, pi_info = ppo_loss(ac, data, self.clip_ratio, self.entropy_coef)
+            loss_pi.backward()
+            if self.use_max_grad_norm:
+                torch.nn.utils.clip_grad_norm_(ac.pi.parameters(), self.max_grad_norm)
+            avg_grads(ac.pi.net)
+            self.pi_opt.step()
+            if self.use_kl_early_stopping:
+                with torch.no_grad():
+                    kl = torch.distributions.kl.kl_divergence(p_dist, ac.pi.dist(data["obs"])).mean()
+                    if dist.is_initialized() and dist.get_world_size() > 1:
+                        dist.all_reduce(kl); kl /= dist.get_world_size()
+                if kl.item() > self.target_kl:
+                    stop_iter = i + 1
+                    break
+        # ---- running statistics from RAW data, after the update (update_running_statistics)
+        if self.use_standardized_obs:
+            ac.obs_oms.update(raw_obs)
+        if self.use_reward_scaling:
+            ac.ret_oms.update(disc_ret.reshape(-1))
+        return dict(loss_pi=float(loss_pi_before), loss_v=loss_v_before, stop_iter=stop_iter,
+                    entropy=float(pi_info["ent"].detach()), ratio=float(pi_info["ratio"].detach()))
+
+    def learn_one_epoch(self):
+        t0 = time.time()
+        if self.use_exploration_noise_anneal:
+            self.ac.update(frac=self.epoch / self.epochs)
+        stats = self.roll_out()
+        info = self.update()
+        if self.scheduler is not None:
+            self.scheduler.step()
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(stats)
+        s = stats.tolist()
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        info.update(epoch=self.epoch + 1, ep_ret=s[0] / max(s[2], 1.0), ep_len=s[1] / max(s[2], 1.0),
+                    episodes=s[2], fps=self.T * self.N * world / (time.time() - t0),
+                    noise_std=float(torch.exp(self.ac.pi.log_std[0])))
+        self.log.append(info)
+        self.epoch += 1
+        return info
+
+    def learn(self, epochs=None, verbose=False):
+        for _ in range(epochs or self.epochs):
+            info = self.learn_one_epoch()
+            if verbose:
+                print({k: (round(v, 4) if isinstance(v, float) else v) for k, v in info.items()})
+        return self.ac, self.env

@@ -1,0 +1,202 @@
+"""The caller of the hot path: on-device PPO pieces against golden
+vectors produced by the reference's own trainer classes (oracle/refgen/gen_golden_trainer.py):
+OnlineMeanStd, ActorCritic forward (state_dict interchange), PPO-clip / value losses, exploration
+noise schedule on CPU; the HIP GAE kernel and a short end-to-end learning run on the GPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trainer.npz")
+
+
+@pytest.fixture(scope="module")
+def g():
+    return np.load(GOLD)
+
+
+def test_online_mean_std_matches_reference(g):
+    from phoenix_drone_simulation_amd.ppo import OnlineMeanStd
+    oms = OnlineMeanStd(shape=(42,))
+    for i in range(3):
+        oms.update(torch.from_numpy(g[f"oms_batch{i}"]))
+        np.testing.assert_allclose(oms.mean.numpy(), g[f"oms_mean{i}"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(oms.std.numpy(), g[f"oms_std{i}"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_array_equal(oms.count.numpy(), g[f"oms_count{i}"])
+    x = torch.from_numpy(g["oms_fwd_in"])
+    np.testing.assert_allclose(oms(x).numpy(), g["oms_fwd_out"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(oms(x, subtract_mean=False, clip=True).numpy(), g["oms_fwd_clip"], rtol=1e-6, atol=1e-6)
+    r = OnlineMeanStd(shape=(1,))
+    for i in range(2):
+        r.update(torch.from_numpy(g[f"roms_batch{i}"]))
+        np.testing.assert_allclose(r.mean.numpy(), g[f"roms_mean{i}"], rtol=1e-6)
+        np.testing.assert_allclose(r.std.numpy(), g[f"roms_std{i}"], rtol=1e-6)
+
+
+def _load_ac(g):
+    from phoenix_drone_simulation_amd.ppo import ActorCritic
+    ac = ActorCritic(42, 4)
+    sd = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd__")}
+    assert set(sd) == set(ac.state_dict())  # the reference's state_dict keys, one for one
+    ac.load_state_dict(sd)
+    return ac
+
+
+def test_actor_critic_forward_and_losses_match_reference(g):
+    from phoenix_drone_simulation_amd.ppo import ppo_loss, value_loss
+    ac = _load_ac(g)
+    ac.eval()
+    a, v, _ = ac.step(torch.from_numpy(g["ac_obs"]))
+    np.testing.assert_allclose(a.numpy(), g["ac_mean_action"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(v.numpy(), g["ac_value"], rtol=1e-5, atol=1e-6)
+    obs = ac.obs_oms(torch.from_numpy(g["ac_obs"]))
+    data = dict(obs=obs, act=torch.from_numpy(g["loss_act"]), log_p=torch.from_numpy(g["loss_old_logp"]),
+                adv=torch.from_numpy(g["loss_adv"]))
+    with torch.no_grad():
+        _, logp = ac.pi(obs, data["act"])
+        loss, info = ppo_loss(ac, data, clip_ratio=0.2, entropy_coef=0.0)
+        lv = value_loss(ac, obs, torch.from_numpy(g["loss_target_v"]))
+    np.testing.assert_allclose(logp.numpy(), g["loss_logp_act"], rtol=1e-5, atol=1e-5)
+    assert float(loss) == pytest.approx(float(g["loss_pi"]), rel=1e-5)
+    assert float(lv) == pytest.approx(float(g["loss_v"]), rel=1e-5)
+    assert float(info["kl"]) == pytest.approx(float(g["loss_kl"]), rel=1e-5)
+    assert float(info["ent"]) == pytest.approx(float(g["loss_ent"]), rel=1e-5)
+    assert float(info["ratio"]) == pytest.approx(float(g["loss_ratio"]), rel=1e-5)
+
+
+def test_exploration_noise_schedule(g):
+    from phoenix_drone_simulation_amd.ppo import ActorCritic
+    ac = ActorCritic(42, 4)
+    for f, s in zip(g["anneal_frac"], g["anneal_std"]):
+        ac.pi.set_log_std(float(f))
+        assert float(torch.exp(ac.pi.log_std[0])) == pytest.approx(float(s), rel=1e-6)
+
+
+def _gae_numpy(rew, val, term, trunc, fval, last_val, gamma, lam, scale, clip):
+    """Host restatement of Buffer.finish_path per path (algs/core.py:461-533) for [T, N] arrays."""
+    T, N = rew.shape
+    adv, tv, dr = np.zeros_like(rew), np.zeros_like(rew), np.zeros_like(rew)
+    for n in range(N):
+        start = 0
+        for t in range(T):
+            end = term[t, n] or trunc[t, n] or t == T - 1
+            if not end:
+                continue
+            b = 0.0 if term[t, n] else (fval[t, n] if trunc[t, n] else last_val[n])
+            r = np.append(rew[start:t + 1, n], b).astype(np.float64)
+            v = np.append(val[start:t + 1, n], b).astype(np.float64)
+            disc = np.zeros(len(r)); acc = 0.0
+            for k in range(len(r) - 1, -1, -1):
+                acc = r[k] + gamma * acc; disc[k] = acc
+            rs = np.clip(r * scale, -clip, clip) if scale > 0 else r
+            deltas = rs[:-1] + gamma * v[1:] - v[:-1]
+            a = np.zeros(len(deltas)); acc = 0.0
+            for k in range(len(deltas) - 1, -1, -1):
+                acc = deltas[k] + gamma * lam * acc; a[k] = acc
+            adv[start:t + 1, n], tv[start:t + 1, n], dr[start:t + 1, n] = a, a + v[:-1], disc[:-1]
+            start = t + 1
+    return adv, tv, dr
+
+
+@pytest.mark.gpu
+def test_gae_kernel_matches_reference_buffer(g):
+    """pds_gae on the exact trajectories the reference Buffer processed (4 paths: terminated,
+    bootstrapped one-step path, ...), with and without reward scaling."""
+    from phoenix_drone_simulation_amd.ppo import gae
+    dev = torch.device("cuda")
+    for tag in ("plain", "scaled"):
+        rew, val = g[f"buf_{tag}_rew"], g[f"buf_{tag}_val"]
+        lens, lvs = g[f"buf_{tag}_lens"], g[f"buf_{tag}_last_vals"]
+        T = len(rew)
+        term = np.zeros(T, np.uint8); trunc = np.zeros(T, np.uint8); fval = np.zeros(T, np.float32)
+        k = 0
+        for L, lv in zip(lens, lvs):
+            k += int(L)
+            if lv == 0.0:
+                term[k - 1] = 1
+            else:
+                trunc[k - 1] = 1; fval[k - 1] = lv
+        scale = float(1.0 / (g["buf_ret_std"][0] + 1e-5)) if tag == "scaled" else 0.0
+        col = lambda x, dt=torch.float32: torch.tensor(x, dtype=dt, device=dev).reshape(T, 1)  # noqa: E731
+        adv, tv, dr = gae(col(rew), col(val), col(term, torch.uint8), col(trunc, torch.uint8), col(fval),
+                          torch.zeros(1, device=dev), 0.99, 0.95, scale, 10.0)
+        np.testing.assert_allclose(adv.cpu().numpy()[:, 0], g[f"buf_{tag}_adv"], rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(tv.cpu().numpy()[:, 0], g[f"buf_{tag}_target_v"], rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(dr.cpu().numpy()[:, 0], g[f"buf_{tag}_discounted_ret"], rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.gpu
+def test_gae_kernel_random_rollout():
+    from phoenix_drone_simulation_amd.ppo import gae
+    rs = np.random.RandomState(3)
+    T, N = 37, 300
+    rew = rs.normal(-1, 2, (T, N)).astype(np.float32); val = rs.normal(-3, 2, (T, N)).astype(np.float32)
+    term = (rs.rand(T, N) < 0.05).astype(np.uint8); trunc = ((rs.rand(T, N) < 0.03) & (term == 0)).astype(np.uint8)
+    fval = rs.normal(-3, 2, (T, N)).astype(np.float32); last = rs.normal(-3, 2, N).astype(np.float32)
+    dev = torch.device("cuda")
+    for scale in (0.0, 0.37):
+        out = gae(*(torch.tensor(x, device=dev) for x in (rew, val, term, trunc, fval, last)), 0.99, 0.95, scale, 10.0)
+        ref = _gae_numpy(rew, val, term, trunc, fval, last, 0.99, 0.95, scale, 10.0)
+        for a, b in zip(out, ref):
+            np.testing.assert_allclose(a.cpu().numpy(), b, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_ppo_learns_hover_end_to_end():
+    """Learning-curve check: PPO on DroneHoverSimpleEnv-v0 (the reference's default env config: sensor
+    noise, 10 % DR, thrust noise) improves the mean episode return and length within a few epochs."""
+    import phoenix_drone_simulation_amd as pds
+    from phoenix_drone_simulation_amd.ppo import PPOTrainer
+    env = pds.make("DroneHoverSimpleEnv-v0", num_envs=2048, seed=1)
+    tr = PPOTrainer(env, rollout_len=64, epochs=12, train_pi_iterations=40, seed=1)
+    tr.learn()
+    first, last = tr.log[0], tr.log[-1]
+    assert all(np.isfinite(e["loss_pi"]) and np.isfinite(e["loss_v"]) for e in tr.log)
+    assert last["ep_len"] > 1.5 * first["ep_len"], (first, last)
+    assert last["ep_ret"] / last["ep_len"] > first["ep_ret"] / first["ep_len"], (first, last)
+    assert last["noise_std"] < first["noise_std"]
+    env.close()
+
+
+_DDP_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+from phoenix_drone_simulation_amd.ppo import avg_grads, OnlineMeanStd, ActorCritic
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.manual_seed(0)
+ac = ActorCritic(42, 4)
+for i, p in enumerate(ac.pi.net.parameters()):
+    p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+avg_grads(ac.pi.net)     # mpi_avg_grads: mean over ranks, one flattened all-reduce
+for i, p in enumerate(ac.pi.net.parameters()):
+    assert torch.allclose(p.grad, torch.full_like(p, 1.5 * (i + 1))), (rank, i)
+# OnlineMeanStd over two ranks == single-process update on the concatenated batch
+torch.manual_seed(1)
+full = torch.randn(64, 42) * 3 + 1
+oms = OnlineMeanStd(shape=(42,)); oms.update(full[rank * 32:(rank + 1) * 32])
+ref = OnlineMeanStd(shape=(42,))
+dist.destroy_process_group()
+ref.update(full)
+assert torch.allclose(oms.mean, ref.mean, atol=1e-5) and torch.allclose(oms.std, ref.std, atol=1e-4), rank
+assert float(oms.count) == 64.0
+print("rank", rank, "ok")
+"""
+
+
+def test_gradient_averaging_and_running_stats_world2_gloo(tmp_path):
+    """The N>1 path of the trainer on CPU: 2 processes over gloo (the reference's mpi_avg_grads /
+    MPI-averaged OnlineMeanStd, utils/mpi_tools.py:30-36, utils/online_mean_std.py:76-83)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "worker.py"
+    script.write_text(_DDP_WORKER.format(root=root))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"rank {r} ok" in o
