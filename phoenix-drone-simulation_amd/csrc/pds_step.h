@@ -111,8 +111,11 @@ PDS_DEV void sub_noise(const StepArgs &a, uint32_t env_id, long long ii, int sub
 // for this shape and doubled the input registers, so there is no prefetch here.
 // __launch_bounds__(256, 3): LDS admits 3 blocks (12 waves) per CU, so cap VGPRs at 168.
 template <class V>
+// The lean variants are additionally held to 128 VGPRs (min 4 waves/SIMD): measured 2-3 % faster
+// (62.7 vs 64.3 us Hover, 63.5 vs 64.7 us TakeOff+GE on the same box); the observation-noise
+// variants spill badly under that cap (154 vs 106 us) and keep 168.
 #ifndef PDS_MIN_WAVES
-#define PDS_MIN_WAVES 3
+#define PDS_MIN_WAVES (V::ON ? 3 : 4)
 #endif
 __global__ __launch_bounds__(kBlock, PDS_MIN_WAVES) void step_kernel(const StepArgs a) {
   constexpr int TASK = V::TASK;

@@ -8,7 +8,10 @@
 
 namespace pds {
 
-constexpr int kBlock = 256;      // 4 waves; each wave owns a private LDS tile (no block barrier needed)
+#ifndef PDS_BLOCK
+#define PDS_BLOCK 256
+#endif
+constexpr int kBlock = PDS_BLOCK;  // 4 waves; each wave owns a private LDS tile (no block barrier needed)
 constexpr int kWave = 64;
 constexpr int kQueueCap = 128;   // deferred-reset queue entries per wave (LDS)
 constexpr int kRefPoints = 300;  // envs/circle.py:48, envs/takeoff.py:43
