@@ -1,0 +1,75 @@
+"""Policy JSON interchange: a trained policy shipped with the reference
+(experiments/07_control_structure_hypothesis/models/PWM/PWM_seed_00000_model.json, kept as a DATA
+fixture) loads, passes its own check_sum, round-trips through the exporter, and -- on the GPU -- flies
+the batched Circle env far longer than random actions do."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+FIX = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "policy_PWM_seed_00000_model.json")
+
+
+def test_reference_policy_loads_and_checksum_holds():
+    from phoenix_drone_simulation_amd.policy_io import load_network_json
+    pol = load_network_json(FIX)
+    assert pol.mean.shape == (40,) and pol.activation == "relu"
+    sizes = [(l.in_features, l.out_features) for l in pol.net if isinstance(l, torch.nn.Linear)]
+    assert sizes == [(40, 50), (50, 50), (50, 4)]
+    data = json.load(open(FIX))
+    assert float(pol.net(torch.ones(40)).sum()) == pytest.approx(float(data["check_sum"]), rel=1e-5)
+    bad = dict(data, check_sum=float(data["check_sum"]) + 1.0)
+    p = os.path.join(os.path.dirname(FIX), "_bad_tmp.json")
+    try:
+        json.dump(bad, open(p, "w"))
+        with pytest.raises(ValueError):
+            load_network_json(p)
+    finally:
+        os.remove(p)
+
+
+def test_export_roundtrip(tmp_path):
+    from phoenix_drone_simulation_amd.policy_io import load_network_json, dump_json, convert_actor_critic_to_json
+    from phoenix_drone_simulation_amd.ppo import ActorCritic
+    pol = load_network_json(FIX)
+    sp = np.stack([pol.mean.numpy(), pol.std.numpy()])
+    dump_json("relu", sp, pol.net, str(tmp_path / "m.json"))
+    again = load_network_json(str(tmp_path / "m.json"))
+    x = torch.randn(16, 40)
+    assert torch.allclose(pol(x), again(x), atol=1e-6)
+    ref = json.load(open(FIX)); new = json.load(open(tmp_path / "m.json"))
+    assert set(ref) == set(new) and new["0"]["type"] == "standard"
+    ac = ActorCritic(42, 4)
+    ac.obs_oms.update(torch.randn(100, 42) * 2 + 1)
+    convert_actor_critic_to_json(ac, str(tmp_path / "ac.json"))
+    p2 = load_network_json(str(tmp_path / "ac.json"))
+    ac.eval()
+    obs = torch.randn(8, 42)
+    assert torch.allclose(p2(obs), ac.step(obs)[0], atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_reference_policy_flies_the_batched_circle_env():
+    import phoenix_drone_simulation_amd as pds
+    from phoenix_drone_simulation_amd.policy_io import load_network_json
+    n = 4096
+    kw = dict(observation_noise=-1, domain_randomization=-1, motor_thrust_noise=0)
+    lens = {}
+    for name in ("policy", "random"):
+        env = pds.make("DroneCircleSimpleEnv-v0", num_envs=n, seed=3, **kw)
+        pol = load_network_json(FIX).to(env.device)
+        obs, _ = env.reset()
+        steps = torch.zeros(n, device=env.device); total, count = 0.0, 0.0
+        for t in range(300):
+            a = pol(obs) if name == "policy" else (-0.11 + 0.1 * torch.randn(n, 4, device=env.device))
+            obs, r, term, trunc, info = env.step(a.contiguous())
+            steps += 1
+            done = term | trunc
+            total += float((steps * done).sum()); count += float(done.sum())
+            steps = torch.where(done, torch.zeros_like(steps), steps)
+        total += float(steps.sum()); count += n
+        lens[name] = total / count
+        env.close()
+    assert lens["policy"] > 3 * lens["random"], lens
