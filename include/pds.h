@@ -46,6 +46,10 @@ extern "C" {
 #define PDS_TASK_CIRCLE 1  /* DroneCircleSimpleEnv-v0  */
 #define PDS_TASK_TAKEOFF 2 /* DroneTakeOffSimpleEnv-v0 */
 
+#define PDS_CTRL_PWM 0           /* envs/control.py:91-100  */
+#define PDS_CTRL_ATTITUDE_RATE 1 /* envs/control.py:120-191 */
+#define PDS_CTRL_ATTITUDE 2      /* envs/control.py:194-287 */
+
 #define PDS_OK 0
 #define PDS_EINVAL -1
 #define PDS_ENODEVICE -2
@@ -75,6 +79,8 @@ typedef struct pds_config {
   double penalty_action, penalty_angle, penalty_spin, penalty_terminal, penalty_velocity, ARP;
   double target_pos[3];
   double init_xyz[3], init_rpy[3], init_xyz_dot[3], init_rpy_dot[3];
+  int32_t control_mode;              /* PDS_CTRL_*: 'PWM' (default), 'AttitudeRate', 'Attitude' (envs/control.py) */
+  int32_t reserved_;
 } pds_config;
 
 typedef struct pds_handle pds_handle;
@@ -99,7 +105,8 @@ enum pds_field {
   PDS_F_GYRO_BIAS = 15,  /* 3  sensor_noise.gyro_bias */
   PDS_F_GYRO_LPF = 16,   /* 3  gyro_lpf._x */
   PDS_F_NOISY_OBS = 17,  /* 10 observation_history[-1][0:10]: noisy xyz, quaternion, velocity */
-  PDS_F_COUNT_ = 18
+  PDS_F_PID = 18,        /* 12 rate integral3, rate last_error3, attitude integral3, attitude last_error3 */
+  PDS_F_COUNT_ = 19
 };
 
 /* Layout of one row of `d_samples` for pds_reset_from_samples (the values np.random returned in

@@ -37,6 +37,7 @@ class Config(C.Structure):
         ("penalty_terminal", C.c_double), ("penalty_velocity", C.c_double), ("ARP", C.c_double),
         ("target_pos", C.c_double * 3), ("init_xyz", C.c_double * 3),
         ("init_rpy", C.c_double * 3), ("init_xyz_dot", C.c_double * 3), ("init_rpy_dot", C.c_double * 3),
+        ("control_mode", C.c_int32), ("pad2_", C.c_int32),
     ]
 
 
@@ -75,6 +76,7 @@ def _env_struct(real):
             ("A", real * 4), ("B", real * 4), ("K", real * 4), ("T", real * 4), ("t2w", real * 4),
             ("T_s", real),
             ("ou", real * 4), ("gyro_bias", real * 3), ("lpf", real * 3), ("kf_state", real * 17),
+            ("rate_int", real * 3), ("rate_err", real * 3), ("att_int", real * 3), ("att_err", real * 3),
             ("iteration", C.c_int32), ("ref_offset", C.c_int32), ("elapsed_steps", C.c_int32),
             ("obs_len", C.c_int32),
         ]
@@ -118,6 +120,8 @@ def default_config(task, **overrides):
                 getattr(c, k)[i] = float(v[i])
         elif k == "observation_noise":
             c.observation_noise = 1 if v > 0 else 0
+        elif k == "control_mode":
+            c.control_mode = {"PWM": 0, "AttitudeRate": 1, "Attitude": 2}[v] if isinstance(v, str) else int(v)
         else:
             assert hasattr(c, k), k
             setattr(c, k, v)

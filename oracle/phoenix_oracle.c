@@ -240,6 +240,58 @@ void SUF(po_update_motor_dynamics)(ENV *e, const REAL *T_new, const REAL *Ts_new
 
 static REAL clipr(REAL v, REAL lo, REAL hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+/* envs/control.py:120-191 AttitudeRate, :194-287 Attitude (cascaded), :34-50 mixer.  The
+ * controllers are built with time_step = 1/sim_freq (envs/agents.py:72-77) and keep it under
+ * domain randomisation. */
+static void rate_pid(const po_config *c, ENV *e, const REAL target[3], REAL out[3]) {
+  const REAL kp[3] = {250, 250, 120}, ki[3] = {500, 500, (REAL)16.7}, kd[3] = {(REAL)2.5, (REAL)2.5, 0};
+  const REAL lim[3] = {(REAL)33.3, (REAL)33.3, (REAL)166.7};
+  const REAL dt = (REAL)c->time_step;
+  for (int i = 0; i < 3; ++i) {
+    REAL error = (target[i] - e->rpy_dot[i]) * (REAL)180. / (REAL)PO_PI;   /* control.py:166 */
+    REAL derivative = (error - e->rate_err[i]) / dt;
+    e->rate_err[i] = error;
+    e->rate_int[i] = clipr(e->rate_int[i] + error * dt, -lim[i], lim[i]);
+    out[i] = kp[i] * error + ki[i] * e->rate_int[i] + kd[i] * derivative;   /* :174-176 */
+  }
+}
+
+static void att_pid(const po_config *c, ENV *e, const REAL target[3], REAL out[3]) {
+  const REAL kp[3] = {6, 6, 6}, ki[3] = {3, 3, 1}, kd[3] = {0, 0, (REAL)0.35};
+  const REAL lim[3] = {20, 20, 360};
+  const REAL dt = (REAL)c->time_step;
+  for (int i = 0; i < 3; ++i) {
+    REAL error = (target[i] - e->rpy[i]) * (REAL)180. / (REAL)PO_PI;       /* control.py:268 */
+    REAL derivative = (error - e->att_err[i]) / dt;
+    e->att_err[i] = error;
+    e->att_int[i] = clipr(e->att_int[i] + error * dt, -lim[i], lim[i]);
+    REAL o = kp[i] * error + ki[i] * e->att_int[i] + kd[i] * derivative;
+    out[i] = o / (REAL)180. * (REAL)PO_PI;                                  /* degree_to_rad :277 */
+  }
+}
+
+static void control_pid(const po_config *c, ENV *e, const REAL a[4]) {
+  REAL ca[4], factors[3], thrust;
+  for (int i = 0; i < 4; ++i) ca[i] = clipr(a[i], -1, 1);
+  if (c->control_mode == 1) {              /* AttitudeRate.act, control.py:151-160 */
+    thrust = (REAL)30000 + ca[0] * (REAL)30000;
+    REAL tgt[3] = {ca[1] * (REAL)PO_PI / 3, ca[2] * (REAL)PO_PI / 3, ca[3] * (REAL)PO_PI / 3};
+    rate_pid(c, e, tgt, factors);
+  } else {                                 /* Attitude.act, control.py:244-259 */
+    REAL tgt[3] = {ca[1] * (REAL)PO_PI / 18, ca[2] * (REAL)PO_PI / 18, ca[3] * (REAL)PO_PI / 18};
+    thrust = (REAL)45000 + ca[0] * (REAL)10000;
+    REAL rates[3];
+    att_pid(c, e, tgt, rates);
+    rate_pid(c, e, rates, factors);
+  }
+  /* rpy_control_factors_to_PWM, control.py:34-50 */
+  const REAL r = factors[0] / (REAL)2.0, p = factors[1] / (REAL)2.0, y = factors[2];
+  e->pwm[0] = clipr(thrust - r - p - y, 0, 60000);
+  e->pwm[1] = clipr(thrust - r + p + y, 0, 60000);
+  e->pwm[2] = clipr(thrust + r + p - y, 0, 60000);
+  e->pwm[3] = clipr(thrust + r - p + y, 0, 60000);
+}
+
 /* envs/agents.py:259-298 apply_action (use_latency False for the Simple agent, :492), with
  * envs/control.py:94-100 PWM.act and envs/utils.py:104-108 OUNoise.noise inlined. */
 void SUF(po_apply_action)(const po_config *c, ENV *e, const REAL a[4], po_rng *rng, REAL forces[4],
@@ -247,8 +299,12 @@ void SUF(po_apply_action)(const po_config *c, ENV *e, const REAL a[4], po_rng *r
   REAL torques[4];
   const REAL sigma = (REAL)(0.2 * c->motor_thrust_noise); /* agents.py:206 */
   for (int i = 0; i < 4; ++i) e->last_action[i] = a[i];   /* :264 */
-  for (int i = 0; i < 4; ++i)                              /* control.py:98-99 */
-    e->pwm[i] = (REAL)30000 + clipr(a[i], -1, 1) * (REAL)30000;
+  if (c->control_mode == 0) {
+    for (int i = 0; i < 4; ++i)                            /* PWM.act, control.py:98-99 */
+      e->pwm[i] = (REAL)30000 + clipr(a[i], -1, 1) * (REAL)30000;
+  } else {
+    control_pid(c, e, a);                                  /* AttitudeRate.act / Attitude.act */
+  }
   for (int i = 0; i < 4; ++i) { /* utils.py:105-107: dx = theta*(mu-x) + sigma*randn; theta .15 mu 0 */
     REAL x = e->ou[i];
     REAL dx = (REAL)0.15 * ((REAL)0 - x) + sigma * rng_normal(rng);
@@ -541,6 +597,7 @@ void SUF(po_reset)(const po_config *c, ENV *e, const po_reset_sample *s, po_rng 
   e->elapsed_steps = 0;        /* TimeLimit.reset */
   /* drone.reset(): agents.py:380-386 */
   for (int i = 0; i < 4; ++i) { e->x[i] = 0; e->y[i] = 0; e->last_action[i] = 0; }
+  for (int i = 0; i < 3; ++i) { e->rate_int[i] = e->rate_err[i] = e->att_int[i] = e->att_err[i] = 0; } /* control.reset() */
 
   /* ---- task_specific_reset ---- */
   REAL pos[3] = {(REAL)c->init_xyz[0], (REAL)c->init_xyz[1], (REAL)c->init_xyz[2]};

@@ -52,6 +52,8 @@ typedef struct po_config {
   double target_pos[3];
   double init_xyz[3];
   double init_rpy[3], init_xyz_dot[3], init_rpy_dot[3]; /* envs/base.py:84-91; mutated by simopt callers */
+  int32_t control_mode;              /* 0 PWM, 1 AttitudeRate, 2 Attitude (envs/control.py:91-287) */
+  int32_t pad2_;
 } po_config;
 
 /* Values drawn by one reset() in the reference's draw order (the *sampled values*, i.e. what
@@ -86,6 +88,7 @@ typedef struct po_rng {
     REAL target_pos[3];                                                                             \
     REAL dt, m, J[3], ftf0, ftf1, A[4], B[4], K[4], T[4], t2w[4], T_s;                             \
     REAL ou[4], gyro_bias[3], lpf[3], kf_state[17];                                                 \
+    REAL rate_int[3], rate_err[3], att_int[3], att_err[3]; /* PID integrals / last errors */        \
     int32_t iteration, ref_offset, elapsed_steps, obs_len;                                          \
   } po_env##SUF;                                                                                    \
   int po_sizeof_env##SUF(void);                                                                     \

@@ -90,7 +90,8 @@ class Recorder:
 # ------------------------------------------------------------------------------------------------
 STATE_FIELDS = ["xyz", "rpy", "quat", "xyz_dot", "rpy_dot", "x", "last_action", "env_last_action",
                 "act_hist", "obs_hist", "target_pos", "dt", "m", "J", "ftf0", "ftf1", "A", "B", "K",
-                "ou", "gyro_bias", "lpf", "kf_state", "iteration", "ref_offset"]
+                "ou", "gyro_bias", "lpf", "kf_state", "iteration", "ref_offset",
+                "rate_int", "rate_err", "att_int", "att_err"]
 
 
 def capture(env):
@@ -119,6 +120,15 @@ def capture(env):
         kf_state=np.array(e.state, dtype=np.float64).reshape(-1)[:17],
         iteration=int(e.iteration), ref_offset=int(getattr(e, "ref_offset", 0)),
     )
+    # PID controller state (envs/control.py:133-134, 227-228, 239-241)
+    ctl = d.control
+    z3 = np.zeros(3)
+    rate = getattr(ctl, "attitude_rate_controller", ctl if hasattr(ctl, "kp_att_rate") else None)
+    st["rate_int"] = np.array(rate.integral, dtype=np.float64) if rate is not None else z3
+    st["rate_err"] = np.array(rate.last_error, dtype=np.float64) if rate is not None else z3
+    att = ctl if hasattr(ctl, "kps") else None
+    st["att_int"] = np.array(att.integral, dtype=np.float64) if att is not None else z3
+    st["att_err"] = np.array(att.last_error, dtype=np.float64) if att is not None else z3
     return st
 
 
@@ -418,6 +428,13 @@ def main():
         scen.append((f"{task}_defaults", task, dict(), 12, 10, act_random(0.2), 160 + ti, False, None, False))
         scen.append((f"{task}_noise_only", task, dict(domain_randomization=-1, motor_thrust_noise=0.05), 6, 10, act_random(0.2), 170 + ti, False, None, False))
         scen.append((f"{task}_agg2", task, dict(DET, aggregate_phy_steps=2) if task != "takeoff" else None, 6, 10, act_random(0.3), 180 + ti, False, None, False))
+    # PID control modes on the Simple physics (envs/control.py:120-287)
+    pid_act = lambda ep, t, rs, e: np.clip(0.5 * rs.standard_normal(4), -1.3, 1.3) * np.array([0.3, 1, 1, 1]) + np.array([-0.1, 0, 0, 0])
+    scen.append(("hover_rate", "hover", dict(DET, control_mode="AttitudeRate"), 10, 10, pid_act, 200, False, None, False))
+    scen.append(("hover_rate_agg4_dr", "hover", dict(DET, control_mode="AttitudeRate", aggregate_phy_steps=4, domain_randomization=0.1), 8, 8, pid_act, 201, False, None, False))
+    scen.append(("hover_att_agg2", "hover", dict(DET, control_mode="Attitude", aggregate_phy_steps=2), 10, 10, pid_act, 202, False, None, False))
+    scen.append(("circle_att_motor", "circle", dict(DET, control_mode="Attitude"), 8, 10, pid_act, 203, True, None, False))
+    scen.append(("circle_rate_noise_only", "circle", dict(control_mode="AttitudeRate", domain_randomization=-1), 6, 8, pid_act, 204, False, None, False))
     scen.append(("hover_edge", "hover", dict(DET, enable_reset_distribution=False), 20, 3, act_random(0.2), 190, False, edge_hover, True))
     scen.append(("takeoff_edge", "takeoff", dict(DET, enable_reset_distribution=False), 3, 4, act_random(0.2, center=0.3), 191, False, edge_takeoff, True))
     scen.append(("circle_edge", "circle", dict(DET, enable_reset_distribution=False), 3, 4, act_random(0.2), 192, False, edge_circle, True))

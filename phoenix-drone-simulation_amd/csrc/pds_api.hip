@@ -23,7 +23,7 @@ struct FieldArgs {
   int field;
   int parity;
   int set;
-  int has_motor, has_dr, has_tn, has_on;
+  int has_motor, has_dr, has_tn, has_on, ctrl;
 };
 
 __global__ __launch_bounds__(kBlock) void field_kernel(const FieldArgs a) {
@@ -129,6 +129,20 @@ __global__ __launch_bounds__(kBlock) void field_kernel(const FieldArgs a) {
         for (int j = 0; j < 10; ++j) uf[10 * i + j] = 0.f;
       }
       break;
+    case PDS_F_PID: {
+      float v[12];
+      for (int j = 0; j < 12; ++j) v[j] = 0.f;
+      if (a.set) {
+        for (int j = 0; j < 12; ++j) v[j] = uf[12 * i + j];
+        if (a.ctrl >= 1) { a.st.pid0[i] = make_float4(v[0], v[1], v[2], v[3]); a.st.pid1[i] = make_float2(v[4], v[5]); }
+        if (a.ctrl == 2) { a.st.pid2[i] = make_float4(v[6], v[7], v[8], v[9]); a.st.pid3[i] = make_float2(v[10], v[11]); }
+      } else {
+        if (a.ctrl >= 1) { const float4 p0 = a.st.pid0[i]; const float2 p1 = a.st.pid1[i]; v[0] = p0.x; v[1] = p0.y; v[2] = p0.z; v[3] = p0.w; v[4] = p1.x; v[5] = p1.y; }
+        if (a.ctrl == 2) { const float4 p2 = a.st.pid2[i]; const float2 p3 = a.st.pid3[i]; v[6] = p2.x; v[7] = p2.y; v[8] = p2.z; v[9] = p2.w; v[10] = p3.x; v[11] = p3.y; }
+        for (int j = 0; j < 12; ++j) uf[12 * i + j] = v[j];
+      }
+      break;
+    }
     default: break;
   }
 }
@@ -204,6 +218,7 @@ extern "C" int pds_default_config(int task, pds_config *c) {
   c->ARP = (task == PDS_TASK_CIRCLE) ? 1e-3 : 0.0;
   c->target_pos[2] = 1.0;
   c->init_xyz[2] = (task == PDS_TASK_TAKEOFF) ? (double)0.0125f : 1.0;
+  c->control_mode = PDS_CTRL_PWM;
   return PDS_OK;
 }
 
@@ -268,6 +283,12 @@ extern "C" int pds_create(const pds_config *cfg, pds_handle **out) {
     snprintf(g_create_err, sizeof(g_create_err), "invalid pds_config");
     return PDS_EINVAL;
   }
+  if (cfg->control_mode < 0 || cfg->control_mode > 2 ||
+      (cfg->control_mode != PDS_CTRL_PWM && (cfg->task == PDS_TASK_TAKEOFF || cfg->use_ground_effect))) {
+    snprintf(g_create_err, sizeof(g_create_err),
+             "control_mode %d: the PID modes exist for Hover/Circle without the ground-effect extension", cfg->control_mode);
+    return cfg->control_mode < 0 || cfg->control_mode > 2 ? PDS_EINVAL : PDS_EUNSUPPORTED;
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device >= ndev) {
     snprintf(g_create_err, sizeof(g_create_err), "no HIP device %d (found %d); there is no CPU fallback", cfg->device, ndev);
@@ -284,6 +305,7 @@ extern "C" int pds_create(const pds_config *cfg, pds_handle **out) {
   h->flags.ge = cfg->use_ground_effect != 0;
   h->flags.tn = cfg->motor_thrust_noise > 0;
   h->flags.on = cfg->observation_noise > 0;
+  h->flags.ctrl = cfg->control_mode;
   {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess || cus <= 0) cus = 256;
@@ -306,6 +328,8 @@ extern "C" int pds_create(const pds_config *cfg, pds_handle **out) {
     alloc((void **)&h->st.nz0, n * 16); alloc((void **)&h->st.nz1, n * 8);
     alloc((void **)&h->st.oh0, n * 16); alloc((void **)&h->st.oh1, n * 16); alloc((void **)&h->st.oh2, n * 8);
   }
+  if (f.ctrl >= 1) { alloc((void **)&h->st.pid0, n * 16); alloc((void **)&h->st.pid1, n * 8); }
+  if (f.ctrl == 2) { alloc((void **)&h->st.pid2, n * 16); alloc((void **)&h->st.pid3, n * 8); }
   alloc((void **)&h->d_circle_ref, kRefPoints * sizeof(float2));
   if (e == hipSuccess) {
     float2 ref[kRefPoints];  // envs/circle.py:45-56
@@ -331,7 +355,7 @@ extern "C" int pds_destroy(pds_handle *h) {
   (void)hipSetDevice(h->cfg.device);
   void *ptrs[] = {h->st.s0, h->st.s1, h->st.s2, h->st.hist[0], h->st.hist[1], h->st.ctr, h->st.mx,
                   h->st.par0, h->st.par1, h->st.mA, h->st.mK, h->st.ou, h->st.nz0, h->st.nz1,
-                  h->st.oh0, h->st.oh1, h->st.oh2, h->d_circle_ref};
+                  h->st.oh0, h->st.oh1, h->st.oh2, h->st.pid0, h->st.pid1, h->st.pid2, h->st.pid3, h->d_circle_ref};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   delete h;
   return PDS_OK;
@@ -355,6 +379,8 @@ extern "C" int pds_bytes_per_env_step(const pds_handle *h) {
   if (f.motor && f.dr) b += 32;
   if (f.tn) b += 32;
   if (f.on) b += 48 + 80;
+  if (f.ctrl >= 1) b += 48;  // rate-PID integral + last error, R+W
+  if (f.ctrl == 2) b += 48;  // attitude-PID integral + last error, R+W
   return b;
 }
 
@@ -451,6 +477,7 @@ extern "C" int pds_field_width(int field) {
     case PDS_F_STEP_COUNT: case PDS_F_QUAT_SIGN: case PDS_F_REF_OFFSET: return 1;
     case PDS_F_PARAMS: return 6;
     case PDS_F_NOISY_OBS: return 10;
+    case PDS_F_PID: return 12;
     default: return PDS_EINVAL;
   }
 }
@@ -463,7 +490,7 @@ static int do_field(pds_handle *h, int field, void *d_ptr, int set, void *stream
   FieldArgs a;
   memset(&a, 0, sizeof(a));
   a.st = h->st; a.k = h->k; a.user = d_ptr; a.n = h->cfg.num_envs; a.field = field; a.parity = h->parity; a.set = set;
-  a.has_motor = h->flags.motor; a.has_dr = h->flags.dr; a.has_tn = h->flags.tn; a.has_on = h->flags.on;
+  a.has_motor = h->flags.motor; a.has_dr = h->flags.dr; a.has_tn = h->flags.tn; a.has_on = h->flags.on; a.ctrl = h->flags.ctrl;
   const dim3 grid((unsigned)((a.n + kBlock - 1) / kBlock));
   hipLaunchKernelGGL(field_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, a);
   PDS_HIP(h, hipGetLastError());

@@ -388,6 +388,14 @@ PDS_DEV void reset_store(const StepArgs &a, const float2 *ref_lds, long long i, 
   a.st.hist[0][i] = r.u0;
   a.st.hist[1][i] = r.u0;
   a.st.ctr[i] = r.ctr;
+  if (a.st.pid0 != nullptr) {  // control.reset(): envs/agents.py:379, envs/control.py:178-187, 279-287
+    a.st.pid0[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    a.st.pid1[i] = make_float2(0.f, 0.f);
+    if (a.st.pid2 != nullptr) {
+      a.st.pid2[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      a.st.pid3[i] = make_float2(0.f, 0.f);
+    }
+  }
   if (V::MOTOR) a.st.mx[i] = r.mx;
   if (V::DR) {
     a.st.par0[i] = make_float4(r.par.dt, r.par.m, r.par.Jx, r.par.Jy);

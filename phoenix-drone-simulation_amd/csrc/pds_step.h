@@ -36,8 +36,8 @@ PDS_DEV void flush_tile(const float *tile, float *gdst, int rows, int lane) {
 
 // Inputs of one env-step, loaded 16 B/lane.
 struct Loaded {
-  float4 act, q0, q1, q2, h1, h2, mx, p0, mA, mK, ou, nz0, oh0, oh1;
-  float2 p1, nz1, oh2;
+  float4 act, q0, q1, q2, h1, h2, mx, p0, mA, mK, ou, nz0, oh0, oh1, pid0, pid2;
+  float2 p1, nz1, oh2, pid1, pid3;
   uint32_t ctr;
 };
 
@@ -57,10 +57,70 @@ PDS_DEV void load_env(const StepArgs &a, long long ii, Loaded &L) {
     if (V::MOTOR) { L.mA = a.st.mA[ii]; L.mK = a.st.mK[ii]; }
   }
   if (V::TN) L.ou = a.st.ou[ii];
+  if (V::CTRL >= 1) { L.pid0 = a.st.pid0[ii]; L.pid1 = a.st.pid1[ii]; }
+  if (V::CTRL == 2) { L.pid2 = a.st.pid2[ii]; L.pid3 = a.st.pid3[ii]; }
   if (V::ON) {
     L.nz0 = a.st.nz0[ii]; L.nz1 = a.st.nz1[ii];
     L.oh0 = a.st.oh0[ii]; L.oh1 = a.st.oh1[ii]; L.oh2 = a.st.oh2[ii];
   }
+}
+
+// envs/control.py:120-191 AttitudeRate.compute_output: PID on the body rates in deg/s with the
+// firmware gains (control.py:12-27); dt is the controller's construction-time step 1/sim_freq.
+PDS_DEV void rate_pid(float dt, const EnvRegs &e, const float target[3], PidState &ps, float out[3]) {
+  const float kp[3] = {250.f, 250.f, 120.f}, ki[3] = {500.f, 500.f, 16.7f}, kd[3] = {2.5f, 2.5f, 0.f};
+  const float lim[3] = {33.3f, 33.3f, 166.7f};
+  const float w[3] = {e.wx, e.wy, e.wz};
+  const float inv_dt = 1.0f / dt;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float error = (target[i] - w[i]) * 180.f / kPi;
+    const float derivative = (error - ps.rate_err[i]) * inv_dt;
+    ps.rate_err[i] = error;
+    ps.rate_int[i] = clampf(ps.rate_int[i] + error * dt, -lim[i], lim[i]);
+    out[i] = kp[i] * error + ki[i] * ps.rate_int[i] + kd[i] * derivative;
+  }
+}
+
+// envs/control.py:194-287 Attitude.compute_output: outer loop on the Euler angles, output in rad/s
+PDS_DEV void att_pid(float dt, const EnvRegs &e, const float target[3], PidState &ps, float out[3]) {
+  const float kp[3] = {6.f, 6.f, 6.f}, ki[3] = {3.f, 3.f, 1.f}, kd[3] = {0.f, 0.f, 0.35f};
+  const float lim[3] = {20.f, 20.f, 360.f};
+  const float r[3] = {e.roll, e.pitch, e.yaw};
+  const float inv_dt = 1.0f / dt;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float error = (target[i] - r[i]) * 180.f / kPi;
+    const float derivative = (error - ps.att_err[i]) * inv_dt;
+    ps.att_err[i] = error;
+    ps.att_int[i] = clampf(ps.att_int[i] + error * dt, -lim[i], lim[i]);
+    out[i] = (kp[i] * error + ki[i] * ps.att_int[i] + kd[i] * derivative) / 180.f * kPi;
+  }
+}
+
+// action -> PWM for the PID control modes: AttitudeRate.act (control.py:151-160) / Attitude.act
+// (control.py:244-259) + rpy_control_factors_to_PWM (control.py:34-50)
+template <int CTRL>
+PDS_DEV void control_pwm(float dt, const EnvRegs &e, const float av[4], PidState &ps, float pwm[4]) {
+  const float c0 = clampf(av[0], -1.f, 1.f), c1 = clampf(av[1], -1.f, 1.f), c2 = clampf(av[2], -1.f, 1.f),
+              c3 = clampf(av[3], -1.f, 1.f);
+  float factors[3], thrust;
+  if (CTRL == 1) {
+    thrust = 30000.f + c0 * 30000.f;
+    const float tgt[3] = {c1 * kPi / 3.f, c2 * kPi / 3.f, c3 * kPi / 3.f};
+    rate_pid(dt, e, tgt, ps, factors);
+  } else {
+    const float tgt[3] = {c1 * kPi / 18.f, c2 * kPi / 18.f, c3 * kPi / 18.f};
+    thrust = 45000.f + c0 * 10000.f;
+    float rates[3];
+    att_pid(dt, e, tgt, ps, rates);
+    rate_pid(dt, e, rates, ps, factors);
+  }
+  const float r = factors[0] * 0.5f, p = factors[1] * 0.5f, y = factors[2];
+  pwm[0] = clampf(thrust - r - p - y, 0.f, 60000.f);
+  pwm[1] = clampf(thrust - r + p + y, 0.f, 60000.f);
+  pwm[2] = clampf(thrust + r + p - y, 0.f, 60000.f);
+  pwm[3] = clampf(thrust + r - p + y, 0.f, 60000.f);
 }
 
 // Standard variates of one physics sub-step: OUNoise.noise (4 z) and the gyro part of the
@@ -180,6 +240,17 @@ __global__ __launch_bounds__(kBlock, PDS_MIN_WAVES) void step_kernel(const StepA
       ns.bias[0] = cur.nz0.x; ns.bias[1] = cur.nz0.y; ns.bias[2] = cur.nz0.z;
       ns.lpf[0] = cur.nz0.w; ns.lpf[1] = cur.nz1.x; ns.lpf[2] = cur.nz1.y;
     }
+    PidState ps;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { ps.rate_int[j] = ps.rate_err[j] = ps.att_int[j] = ps.att_err[j] = 0.f; }
+    if (V::CTRL >= 1) {
+      ps.rate_int[0] = cur.pid0.x; ps.rate_int[1] = cur.pid0.y; ps.rate_int[2] = cur.pid0.z;
+      ps.rate_err[0] = cur.pid0.w; ps.rate_err[1] = cur.pid1.x; ps.rate_err[2] = cur.pid1.y;
+    }
+    if (V::CTRL == 2) {
+      ps.att_int[0] = cur.pid2.x; ps.att_int[1] = cur.pid2.y; ps.att_int[2] = cur.pid2.z;
+      ps.att_err[0] = cur.pid2.w; ps.att_err[1] = cur.pid3.x; ps.att_err[2] = cur.pid3.y;
+    }
     EnvRegs e{cur.q0.x, cur.q0.y, cur.q0.z, cur.q0.w, cur.q1.x, cur.q1.y, cur.q1.z, cur.q1.w,
               cur.q2.x, cur.q2.y, cur.q2.z, cur.q2.w};
     const int step = (int)ctr_step(ctr);
@@ -212,11 +283,16 @@ __global__ __launch_bounds__(kBlock, PDS_MIN_WAVES) void step_kernel(const StepA
       SubNoise sn;
       if (V::TN || V::ON) sub_noise<V>(a, env_id, ii, sub, sn);
       // CrazyFlieAgent.apply_action, envs/agents.py:259-298 (+ PWM.act envs/control.py:94-100)
-      float f[4];
+      float f[4], pwmv[4];
+      if (V::CTRL == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pwmv[j] = 30000.f + clampf(av[j], -1.f, 1.f) * 30000.f;
+      } else {
+        control_pwm<V::CTRL>(k.dt_nom, e, av, ps, pwmv);
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float pwm = 30000.f + clampf(av[j], -1.f, 1.f) * 30000.f;
-        const float un = pwm * (1.0f / 60000.f);
+        const float un = pwmv[j] * (1.0f / 60000.f);
         float noise1 = 1.0f;
         if (V::TN) {  // OUNoise.noise, envs/utils.py:104-108 (theta .15, mu 0); never reset
           ns.ou[j] = ns.ou[j] + (0.15f * (0.f - ns.ou[j]) + k.ou_sigma * sn.ou[j]);
@@ -364,6 +440,14 @@ __global__ __launch_bounds__(kBlock, PDS_MIN_WAVES) void step_kernel(const StepA
       a.st.ctr[i] = ctr_new;
       if (V::MOTOR) a.st.mx[i] = make_float4(xm[0], xm[1], xm[2], xm[3]);
       if (V::TN) a.st.ou[i] = make_float4(ns.ou[0], ns.ou[1], ns.ou[2], ns.ou[3]);
+      if (V::CTRL >= 1) {
+        a.st.pid0[i] = make_float4(ps.rate_int[0], ps.rate_int[1], ps.rate_int[2], ps.rate_err[0]);
+        a.st.pid1[i] = make_float2(ps.rate_err[1], ps.rate_err[2]);
+      }
+      if (V::CTRL == 2) {
+        a.st.pid2[i] = make_float4(ps.att_int[0], ps.att_int[1], ps.att_int[2], ps.att_err[0]);
+        a.st.pid3[i] = make_float2(ps.att_err[1], ps.att_err[2]);
+      }
       if (V::ON) {
         a.st.nz0[i] = make_float4(ns.bias[0], ns.bias[1], ns.bias[2], ns.lpf[0]);
         a.st.nz1[i] = make_float2(ns.lpf[1], ns.lpf[2]);
@@ -419,9 +503,34 @@ __global__ __launch_bounds__(kBlock, PDS_MIN_WAVES) void step_kernel(const StepA
 #define PDS_LAUNCH_STEP(V, grid, s, a) hipLaunchKernelGGL((step_kernel<PDS_UNPAREN V>), grid, dim3(kBlock), 0, s, a)
 #define PDS_LAUNCH_RESET(V, grid, s, a) hipLaunchKernelGGL((reset_kernel<PDS_UNPAREN V>), grid, dim3(kBlock), 0, s, a)
 
+// PID control modes: 16 variants each (motor x DR x thrust noise x observation noise), no ground effect
+#define PDS_PID_CASES(TASK, C, grid, s, a)                                                            \
+  switch ((f.motor ? 8 : 0) | (f.dr ? 4 : 0) | (f.tn ? 2 : 0) | (f.on ? 1 : 0)) {                    \
+    case 0: PDS_LAUNCH_STEP((Variant<TASK, false, false, false, false, false, C>), grid, s, a); break; \
+    case 1: PDS_LAUNCH_STEP((Variant<TASK, false, false, false, false, true, C>), grid, s, a); break;  \
+    case 2: PDS_LAUNCH_STEP((Variant<TASK, false, false, false, true, false, C>), grid, s, a); break;  \
+    case 3: PDS_LAUNCH_STEP((Variant<TASK, false, false, false, true, true, C>), grid, s, a); break;   \
+    case 4: PDS_LAUNCH_STEP((Variant<TASK, false, true, false, false, false, C>), grid, s, a); break;  \
+    case 5: PDS_LAUNCH_STEP((Variant<TASK, false, true, false, false, true, C>), grid, s, a); break;   \
+    case 6: PDS_LAUNCH_STEP((Variant<TASK, false, true, false, true, false, C>), grid, s, a); break;   \
+    case 7: PDS_LAUNCH_STEP((Variant<TASK, false, true, false, true, true, C>), grid, s, a); break;    \
+    case 8: PDS_LAUNCH_STEP((Variant<TASK, true, false, false, false, false, C>), grid, s, a); break;  \
+    case 9: PDS_LAUNCH_STEP((Variant<TASK, true, false, false, false, true, C>), grid, s, a); break;   \
+    case 10: PDS_LAUNCH_STEP((Variant<TASK, true, false, false, true, false, C>), grid, s, a); break;  \
+    case 11: PDS_LAUNCH_STEP((Variant<TASK, true, false, false, true, true, C>), grid, s, a); break;   \
+    case 12: PDS_LAUNCH_STEP((Variant<TASK, true, true, false, false, false, C>), grid, s, a); break;  \
+    case 13: PDS_LAUNCH_STEP((Variant<TASK, true, true, false, false, true, C>), grid, s, a); break;   \
+    case 14: PDS_LAUNCH_STEP((Variant<TASK, true, true, false, true, false, C>), grid, s, a); break;   \
+    default: PDS_LAUNCH_STEP((Variant<TASK, true, true, false, true, true, C>), grid, s, a); break;    \
+  }
+
 #define PDS_DEFINE_TASK_LAUNCHERS(NAME, TASK)                                                        \
   void launch_step_##NAME(const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a) {       \
-    PDS_DISPATCH5(PDS_LAUNCH_STEP, TASK, f, grid, s, a);                                             \
+    if (f.ctrl == 0) {                                                                                \
+      PDS_DISPATCH5(PDS_LAUNCH_STEP, TASK, f, grid, s, a);                                           \
+    } else if (TASK != PDS_TASK_TAKEOFF) { /* TakeOff fixes control_mode='PWM', envs/takeoff.py:225 */ \
+      if (f.ctrl == 1) { PDS_PID_CASES(TASK, 1, grid, s, a) } else { PDS_PID_CASES(TASK, 2, grid, s, a) } \
+    }                                                                                                 \
   }                                                                                                   \
   void launch_reset_##NAME(const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a) {      \
     /* the reset code does not depend on the GE / TN flags: 8 variants */                            \

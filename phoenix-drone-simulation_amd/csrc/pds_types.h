@@ -41,6 +41,10 @@ struct DevState {
   float4 *oh0;      // noisy o(k): x y z qx             (observation_noise > 0; a noisy observation
   float4 *oh1;      //             qy qz qw vx           cannot be rebuilt from the true state, so the
   float2 *oh2;      //             vy vz                 history half is kept)
+  float4 *pid0;     // rate-PID integral xyz, last_error x  (control_mode != PWM)
+  float2 *pid1;     // rate-PID last_error y z
+  float4 *pid2;     // attitude-PID integral xyz, last_error x (control_mode == Attitude)
+  float2 *pid3;     // attitude-PID last_error y z
   const float2 *circle_ref;  // [300] (x, y) of the reference circle, z = 1
 };
 
@@ -80,8 +84,9 @@ struct StepArgs {
 };
 
 // Compile-time variant of the fused step: task and feature flags.
-template <int TASK_, bool MOTOR_, bool DR_, bool GE_, bool TN_, bool ON_>
+template <int TASK_, bool MOTOR_, bool DR_, bool GE_, bool TN_, bool ON_, int CTRL_ = 0>
 struct Variant {
+  static constexpr int CTRL = CTRL_;     // 0 PWM, 1 AttitudeRate PID, 2 cascaded Attitude PID (envs/control.py)
   static constexpr int TASK = TASK_;
   static constexpr bool MOTOR = MOTOR_;  // first-order motor model (envs/agents.py:284-288)
   static constexpr bool DR = DR_;        // per-env dt, m, J, ftf1 (, A, K)
@@ -112,6 +117,10 @@ struct ObsNoise {
 // what a noisy observation keeps besides the filtered gyro (which lives in the low-pass state)
 struct NoisyObs {
   float x, y, z, qx, qy, qz, qw, vx, vy, vz;
+};
+
+struct PidState {  // envs/control.py:133-134, 227-228
+  float rate_int[3], rate_err[3], att_int[3], att_err[3];
 };
 
 struct NoiseState {
@@ -156,6 +165,7 @@ PDS_DEV int target_index(int step, int agg, int ref_offset) {
 // ---- host-side launch interface of the per-task translation units -------------------------------
 struct LaunchFlags {
   bool motor, dr, ge, tn, on;
+  int ctrl;
 };
 void launch_step_hover(const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
 void launch_step_circle(const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);

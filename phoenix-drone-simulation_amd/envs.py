@@ -80,8 +80,8 @@ class DroneVecEnv:
                  enable_reset_distribution=True, latency=0.015, motor_time_constant=0.080,
                  motor_thrust_noise=0.05, observation_frequency=100, observation_history_size=2,
                  render_mode=None, debug=False, max_episode_steps=500):
-        if control_mode != 'PWM':
-            raise NotImplementedError(f"control_mode={control_mode!r}: only 'PWM' is on the accelerated path")
+        if control_mode not in native.CONTROL_MODES:
+            raise AssertionError(f'Control={control_mode} not found.')  # envs/agents.py:70-71
         if observation_history_size != 2:
             raise NotImplementedError("observation_history_size != 2 is not on the accelerated path")
         if render_mode not in (None, 'rgb_array'):
@@ -102,6 +102,7 @@ class DroneVecEnv:
         cfg.device = self.device.index
         cfg.use_motor_dynamics = int(bool(use_motor_dynamics))
         cfg.use_ground_effect = int(bool(use_ground_effect))
+        cfg.control_mode = native.CONTROL_MODES[control_mode]
         cfg.observation_noise = 1 if observation_noise > 0 else 0
         cfg.aggregate_phy_steps = int(aggregate_phy_steps)
         cfg.enable_reset_distribution = int(bool(enable_reset_distribution))
@@ -278,8 +279,8 @@ class DroneTakeOffSimpleEnv(DroneVecEnv):
     task = "takeoff"
 
     def __init__(self, **kwargs):
-        if kwargs.get("aggregate_phy_steps", 1) != 1:
-            raise TypeError("DroneTakeOffSimpleEnv fixes aggregate_phy_steps=1 (envs/takeoff.py:224)")
+        if kwargs.get("aggregate_phy_steps", 1) != 1 or kwargs.get("control_mode", "PWM") != "PWM":
+            raise TypeError("DroneTakeOffSimpleEnv fixes aggregate_phy_steps=1, control_mode='PWM' (envs/takeoff.py:224-225)")
         super().__init__(**kwargs)
 
 

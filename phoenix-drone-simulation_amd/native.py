@@ -15,7 +15,8 @@ NOISE_FLOATS = 37
 # field ids (enum pds_field)
 FIELDS = dict(pos=0, rpy=1, vel=2, omega=3, quat=4, motor_x=5, last_action=6, prev_action=7,
               step_count=8, quat_sign=9, ref_offset=10, params=11, motor_A=12, motor_K=13, ou=14,
-              gyro_bias=15, gyro_lpf=16, noisy_obs=17)
+              gyro_bias=15, gyro_lpf=16, noisy_obs=17, pid=18)
+CONTROL_MODES = {'PWM': 0, 'AttitudeRate': 1, 'Attitude': 2}
 INT_FIELDS = ("step_count", "quat_sign", "ref_offset")
 # sample row offsets (PDS_S_*)
 SAMPLE_LAYOUT = dict(pos_offset=(0, 3), rpy=(3, 3), vel=(6, 3), omega=(9, 3), motor_x=(12, 4),
@@ -48,6 +49,7 @@ class Config(C.Structure):
         ("penalty_terminal", C.c_double), ("penalty_velocity", C.c_double), ("ARP", C.c_double),
         ("target_pos", C.c_double * 3), ("init_xyz", C.c_double * 3), ("init_rpy", C.c_double * 3),
         ("init_xyz_dot", C.c_double * 3), ("init_rpy_dot", C.c_double * 3),
+        ("control_mode", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 

@@ -28,8 +28,10 @@ def _inject_noise_state(env, ou, bias, lpf, noisy_obs10):
 @pytest.mark.parametrize("name", NOISE_SCENARIOS)
 def test_noisy_single_step_vs_reference(name):
     g = gu.Golden(name)
+    RTOL, ATOL = gu.tolerances(name)
     pre = {k: [] for k in ("xyz", "rpy", "quat", "xyz_dot", "rpy_dot", "x", "act_hist", "iteration", "ref_offset",
-                           "dt", "m", "J", "ftf1", "A", "K", "ou", "gyro_bias", "lpf", "obs_hist")}
+                           "dt", "m", "J", "ftf1", "A", "K", "ou", "gyro_bias", "lpf", "obs_hist",
+                           "rate_int", "rate_err", "att_int", "att_err")}
     exp = {k: [] for k in ("obs", "reward", "cost", "terminated", "truncated", "ou", "gyro_bias", "lpf", "xyz", "rpy_dot")}
     acts, variates = [], []
     for ep in range(g.E):

@@ -49,6 +49,8 @@ def _inject(env, st, agg):
     sign = (np.sum(st["quat"] * _quat_from_euler(st["rpy"]), -1) < 0).astype(np.int32)
     env.set_state("quat_sign", sign)
     env.set_state("ref_offset", st["ref_offset"].astype(np.int32))
+    if env.cfg.control_mode != 0:
+        env.set_state("pid", np.concatenate([st["rate_int"], st["rate_err"], st["att_int"], st["att_err"]], 1))
     if env.cfg.use_motor_dynamics:
         env.set_state("motor_x", st["x"])
     if env.cfg.domain_randomization > 0:
@@ -62,9 +64,10 @@ def _inject(env, st, agg):
 def _gather_single_steps(g):
     """All (episode, t) pairs of a scenario as one batch: pre-step state, action, expected outputs."""
     pre = {k: [] for k in ("xyz", "rpy", "quat", "xyz_dot", "rpy_dot", "x", "act_hist", "iteration",
-                           "ref_offset", "dt", "m", "J", "ftf1", "A", "K")}
+                           "ref_offset", "dt", "m", "J", "ftf1", "A", "K", "rate_int", "rate_err", "att_int",
+                           "att_err")}
     exp = {k: [] for k in ("obs", "reward", "cost", "terminated", "truncated", "xyz", "rpy", "xyz_dot",
-                           "rpy_dot", "x", "quat")}
+                           "rpy_dot", "x", "quat", "rate_int", "rate_err", "att_int", "att_err")}
     acts = []
     for ep in range(g.E):
         for t in range(g.n_valid(ep)):
@@ -73,7 +76,7 @@ def _gather_single_steps(g):
             acts.append(g["actions"][ep, t])
             for k in ("obs", "reward", "cost", "terminated", "truncated"):
                 exp[k].append(g[k][ep, t])
-            for k in ("xyz", "rpy", "xyz_dot", "rpy_dot", "x", "quat"):
+            for k in ("xyz", "rpy", "xyz_dot", "rpy_dot", "x", "quat", "rate_int", "rate_err", "att_int", "att_err"):
                 exp[k].append(g["step_" + k][ep, t])
     return ({k: np.array(v) for k, v in pre.items()}, np.array(acts), {k: np.array(v) for k, v in exp.items()})
 
@@ -84,6 +87,7 @@ def test_single_step_vs_reference(name):
     observation, reward, termination, truncation and cost."""
     g = gu.Golden(name)
     pre, acts, exp = _gather_single_steps(g)
+    RTOL, ATOL = gu.tolerances(name)
     B = acts.shape[0]
     agg = int(g.kwargs.get("aggregate_phy_steps", 1))
     env = _make(g, B, auto_reset=False)
@@ -104,6 +108,12 @@ def test_single_step_vs_reference(name):
     gu.assert_close(env.get_state("quat").cpu().numpy(), exp["quat"], RTOL, ATOL, name + " quat")
     if g.motor:
         gu.assert_close(env.get_state("motor_x").cpu().numpy(), exp["x"], RTOL, ATOL, name + " motor x")
+    if env.cfg.control_mode != 0:
+        pid = env.get_state("pid").cpu().numpy()
+        want = np.concatenate([exp["rate_int"], exp["rate_err"], exp["att_int"], exp["att_err"]], 1)
+        if env.cfg.control_mode == 1:
+            want[:, 6:] = 0
+        gu.assert_close(pid, want, 1e-4, 1e-3, name + " pid state")  # deg and deg/s, behind a 1/dt derivative
     env.close()
 
 

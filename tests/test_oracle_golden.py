@@ -100,13 +100,14 @@ def _replay(name, precision, rtol, atol, resync):
         for t in range(g.n_valid(ep)):
             if resync and t > 0:
                 # single-step parity: restart every step from the reference's recorded state
-                for k in gu.DYN_FIELDS + ["x", "last_action", "env_last_action", "act_hist", "obs_hist", "ou", "gyro_bias", "lpf", "kf_state"]:
+                for k in gu.DYN_FIELDS + ["x", "last_action", "env_last_action", "act_hist", "obs_hist", "ou", "gyro_bias", "lpf", "kf_state",
+                          "rate_int", "rate_err", "att_int", "att_err"]:
                     env.set(k, g["step_" + k][ep, t - 1])
             obs, r, term, trunc, cost = env.step(g["actions"][ep, t])
             w = f"{name} ep{ep} t{t}"
             gu.assert_close(obs, g["obs"][ep, t], rtol, atol, w + " obs")
             gu.assert_close(r, g["reward"][ep, t], rtol, atol * 10, w + " reward")
-            for k in gu.DYN_FIELDS + ["x", "ou", "gyro_bias", "lpf"]:
+            for k in gu.DYN_FIELDS + ["x", "ou", "gyro_bias", "lpf", "rate_int", "att_int"]:
                 gu.assert_close(env.get(k), g["step_" + k][ep, t], rtol, atol, w + " " + k)
             assert term == bool(g["terminated"][ep, t]), w
             assert trunc == bool(g["truncated"][ep, t]), w
@@ -125,4 +126,5 @@ def test_oracle_f32_single_step(name):
     """float32 oracle, re-synchronised to the reference state before every step: 1e-6 relative
     (north_star tolerance) + 2e-6 absolute for near-cancelling terms (yaw torque, tau_x/tau_y at
     equal thrusts integrate into rpy_dot with 1/J ~ 6e4 gain)."""
-    _replay(name, "f32", rtol=1e-6, atol=2e-6, resync=True)
+    rtol, atol = gu.tolerances(name)
+    _replay(name, "f32", rtol=rtol, atol=atol, resync=True)
