@@ -9,6 +9,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <utility>
+#include <vector>
 
 #include "pds_types.h"
 
@@ -160,6 +162,7 @@ struct pds_handle {
   Consts k;
   LaunchFlags flags;
   float2 *d_circle_ref;
+  void *slab;  // one allocation holds every state array (staggered, see pds_create)
   int obs_dim;
   int num_cus;
   long long grid_override;
@@ -316,7 +319,11 @@ extern "C" int pds_create(const pds_config *cfg, pds_handle **out) {
   const size_t n = (size_t)cfg->num_envs;
   const LaunchFlags &f = h->flags;
   hipError_t e = hipSetDevice(cfg->device);
-  auto alloc = [&](void **p, size_t bytes) { if (e == hipSuccess) { e = hipMalloc(p, bytes); if (e == hipSuccess) e = hipMemset(*p, 0, bytes); } };
+  // All state arrays live in ONE slab; consecutive arrays are staggered by an odd multiple of 256 B so
+  // that the 6-17 concurrent streams of the step kernel do not start at the same offset modulo a power
+  // of two (power-of-two env counts otherwise alias them onto the same HBM channels/banks).
+  std::vector<std::pair<void **, size_t>> req;
+  auto alloc = [&](void **p, size_t bytes) { req.emplace_back(p, bytes); };
   alloc((void **)&h->st.s0, n * 16); alloc((void **)&h->st.s1, n * 16); alloc((void **)&h->st.s2, n * 16);
   alloc((void **)&h->st.hist[0], n * 16); alloc((void **)&h->st.hist[1], n * 16);
   alloc((void **)&h->st.ctr, n * 4);
@@ -331,6 +338,21 @@ extern "C" int pds_create(const pds_config *cfg, pds_handle **out) {
   if (f.ctrl >= 1) { alloc((void **)&h->st.pid0, n * 16); alloc((void **)&h->st.pid1, n * 8); }
   if (f.ctrl == 2) { alloc((void **)&h->st.pid2, n * 16); alloc((void **)&h->st.pid3, n * 8); }
   alloc((void **)&h->d_circle_ref, kRefPoints * sizeof(float2));
+  {
+    const char *sv = getenv("PDS_STAGGER");
+    const size_t stagger = sv ? (size_t)atoll(sv) : (size_t)kStaggerBytes;
+    size_t total = 0;
+    std::vector<size_t> off;
+    for (size_t j = 0; j < req.size(); ++j) {
+      total = (total + 255) / 256 * 256 + stagger;
+      off.push_back(total);
+      total += req[j].second;
+    }
+    if (e == hipSuccess) e = hipMalloc(&h->slab, total + 256);
+    if (e == hipSuccess) e = hipMemset(h->slab, 0, total + 256);
+    if (e == hipSuccess)
+      for (size_t j = 0; j < req.size(); ++j) *req[j].first = (char *)h->slab + off[j];
+  }
   if (e == hipSuccess) {
     float2 ref[kRefPoints];  // envs/circle.py:45-56
     for (int t = 0; t < kRefPoints; ++t) {
@@ -353,10 +375,7 @@ extern "C" int pds_create(const pds_config *cfg, pds_handle **out) {
 extern "C" int pds_destroy(pds_handle *h) {
   if (!h) return PDS_OK;
   (void)hipSetDevice(h->cfg.device);
-  void *ptrs[] = {h->st.s0, h->st.s1, h->st.s2, h->st.hist[0], h->st.hist[1], h->st.ctr, h->st.mx,
-                  h->st.par0, h->st.par1, h->st.mA, h->st.mK, h->st.ou, h->st.nz0, h->st.nz1,
-                  h->st.oh0, h->st.oh1, h->st.oh2, h->st.pid0, h->st.pid1, h->st.pid2, h->st.pid3, h->d_circle_ref};
-  for (void *p : ptrs) if (p) (void)hipFree(p);
+  if (h->slab) (void)hipFree(h->slab);
   delete h;
   return PDS_OK;
 }
@@ -443,13 +462,8 @@ extern "C" int pds_step_with_variates(pds_handle *h, const float *d_actions, con
   a.obs = d_obs; a.reward = d_reward; a.term = d_terminated; a.trunc = d_truncated; a.cost = d_cost;
   a.final_obs = d_final_obs;
   a.noise = d_variates;
-  // default: one 256-env block per 4 tiles (the hardware dispatcher balances blocks whose
-  // deferred-reset drains have different lengths; measured faster than a resident grid).
-  // PDS_GRID_BLOCKS caps the grid (the kernel is a grid-stride loop): tuning knob.
-  const long long blocks_needed = (a.n + kBlock - 1) / kBlock;
-  long long blocks = blocks_needed;
-  if (h->grid_override > 0 && h->grid_override < blocks) blocks = h->grid_override;
-  const dim3 grid((unsigned)blocks);
+  // one 256-env block per 4 tiles
+  const dim3 grid((unsigned)((a.n + kBlock - 1) / kBlock));
   hipStream_t s = (hipStream_t)stream;
   switch (h->cfg.task) {
     case PDS_TASK_HOVER: launch_step_hover(h->flags, grid, s, a); break;

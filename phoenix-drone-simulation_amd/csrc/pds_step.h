@@ -165,10 +165,12 @@ PDS_DEV void sub_noise(const StepArgs &a, uint32_t env_id, long long ii, int sub
   for (int j = 0; j < 3; ++j) { n.bias_z[j] = z[4 + j]; n.rw_z[j] = z[7 + j]; n.to_z[j] = z[10 + j]; }
 }
 
-// Grid-stride kernel over 64-env tiles; the default launch gives every wave exactly one tile
-// (the hardware dispatcher then balances blocks whose deferred-reset drains differ in length).
-// A register-prefetched persistent variant (256 x 3 resident blocks) measured 66.7 us vs 62.7 us
-// for this shape and doubled the input registers, so there is no prefetch here.
+// One 64-env tile per wave, one launch covers all tiles (the hardware dispatcher balances blocks
+// whose deferred-reset drains differ in length).  A persistent grid-stride variant (256 x 3 resident
+// blocks, register prefetch of the next tile) measured 66.7 us vs 62.7 us for this shape, doubled the
+// input registers, and -- because the compiler hoists every loop-invariant kernel argument out of
+// the tile loop -- pushed the kernel over the SGPR budget (137 v_writelane/v_readlane spill
+// instructions in the main path), so there is no tile loop here.
 // __launch_bounds__(256, 3): LDS admits 3 blocks (12 waves) per CU, so cap VGPRs at 168.
 template <class V>
 // The lean variants are additionally held to 128 VGPRs (min 4 waves/SIMD): measured 2-3 % faster
@@ -197,24 +199,19 @@ __global__ __launch_bounds__(kBlock, PDS_MIN_WAVES) void step_kernel(const StepA
   float *tile = tile_all + wave * (kWave * D);
   float *row = tile + lane * D;
   const long long ntiles = (a.n + kWave - 1) / kWave;
-  const long long tstride = (long long)gridDim.x * (kBlock / kWave);
-  long long t = (long long)blockIdx.x * (kBlock / kWave) + wave;
+  const long long t = (long long)blockIdx.x * (kBlock / kWave) + wave;
   if (t >= ntiles) return;  // wave-uniform
 
-  // The loads of the first tile are issued before anything else so that the (long) scalar
-  // preamble of the kernel overlaps with their latency; the loads of a following tile (only when
-  // the grid is capped) are issued at the end of the iteration, into the same registers.
+  // The loads are issued before anything else so that the scalar preamble of the kernel
+  // (kernel-argument loads, uniform constants) overlaps with their latency.
+  const long long wave_base = t * kWave;
+  const long long i = wave_base + lane;
+  const bool active = i < a.n;
+  const long long ii = active ? i : (a.n - 1);  // tail lanes recompute the last env, stores masked
   Loaded cur;
-  {
-    const long long i0 = t * kWave + lane;
-    load_env<V>(a, i0 < a.n ? i0 : a.n - 1, cur);
-  }
+  load_env<V>(a, ii, cur);
   __builtin_amdgcn_sched_barrier(0);
-  for (;;) {
-    const long long wave_base = t * kWave;
-    const long long i = wave_base + lane;
-    const bool active = i < a.n;
-    const long long ii = active ? i : (a.n - 1);  // tail lanes recompute the last env, stores masked
+  {
     const uint32_t env_id = (uint32_t)(a.env_id_base + (unsigned long long)ii);
 
     const float4 act = cur.act, h1 = cur.h1, h2 = cur.h2;
@@ -468,14 +465,6 @@ __global__ __launch_bounds__(kBlock, PDS_MIN_WAVES) void step_kernel(const StepA
     flush_tile<D>(tile, a.obs + wave_base * D, rem >= kWave ? kWave : (int)rem, lane);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();  // the tile is rewritten by the next iteration
-    if (qcount > kQueueCap - kWave) {  // wave-uniform: next tile could overflow the queue
-      drain_reset_queue<V>(a, ref_lds, queue, qcount, lane, tile);
-      qcount = 0;
-    }
-    t += tstride;
-    if (t >= ntiles) break;  // wave-uniform
-    const long long j = t * kWave + lane;
-    load_env<V>(a, j < a.n ? j : a.n - 1, cur);
   }
   if (qcount > 0) drain_reset_queue<V>(a, ref_lds, queue, qcount, lane, tile);
 }
