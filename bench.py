@@ -39,7 +39,7 @@ def cpu_baseline(task, kw, target_seconds=12.0):
     for s in range(10):
         orc.step(acts[s % 8], seed=0, tick=1 + s)
     one = (time.perf_counter() - t0) / 10
-    steps = int(max(4, min(20000, target_seconds / max(one, 1e-5))))
+    steps = int(max(4, min(8000, target_seconds / max(one, 1e-5))))
     t0 = time.perf_counter()
     for s in range(steps):
         orc.step(acts[s % 8], seed=0, tick=2 + s)
