@@ -15,7 +15,7 @@ constexpr int kBlock = PDS_BLOCK;  // 4 waves; each wave owns a private LDS tile
 constexpr int kWave = 64;
 constexpr int kQueueCap = 64;    // deferred-reset queue entries per wave (LDS): one tile
 constexpr int kRefPoints = 300;  // envs/circle.py:48, envs/takeoff.py:43
-constexpr int kStaggerBytes = 4352;  // 17 x 256 B between consecutive state arrays (PDS_STAGGER overrides)
+constexpr int kStaggerBytes = 4352;  // 17 x 256 B between consecutive state arrays in the slab
 
 // ---- packing of the per-env counter word --------------------------------------------------------
 // bits 0..15 env.step calls since reset | bit 16 quaternion == -Q(rpy) | bits 17..25 Circle ref_offset
