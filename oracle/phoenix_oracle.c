@@ -695,6 +695,19 @@ static void box_muller(uint32_t a, uint32_t b, REAL *z0, REAL *z1) {
   *z1 = r * R_SIN(ang);
 }
 
+/* per-step noise: one word per Box-Muller pair (radius: high 20 bits, angle: low 12 bits), one
+ * 16-bit half word per uniform -- csrc/pds_device.h box_muller_word / u01_lo16 / u01_hi16 */
+static void box_muller_word(uint32_t w, REAL *z0, REAL *z1) {
+  REAL u1 = (REAL)((w >> 12) + 1u) * (REAL)(1.0 / 1048576.0);
+  REAL u2 = (REAL)(w & 0xFFFu) * (REAL)(1.0 / 4096.0);
+  REAL r = R_SQRT((REAL)-2 * R_LOG(u1));
+  REAL ang = (REAL)(2 * PO_PI) * u2;
+  *z0 = r * R_COS(ang);
+  *z1 = r * R_SIN(ang);
+}
+static REAL u01_lo16(uint32_t w) { return (REAL)(w & 0xFFFFu) * (REAL)(1.0 / 65536.0); }
+static REAL u01_hi16(uint32_t w) { return (REAL)(w >> 16) * (REAL)(1.0 / 65536.0); }
+
 void SUF(po_philox_reset_sample)(const po_config *c, uint64_t seed, uint64_t env_id, uint64_t tick,
                                  po_reset_sample *s) {
   po_constants k;
@@ -768,17 +781,20 @@ static void philox_words(uint64_t seed, uint64_t env_id, uint64_t tick, uint32_t
   }
 }
 
-/* one add_noise call that reaches the observation: 6 blocks -> z[24] (numpy order: pos3 vel3 bias3
+/* one add_noise call that reaches the observation: 3 blocks -> z[24] (numpy order: pos3 vel3 bias3
  * rw3 to3 theta3 acc6), u[9] (pos3 vel3 theta3) */
 static void obs_call_streams(uint64_t seed, uint64_t env_id, uint64_t tick, uint32_t blk0, double *z, double *u) {
-  uint32_t w[24];
-  philox_words(seed, env_id, tick, blk0, 6, w);
+  uint32_t w[12];
+  philox_words(seed, env_id, tick, blk0, 3, w);
   REAL n[18];
-  for (int p = 0; p < 9; ++p) box_muller(w[2 * p], w[2 * p + 1], &n[2 * p], &n[2 * p + 1]);
+  for (int p = 0; p < 9; ++p) box_muller_word(w[p], &n[2 * p], &n[2 * p + 1]);
   /* kernel order: pos_z vel_z bias rw to th_z  == numpy order of the first 18 normals */
   for (int i = 0; i < 18; ++i) z[i] = (double)n[i];
   for (int i = 18; i < 24; ++i) z[i] = 0;
-  for (int i = 0; i < 3; ++i) { u[i] = (double)u01(w[18 + i]); u[3 + i] = 0.5; u[6 + i] = (double)u01(w[21 + i]); }
+  for (int i = 0; i < 3; ++i) u[3 + i] = 0.5;
+  u[0] = (double)u01_lo16(w[9]);  u[1] = (double)u01_hi16(w[9]);
+  u[2] = (double)u01_lo16(w[10]); u[6] = (double)u01_hi16(w[10]);
+  u[7] = (double)u01_lo16(w[11]); u[8] = (double)u01_hi16(w[11]);
 }
 
 /* streams of one env.step() (aggregate_phy_steps sub-steps): per sub-step OU z4 + discarded call
@@ -788,13 +804,13 @@ static void step_streams(const po_config *c, uint64_t seed, uint64_t env_id, uin
   int iz = 0, iu = 0;
   const int on = c->observation_noise > 0;
   for (int sub = 0; sub < c->aggregate_phy_steps; ++sub) {
-    uint32_t w[16];
-    philox_words(seed, env_id, tick, PO_BLK_SUB_NOISE + 4u * (uint32_t)sub, on ? 4 : 1, w);
+    uint32_t w[8];
+    philox_words(seed, env_id, tick, PO_BLK_SUB_NOISE + 2u * (uint32_t)sub, on ? 2 : 1, w);
     REAL n[14];
     for (int i = 0; i < 14; ++i) n[i] = 0;
-    box_muller(w[0], w[1], &n[0], &n[1]);
-    box_muller(w[2], w[3], &n[2], &n[3]);
-    if (on) for (int p = 2; p < 7; ++p) box_muller(w[2 * p], w[2 * p + 1], &n[2 * p], &n[2 * p + 1]);
+    box_muller_word(w[0], &n[0], &n[1]);
+    box_muller_word(w[1], &n[2], &n[3]);
+    if (on) for (int p = 2; p < 7; ++p) box_muller_word(w[p], &n[2 * p], &n[2 * p + 1]);
     for (int i = 0; i < 4; ++i) z[iz++] = (double)n[i];             /* OUNoise randn(4) */
     if (on) {
       for (int i = 0; i < 6; ++i) z[iz++] = 0;                      /* pos, vel (discarded) */
@@ -826,7 +842,7 @@ void SUF(po_reset_batch)(const po_config *c, ENV *envs, int64_t n, REAL *obs, ui
     po_rng rng = {z, u, 0, 0, 0, 0};
     if (c->observation_noise > 0) {
       obs_call_streams(seed, (uint64_t)i, tick, PO_BLK_RESET_NOISE, z, u);
-      obs_call_streams(seed, (uint64_t)i, tick, PO_BLK_RESET_NOISE + 6u, z + 24, u + 9);
+      obs_call_streams(seed, (uint64_t)i, tick, PO_BLK_RESET_NOISE + 3u, z + 24, u + 9);
       rng.nz = 48; rng.nu = 18;
     }
     SUF(po_reset)(c, &envs[i], &s, &rng, obs + i * D);
@@ -861,7 +877,7 @@ void SUF(po_step_batch)(const po_config *c, ENV *envs, int64_t n, const REAL *ac
       po_rng rr = {zr, ur, 0, 0, 0, 0};
       if (c->observation_noise > 0) {
         obs_call_streams(seed, (uint64_t)i, tick, PO_BLK_RESET_NOISE, zr, ur);
-        obs_call_streams(seed, (uint64_t)i, tick, PO_BLK_RESET_NOISE + 6u, zr + 24, ur + 9);
+        obs_call_streams(seed, (uint64_t)i, tick, PO_BLK_RESET_NOISE + 3u, zr + 24, ur + 9);
         rr.nz = 48; rr.nu = 18;
       }
       SUF(po_reset)(c, &envs[i], &s, &rr, obs + i * D);

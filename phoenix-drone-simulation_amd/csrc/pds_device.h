@@ -119,7 +119,7 @@ PDS_DEV U4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32
 PDS_DEV U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
   return philox4x32<10>(c0, c1, c2, c3, k0, k1);
 }
-// per-step sensor / thrust noise (10 blocks per env-step): 7 rounds, the smallest Philox4x32 variant
+// per-step sensor / thrust noise (5 blocks per env-step): 7 rounds, the smallest Philox4x32 variant
 // that passes BigCrush (Salmon et al., SC'11, table 2)
 PDS_DEV U4 philox4x32_7(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
   return philox4x32<7>(c0, c1, c2, c3, k0, k1);
@@ -137,6 +137,20 @@ PDS_DEV void box_muller(uint32_t a, uint32_t b, float &z0, float &z1) {
   z0 = r * __builtin_amdgcn_cosf(u2);
   z1 = r * __builtin_amdgcn_sinf(u2);
 }
+
+// Per-step noise: ONE Philox word per Box-Muller pair -- radius from the high 20 bits (|z| <= 5.26),
+// angle from the low 12 bits (a 4096-point rule integrates the smooth periodic angle dependence of
+// the marginal to float precision, so each z is N(0,1) up to the 1.4e-7 tail mass beyond 5.26 sigma)
+// -- and one 16-bit half word per uniform.  Halves the Philox work of the noisy variants.
+PDS_DEV void box_muller_word(uint32_t w, float &z0, float &z1) {
+  const float u1 = (float)((w >> 12) + 1u) * (1.0f / 1048576.0f);
+  const float u2 = (float)(w & 0xFFFu) * (1.0f / 4096.0f);
+  const float r = fast_sqrt(-1.38629436111989061883f * __log2f(u1));
+  z0 = r * __builtin_amdgcn_cosf(u2);
+  z1 = r * __builtin_amdgcn_sinf(u2);
+}
+PDS_DEV float u01_lo16(uint32_t w) { return (float)(w & 0xFFFFu) * (1.0f / 65536.0f); }
+PDS_DEV float u01_hi16(uint32_t w) { return (float)(w >> 16) * (1.0f / 65536.0f); }
 
 PDS_DEV float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 

@@ -10,16 +10,17 @@ namespace pds {
 
 // Philox block ids (counter word 3) -- the RNG contract restated by oracle/phoenix_oracle.c
 constexpr uint32_t kBlkReset = 0;        // 0..8   reset distribution + domain randomisation (10 rounds)
-constexpr uint32_t kBlkResetNoise = 32;  // 32..43 two add_noise calls inside reset (7 rounds)
-constexpr uint32_t kBlkObsNoise = 64;    // 64..69 the add_noise call that produces o(k+1) (7 rounds)
-constexpr uint32_t kBlkSubNoise = 128;   // 128+4*sub+{0..3}: OU + the discarded add_noise call (7 rounds)
+constexpr uint32_t kBlkResetNoise = 32;  // 32..37 two add_noise calls inside reset (7 rounds)
+constexpr uint32_t kBlkObsNoise = 64;    // 64..66 the add_noise call that produces o(k+1) (7 rounds)
+constexpr uint32_t kBlkSubNoise = 128;   // 128+2*sub+{0,1}: OU + the discarded add_noise call (7 rounds)
 
 // Where the Philox words of a reset come from: computed on the spot by the resetting thread
 // (explicit reset kernel), or read back from an LDS scratch that the whole wave filled
-// cooperatively (deferred auto-reset drain: one block per lane instead of 5-21 blocks in a row on
+// cooperatively (deferred auto-reset drain: one block per lane instead of 5-15 blocks in a row on
 // the one or two lanes that own a finished env).
 constexpr int kResetBlocks = 9;        // reset distribution + domain randomisation
-constexpr int kResetNoiseBlocks = 12;  // two add_noise calls
+constexpr int kObsCallBlocks = 3;     // one add_noise call that reaches the observation
+constexpr int kResetNoiseBlocks = 2 * kObsCallBlocks;  // two add_noise calls
 constexpr int kScratchBlocks = kResetBlocks + kResetNoiseBlocks;
 
 struct DirectWords {
@@ -33,7 +34,7 @@ struct LdsWords {
   PDS_DEV U4 noise_block(uint32_t b) const { return slot[kResetBlocks + b]; }
 };
 
-// which of the 21 blocks a variant consumes (the cooperative fill skips the others)
+// which of the 15 blocks a variant consumes (the cooperative fill skips the others)
 template <class V>
 PDS_DEV constexpr bool block_needed(int j) {
   if (j >= kResetBlocks) return V::ON;
@@ -132,24 +133,26 @@ PDS_DEV void sample_load(const float *row, Sample &s) {
 }
 
 // ---- sensor noise -------------------------------------------------------------------------------
-// 24 standard variates of one add_noise call from six Philox blocks: words 0..17 -> 18 normals
-// (9 Box-Muller pairs), words 18..23 -> 6 uniforms.
-PDS_DEV void obs_noise_from_words(const uint32_t w[24], ObsNoise &n) {
+// 24 standard variates of one add_noise call from three Philox blocks: words 0..8 -> 18 normals
+// (one Box-Muller pair per word), words 9..11 -> 6 uniforms (16 bits each).
+PDS_DEV void obs_noise_from_words(const uint32_t w[12], ObsNoise &n) {
   float z[18];
 #pragma unroll
-  for (int p = 0; p < 9; ++p) box_muller(w[2 * p], w[2 * p + 1], z[2 * p], z[2 * p + 1]);
+  for (int p = 0; p < 9; ++p) box_muller_word(w[p], z[2 * p], z[2 * p + 1]);
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     n.pos_z[i] = z[i]; n.vel_z[i] = z[3 + i]; n.bias_z[i] = z[6 + i];
     n.rw_z[i] = z[9 + i]; n.to_z[i] = z[12 + i]; n.th_z[i] = z[15 + i];
-    n.pos_u[i] = u01(w[18 + i]); n.th_u[i] = u01(w[21 + i]);
   }
+  n.pos_u[0] = u01_lo16(w[9]);  n.pos_u[1] = u01_hi16(w[9]);
+  n.pos_u[2] = u01_lo16(w[10]); n.th_u[0] = u01_hi16(w[10]);
+  n.th_u[1] = u01_lo16(w[11]);  n.th_u[2] = u01_hi16(w[11]);
 }
 
 PDS_DEV void obs_noise_philox(uint32_t env_id, const StepArgs &a, uint32_t blk0, ObsNoise &n) {
-  uint32_t w[24];
+  uint32_t w[12];
 #pragma unroll
-  for (int b = 0; b < 6; ++b) {
+  for (int b = 0; b < kObsCallBlocks; ++b) {
     const U4 r = philox4x32_7(env_id, a.tick_lo, a.tick_hi, blk0 + (uint32_t)b, a.seed_lo, a.seed_hi);
     w[4 * b] = r.x; w[4 * b + 1] = r.y; w[4 * b + 2] = r.z; w[4 * b + 3] = r.w;
   }
@@ -158,10 +161,10 @@ PDS_DEV void obs_noise_philox(uint32_t env_id, const StepArgs &a, uint32_t blk0,
 
 template <class SRC>
 PDS_DEV void obs_noise_reset(const SRC &src, int call, ObsNoise &n) {
-  uint32_t w[24];
+  uint32_t w[12];
 #pragma unroll
-  for (int b = 0; b < 6; ++b) {
-    const U4 r = src.noise_block((uint32_t)(6 * call + b));
+  for (int b = 0; b < kObsCallBlocks; ++b) {
+    const U4 r = src.noise_block((uint32_t)(kObsCallBlocks * call + b));
     w[4 * b] = r.x; w[4 * b + 1] = r.y; w[4 * b + 2] = r.z; w[4 * b + 3] = r.w;
   }
   obs_noise_from_words(w, n);

@@ -139,22 +139,19 @@ PDS_DEV void sub_noise(const StepArgs &a, uint32_t env_id, long long ii, int sub
     for (int j = 0; j < 3; ++j) { n.bias_z[j] = p[PDS_N_A_BIAS + j]; n.rw_z[j] = p[PDS_N_A_RW + j]; n.to_z[j] = p[PDS_N_A_TO + j]; }
     return;
   }
-  const uint32_t b0 = kBlkSubNoise + 4u * (uint32_t)sub;
+  // words 0,1 -> OU z[0..3]; words 2..6 -> bias, random walk, turn-on z[4..12] (one pair per word)
+  const uint32_t b0 = kBlkSubNoise + 2u * (uint32_t)sub;
   float z[14];
-  {
-    const U4 r = philox4x32_7(env_id, a.tick_lo, a.tick_hi, b0, a.seed_lo, a.seed_hi);
-    box_muller(r.x, r.y, z[0], z[1]);
-    box_muller(r.z, r.w, z[2], z[3]);
-  }
+  const U4 r = philox4x32_7(env_id, a.tick_lo, a.tick_hi, b0, a.seed_lo, a.seed_hi);
+  box_muller_word(r.x, z[0], z[1]);
+  box_muller_word(r.y, z[2], z[3]);
   if (V::ON) {
     const U4 r1 = philox4x32_7(env_id, a.tick_lo, a.tick_hi, b0 + 1u, a.seed_lo, a.seed_hi);
-    const U4 r2 = philox4x32_7(env_id, a.tick_lo, a.tick_hi, b0 + 2u, a.seed_lo, a.seed_hi);
-    const U4 r3 = philox4x32_7(env_id, a.tick_lo, a.tick_hi, b0 + 3u, a.seed_lo, a.seed_hi);
-    box_muller(r1.x, r1.y, z[4], z[5]);
-    box_muller(r1.z, r1.w, z[6], z[7]);
-    box_muller(r2.x, r2.y, z[8], z[9]);
-    box_muller(r2.z, r2.w, z[10], z[11]);
-    box_muller(r3.x, r3.y, z[12], z[13]);
+    box_muller_word(r.z, z[4], z[5]);
+    box_muller_word(r.w, z[6], z[7]);
+    box_muller_word(r1.x, z[8], z[9]);
+    box_muller_word(r1.y, z[10], z[11]);
+    box_muller_word(r1.z, z[12], z[13]);
   } else {
 #pragma unroll
     for (int j = 4; j < 14; ++j) z[j] = 0.f;
