@@ -54,7 +54,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--envs-per-gpu", type=int, default=1 << 20)
+    ap.add_argument("--envs-per-gpu", type=int, default=None,
+                    help="override the env count of the chosen config (default: the config's own, 2^20 for 0)")
     ap.add_argument("--task", default="hover", choices=["hover", "circle", "takeoff"])
     ap.add_argument("--config", type=int, default=0,
                     help="0: north-star headline (Hover 2^20/GPU); 2/3/4: BASELINE.json configs[1..3]; "
@@ -79,7 +80,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     task = args.task
-    n = args.envs_per_gpu
+    n = 1 << 20
     kw = dict(observation_noise=-1, domain_randomization=-1, motor_thrust_noise=0)
     act_center_shift = 0.0
     if args.config == 2:
@@ -94,6 +95,8 @@ def main():
     elif args.config == 6:  # the reference's DEFAULT env config: sensor + thrust noise, 10 % DR
         task, n = "hover", 1 << 20
         kw = dict(observation_noise=1, domain_randomization=0.10, motor_thrust_noise=0.05)
+    if args.envs_per_gpu is not None:
+        n = args.envs_per_gpu
     env_id = {"hover": "DroneHoverSimpleEnv-v0", "circle": "DroneCircleSimpleEnv-v0",
               "takeoff": "DroneTakeOffSimpleEnv-v0"}[task]
     env = pds.make(env_id, num_envs=n, device=dev, seed=0, env_id_base=rank * n,

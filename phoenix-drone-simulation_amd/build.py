@@ -14,7 +14,11 @@ _HEADERS = ["pds_device.h", "pds_types.h", "pds_reset.h", "pds_step.h"]
 _DEPS = [os.path.join(_CSRC, f) for f in _UNITS + _HEADERS] + [os.path.join(_HERE, "..", "include", "pds.h")]
 _LIB = os.path.join(_HERE, "libpds_hip.so")
 _OBJ = os.path.join(_HERE, "build")
-_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-pass-failed"]
+# -ffp-contract=on: fuse a*b+c only where one source expression says so (the frontend decides), not
+# wherever the optimiser finds a multiply next to an add (hipcc's default "fast" makes that depend
+# on inlining and use counts, i.e. differ between template instantiations of the same code): the
+# 32-row and 64-row tile kernels, and hence any sharding of a batch, must agree bitwise.
+_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-pass-failed", "-ffp-contract=on"]
 
 
 def library_path():

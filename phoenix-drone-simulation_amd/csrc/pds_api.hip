@@ -161,6 +161,7 @@ struct pds_handle {
   DevState st;
   Consts k;
   LaunchFlags flags;
+  int force_tile = 0;  // PDS_FORCE_TILE=half|full (tests / A-B runs): 1 half, 2 full, 0 pick per launch
   float2 *d_circle_ref;
   void *slab;  // one allocation holds every state array (staggered, see pds_create)
   int obs_dim;
@@ -307,6 +308,8 @@ extern "C" int pds_create(const pds_config *cfg, pds_handle **out) {
   h->flags.tn = cfg->motor_thrust_noise > 0;
   h->flags.on = cfg->observation_noise > 0;
   h->flags.ctrl = cfg->control_mode;
+  h->flags.half_tile = false;
+  if (const char *ft = getenv("PDS_FORCE_TILE")) h->force_tile = (ft[0] == 'h') ? 1 : ((ft[0] == 'f') ? 2 : 0);
   const size_t n = (size_t)cfg->num_envs;
   const LaunchFlags &f = h->flags;
   hipError_t e = hipSetDevice(cfg->device);
@@ -456,10 +459,15 @@ extern "C" int pds_step_with_variates(pds_handle *h, const float *d_actions, con
   // one 256-env block per 4 tiles
   const dim3 grid((unsigned)((a.n + kBlock - 1) / kBlock));
   hipStream_t s = (hipStream_t)stream;
+  // half observation tile (4 resident blocks per CU instead of 3) while the grid is between one and
+  // about 2.7 rounds of the full-tile residency; see pds_types.h kHalfTileRows
+  LaunchFlags lf = h->flags;
+  lf.half_tile = grid.x > (unsigned)(kFullTileBlocksPerCU * kCUs) && grid.x <= (unsigned)(8 * kCUs);
+  if (h->force_tile) lf.half_tile = h->force_tile == 1;
   switch (h->cfg.task) {
-    case PDS_TASK_HOVER: launch_step_hover(h->flags, grid, s, a); break;
-    case PDS_TASK_CIRCLE: launch_step_circle(h->flags, grid, s, a); break;
-    default: launch_step_takeoff(h->flags, grid, s, a); break;
+    case PDS_TASK_HOVER: launch_step_hover(lf, grid, s, a); break;
+    case PDS_TASK_CIRCLE: launch_step_circle(lf, grid, s, a); break;
+    default: launch_step_takeoff(lf, grid, s, a); break;
   }
   PDS_HIP(h, hipGetLastError());
   h->parity ^= 1;

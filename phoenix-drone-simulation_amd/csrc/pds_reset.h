@@ -446,7 +446,7 @@ constexpr int kResetsPerPass = kWave / kLanesPerReset;
 template <class V>
 PDS_DEV void drain_reset_queue(const StepArgs &a, const float2 *ref_lds, const uint32_t *queue, int qcount,
                                int lane, float *tile) {
-  static_assert(kResetsPerPass * kScratchBlocks * 16 <= kWave * V::D * 4, "scratch must fit in the wave's tile");
+  static_assert(kResetsPerPass * kScratchBlocks * 16 <= kHalfTileRows * V::D * 4, "scratch must fit in the wave's tile");
   U4 *scratch = reinterpret_cast<U4 *>(tile);
   const int g = lane / kLanesPerReset, b = lane % kLanesPerReset;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

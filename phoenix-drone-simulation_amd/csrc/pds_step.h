@@ -17,10 +17,10 @@
 namespace pds {
 
 // Wave-cooperative copy of this wave's [rows, D] LDS tile to global memory (contiguous region).
-template <int D>
+template <int D, int TR>
 PDS_DEV void flush_tile(const float *tile, float *gdst, int rows, int lane) {
-  if (rows == kWave) {
-    constexpr int NV = kWave * D / 4;  // float4 count (D is even, 64*D divisible by 4)
+  if (rows == TR) {
+    constexpr int NV = TR * D / 4;  // float4 count (D is even, 32*D divisible by 4)
     const float4 *src = reinterpret_cast<const float4 *>(tile);
     float4 *dst = reinterpret_cast<float4 *>(gdst);
 #pragma unroll
@@ -169,18 +169,21 @@ PDS_DEV void sub_noise(const StepArgs &a, uint32_t env_id, long long ii, int sub
 // the tile loop -- pushed the kernel over the SGPR budget (137 v_writelane/v_readlane spill
 // instructions in the main path), so there is no tile loop here.
 // __launch_bounds__(256, 3): LDS admits 3 blocks (12 waves) per CU, so cap VGPRs at 168.
-template <class V>
+template <class V, int TR>
 // The lean variants are additionally held to 128 VGPRs (min 4 waves/SIMD): measured 2-3 % faster
 // (62.7 vs 64.3 us Hover, 63.5 vs 64.7 us TakeOff+GE on the same box); the observation-noise
 // variants spill badly under that cap (154 vs 106 us) and keep 168.
+#ifndef PDS_MIN_WAVES_LEAN
+#define PDS_MIN_WAVES_LEAN 4
+#endif
 #ifndef PDS_MIN_WAVES
-#define PDS_MIN_WAVES (V::ON ? 3 : 4)
+#define PDS_MIN_WAVES (V::ON ? 3 : PDS_MIN_WAVES_LEAN)
 #endif
 __global__ __launch_bounds__(kBlock, PDS_MIN_WAVES) void step_kernel(const StepArgs a) {
   constexpr int TASK = V::TASK;
   constexpr int D = V::D;
   constexpr int O = V::O;
-  __shared__ __attribute__((aligned(16))) float tile_all[kBlock * D];
+  __shared__ __attribute__((aligned(16))) float tile_all[(kBlock / kWave) * TR * D];
   __shared__ float2 ref_lds[(TASK == PDS_TASK_CIRCLE) ? kRefPoints : 1];
   __shared__ uint32_t queue_all[(kBlock / kWave) * kQueueCap];
   const Consts &k = a.k;
@@ -193,8 +196,10 @@ __global__ __launch_bounds__(kBlock, PDS_MIN_WAVES) void step_kernel(const StepA
   }
   uint32_t *queue = queue_all + wave * kQueueCap;
   int qcount = 0;  // wave-uniform
-  float *tile = tile_all + wave * (kWave * D);
-  float *row = tile + lane * D;
+  float *tile = tile_all + wave * (TR * D);
+  // full tile: the row is built in place in LDS; half tile: in registers, staged pass by pass
+  float rowbuf[(TR == kWave) ? 1 : D];
+  float *row = (TR == kWave) ? tile + lane * D : rowbuf;
   const long long ntiles = (a.n + kWave - 1) / kWave;
   const long long t = (long long)blockIdx.x * (kBlock / kWave) + wave;
   if (t >= ntiles) return;  // wave-uniform
@@ -405,24 +410,16 @@ __global__ __launch_bounds__(kBlock, PDS_MIN_WAVES) void step_kernel(const StepA
     // finished env only hands its last observation to final_obs here and queues its index in LDS;
     // the wave resets its queued envs densely after its last tile (or when the queue fills up).
     const bool need_reset = a.auto_reset && (done || trunc) && active;
+    unsigned long long done_mask;  // wave-uniform: lanes whose last observation goes to final_obs
     {
       unsigned long long m = __ballot(need_reset);
       if (m != 0ull) {  // wave-uniform
         const int pos = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
         if (need_reset) queue[pos] = (uint32_t)i | ((uint32_t)ref_offset << 23);
         qcount += __popcll(m);
-        if (a.final_obs != nullptr) {
-          // last observation of each finished env -> final_obs: the whole wave copies one row
-          // (D <= 64 contiguous floats) per finished env straight out of the LDS tile
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          do {
-            const int src_lane = __builtin_ctzll(m);
-            m &= m - 1ull;
-            if (lane < D) a.final_obs[(wave_base + src_lane) * D + lane] = tile[src_lane * D + lane];
-          } while (m != 0ull);
-        }
       }
+      if (a.final_obs == nullptr) m = 0ull;
+      done_mask = m;
     }
 
     // ---- coalesced stores ----------------------------------------------------------------------
@@ -455,13 +452,34 @@ __global__ __launch_bounds__(kBlock, PDS_MIN_WAVES) void step_kernel(const StepA
       nt_store(a.trunc + i, (uint8_t)(trunc ? 1 : 0));
     }
     // LDS rows of this wave were written by its own lanes only: wave-synchronous, no block barrier
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const long long rem = a.n - wave_base;
-    flush_tile<D>(tile, a.obs + wave_base * D, rem >= kWave ? kWave : (int)rem, lane);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();  // the tile is rewritten by the next iteration
+#pragma unroll
+    for (int pass = 0; pass < kWave / TR; ++pass) {
+      if (TR != kWave) {
+        if ((lane / TR) == pass) {
+          float *dst = tile + (lane % TR) * D;
+#pragma unroll
+          for (int j = 0; j < D; ++j) dst[j] = rowbuf[j];
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // last observation of each finished env -> final_obs: the whole wave copies one row
+      // (D <= 64 contiguous floats) per finished env straight out of the LDS tile
+      unsigned long long m = done_mask;
+      if (TR != kWave) m &= (pass == 0) ? 0x00000000FFFFFFFFull : 0xFFFFFFFF00000000ull;
+      while (m != 0ull) {
+        const int src_lane = __builtin_ctzll(m);
+        m &= m - 1ull;
+        if (lane < D) a.final_obs[(wave_base + src_lane) * D + lane] = tile[(src_lane % TR) * D + lane];
+      }
+      const long long left = rem - pass * TR;
+      if (left > 0)
+        flush_tile<D, TR>(tile, a.obs + (wave_base + pass * TR) * D, left >= TR ? TR : (int)left, lane);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();  // the tile is rewritten by the next pass / the reset drain
+    }
   }
   if (qcount > 0) drain_reset_queue<V>(a, ref_lds, queue, qcount, lane, tile);
 }
@@ -486,7 +504,17 @@ __global__ __launch_bounds__(kBlock, PDS_MIN_WAVES) void step_kernel(const StepA
   case base + 3: FN((Variant<TASK, M, R, G, true, true>), __VA_ARGS__); break;
 
 #define PDS_UNPAREN(...) __VA_ARGS__
-#define PDS_LAUNCH_STEP(V, grid, s, a) hipLaunchKernelGGL((step_kernel<PDS_UNPAREN V>), grid, dim3(kBlock), 0, s, a)
+template <class V>
+inline void launch_step_variant(bool half_tile, dim3 grid, hipStream_t s, const StepArgs &a) {
+  if constexpr (!V::ON) {
+    if (half_tile) {
+      hipLaunchKernelGGL((step_kernel<V, kHalfTileRows>), grid, dim3(kBlock), 0, s, a);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((step_kernel<V, kWave>), grid, dim3(kBlock), 0, s, a);
+}
+#define PDS_LAUNCH_STEP(V, grid, s, a) launch_step_variant<PDS_UNPAREN V>(f.half_tile, grid, s, a)
 #define PDS_LAUNCH_RESET(V, grid, s, a) hipLaunchKernelGGL((reset_kernel<PDS_UNPAREN V>), grid, dim3(kBlock), 0, s, a)
 
 // PID control modes: 16 variants each (motor x DR x thrust noise x observation noise), no ground effect

@@ -13,6 +13,16 @@ namespace pds {
 #endif
 constexpr int kBlock = PDS_BLOCK;  // 4 waves; each wave owns a private LDS tile (no block barrier needed)
 constexpr int kWave = 64;
+// Rows of the per-wave LDS observation tile: the step kernel exists with a full tile (64 rows,
+// 43 KB LDS per block for Hover => 3 blocks per CU) and, for the variants without observation
+// noise, with a half tile (32 rows: the wave stages and flushes its 64 rows in two passes, each
+// still one contiguous 16 B-aligned region of the [N, D] tensor => 4 blocks per CU).  Measured on
+// MI355X (profiles/r01_tile_rows.txt): the half tile wins when the grid is between one and about
+// 2.7 rounds of the 3-blocks-per-CU residency (Circle 262 144 + PT1 + DR: 20.8 vs 24.9 us); the full
+// tile wins by 1-2 % from 2^20 envs up (fewer registers, one flush).  pds_step picks per launch.
+constexpr int kHalfTileRows = 32;
+constexpr int kCUs = 256;            // MI355X
+constexpr int kFullTileBlocksPerCU = 3;
 constexpr int kQueueCap = 64;    // deferred-reset queue entries per wave (LDS): one tile
 constexpr int kRefPoints = 300;  // envs/circle.py:48, envs/takeoff.py:43
 constexpr int kStaggerBytes = 4352;  // 17 x 256 B between consecutive state arrays in the slab
@@ -167,6 +177,7 @@ PDS_DEV int target_index(int step, int agg, int ref_offset) {
 struct LaunchFlags {
   bool motor, dr, ge, tn, on;
   int ctrl;
+  bool half_tile;  // per launch: use the 32-row observation tile (variants without observation noise)
 };
 void launch_step_hover(const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
 void launch_step_circle(const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);

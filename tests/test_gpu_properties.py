@@ -165,3 +165,39 @@ def test_masked_reset_only_touches_selected_envs():
     s2 = env.get_state("step_count")
     assert bool((s2[mask] == 0).all()) and torch.equal(s2[~mask], steps[~mask])
     env.close()
+
+
+@pytest.mark.parametrize("task,kw", [
+    ("hover", {}),
+    ("hover", dict(control_mode="AttitudeRate", aggregate_phy_steps=2)),
+    ("circle", dict(use_motor_dynamics=True, domain_randomization=0.10, motor_thrust_noise=0.05)),
+    ("takeoff", dict(use_ground_effect=True)),
+])
+def test_half_and_full_observation_tile_agree_bitwise(task, kw, monkeypatch):
+    """The step kernel exists with a 64-row and a 32-row LDS observation tile (csrc/pds_types.h
+    kHalfTileRows; pds_step picks by grid size).  Same arithmetic, different staging: every output,
+    including final_obs of the envs that finish and the ragged last tile, must be identical."""
+    import phoenix_drone_simulation_amd as pds
+    n = 70001  # not a multiple of 64 nor of 32
+    base = dict(DET, seed=5, max_episode_steps=23)
+    base.update(kw)
+    envs = []
+    for mode in ("half", "full"):
+        monkeypatch.setenv("PDS_FORCE_TILE", mode)
+        envs.append(pds.make(ENV_ID[task], num_envs=n, **base))
+    monkeypatch.delenv("PDS_FORCE_TILE")
+    oa, _ = envs[0].reset(); ob, _ = envs[1].reset()
+    assert torch.equal(oa, ob)
+    finished = 0
+    for k in range(60):
+        a = _actions(n, oa.device, 300 + k, shift=0.2 if task == "takeoff" else 0.0)
+        ra = envs[0].step(a); rb = envs[1].step(a)
+        for x, y in zip(ra[:4], rb[:4]):
+            assert torch.equal(x, y)
+        assert torch.equal(ra[4]["cost"], rb[4]["cost"])
+        fin = (ra[2] | ra[3])
+        finished += int(fin.sum())
+        assert torch.equal(ra[4]["final_obs"][fin], rb[4]["final_obs"][fin])
+    assert finished > n  # every env hit the 23-step limit at least once
+    for e in envs:
+        e.close()
