@@ -494,6 +494,85 @@ PDS_DEV void drain_reset_queue(const StepArgs &a, const float2 *ref_lds, const u
   }
 }
 
+// ---- auto-reset merged into the step's own stores (variants without observation noise) -----------
+// The finished envs of a wave are reset BEFORE the wave stores: the fresh state replaces the
+// terminal one in the registers of the lane that owns the env, so it leaves through the same
+// coalesced stores and the same observation-tile flush as every other env -- no scattered partial-line
+// writes over lines the wave has just written, no wait for those stores.  (Measured on Hover 2^20:
+// the scattered observation-row rewrite of the deferred drain alone cost 1.0 us of 60.)
+// Groups of 8 lanes serve one finished env: lane b of the group computes Philox block b, the words
+// travel through ds_bpermute (no LDS memory: the observation tile is still occupied), every lane of
+// the group evaluates the reset of the group's env, and the finished lane fetches the result from
+// its group's first lane.
+struct ShflWords {
+  U4 mine, blk8;
+  int gbase;
+  PDS_DEV U4 reset_block(uint32_t j) const {
+    if (j == 8u) return blk8;
+    const int src = gbase + (int)j;
+    return U4{(uint32_t)__shfl((int)mine.x, src), (uint32_t)__shfl((int)mine.y, src),
+              (uint32_t)__shfl((int)mine.z, src), (uint32_t)__shfl((int)mine.w, src)};
+  }
+};
+
+// `mine`: this lane's env finished; `pos`: its rank among the wave's `count` finished lanes, whose
+// lane ids are in `lanes[0..count)`.  Must be called in wave-uniform control flow.
+template <class V>
+PDS_DEV void reset_in_registers(const StepArgs &a, const float2 *ref_lds, const uint32_t *lanes, int count,
+                                bool mine, int pos, int lane, long long wave_base, int ref_offset,
+                                EnvRegs &e, Quat &q, float4 &u0, float4 &mx, Params &par, uint32_t &ctr) {
+  static_assert(!V::ON, "observation-noise variants use the deferred drain");
+  const int g = lane / kLanesPerReset, b = lane % kLanesPerReset;
+  for (int base = 0; base < count; base += kResetsPerPass) {
+    const bool on = base + g < count;
+    const int src = on ? (int)lanes[base + g] : lane;
+    const uint32_t env_id = (uint32_t)(a.env_id_base + (unsigned long long)(wave_base + src));
+    const int off_old = __shfl(ref_offset, src);
+    const DirectWords dw{env_id, a.tick_lo, a.tick_hi, a.seed_lo, a.seed_hi};
+    ShflWords sw;
+    sw.gbase = lane - b;
+    sw.mine = U4{0u, 0u, 0u, 0u};
+    sw.blk8 = U4{0u, 0u, 0u, 0u};
+    bool need = false;
+#pragma unroll
+    for (int c = 0; c < kLanesPerReset; ++c) need = need || (c == b && block_needed<V>(c));
+    if (need) sw.mine = dw.reset_block((uint32_t)b);
+    if (V::MOTOR && V::DR) sw.blk8 = dw.reset_block(8u);
+    Sample s;
+    sample_philox<V>(a.k, sw, s);
+    EnvRegs re;
+    Quat rq;
+    float4 ru0, rmx;
+    Params rpar;
+    uint32_t rctr = ctr_pack(0u, 0u, (uint32_t)off_old);
+    reset_env<V>(a.k, ref_lds, s, re, rq, ru0, rmx, rpar, rctr);
+    // result of group (pos - base) -> the finished lane it belongs to
+    const bool take = mine && pos >= base && pos < base + kResetsPerPass;
+    const int from = take ? (pos - base) * kLanesPerReset : lane;
+#define PDS_TAKE(dst, val) { const float t_ = __shfl((val), from); if (take) (dst) = t_; }
+    PDS_TAKE(e.px, re.px) PDS_TAKE(e.py, re.py) PDS_TAKE(e.pz, re.pz)
+    PDS_TAKE(e.vx, re.vx) PDS_TAKE(e.vy, re.vy) PDS_TAKE(e.vz, re.vz)
+    PDS_TAKE(e.roll, re.roll) PDS_TAKE(e.pitch, re.pitch) PDS_TAKE(e.yaw, re.yaw)
+    PDS_TAKE(e.wx, re.wx) PDS_TAKE(e.wy, re.wy) PDS_TAKE(e.wz, re.wz)
+    PDS_TAKE(q.x, rq.x) PDS_TAKE(q.y, rq.y) PDS_TAKE(q.z, rq.z) PDS_TAKE(q.w, rq.w)
+    PDS_TAKE(u0.x, ru0.x) PDS_TAKE(u0.y, ru0.y) PDS_TAKE(u0.z, ru0.z) PDS_TAKE(u0.w, ru0.w)
+    if (V::MOTOR) { PDS_TAKE(mx.x, rmx.x) PDS_TAKE(mx.y, rmx.y) PDS_TAKE(mx.z, rmx.z) PDS_TAKE(mx.w, rmx.w) }
+    if (V::DR) {
+      PDS_TAKE(par.dt, rpar.dt) PDS_TAKE(par.m, rpar.m) PDS_TAKE(par.Jx, rpar.Jx)
+      PDS_TAKE(par.Jy, rpar.Jy) PDS_TAKE(par.Jz, rpar.Jz) PDS_TAKE(par.ftf1, rpar.ftf1)
+      if (V::MOTOR) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { PDS_TAKE(par.A[j], rpar.A[j]) PDS_TAKE(par.K[j], rpar.K[j]) }
+      }
+    }
+#undef PDS_TAKE
+    {
+      const uint32_t t_ = (uint32_t)__shfl((int)rctr, from);
+      if (take) ctr = t_;
+    }
+  }
+}
+
 // Explicit reset (pds_reset / pds_reset_from_samples): not a hot path.
 template <class V>
 __global__ __launch_bounds__(kBlock) void reset_kernel(const StepArgs a) {

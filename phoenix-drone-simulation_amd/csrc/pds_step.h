@@ -183,6 +183,12 @@ __global__ __launch_bounds__(kBlock, PDS_MIN_WAVES) void step_kernel(const StepA
   constexpr int TASK = V::TASK;
   constexpr int D = V::D;
   constexpr int O = V::O;
+  // Auto-reset in registers before the stores, or deferred drain after them (see below).  Measured
+  // on one MI355X box, merged vs deferred: Hover 2^20 58.45 vs 60.0 us, Hover 2^21 108.5 vs 111.0 us;
+  // but Circle + PT1 + DR at 2^20 82.9 vs 78.6 us (181 VGPRs => 2 waves/SIMD), TakeOff (resets only by
+  // the 500-step truncation) 61.4 vs 60.7 us, and under the half tile's 128-VGPR cap it spills
+  // (Circle 262 144: 39 vs 21 us) -- so those keep the deferred drain.
+  constexpr bool MERGED = PDS_MERGED_RESET && !V::ON && TR == kWave && !(V::MOTOR && V::DR) && TASK != PDS_TASK_TAKEOFF;
   __shared__ __attribute__((aligned(16))) float tile_all[(kBlock / kWave) * TR * D];
   __shared__ float2 ref_lds[(TASK == PDS_TASK_CIRCLE) ? kRefPoints : 1];
   __shared__ uint32_t queue_all[(kBlock / kWave) * kQueueCap];
@@ -404,22 +410,49 @@ __global__ __launch_bounds__(kBlock, PDS_MIN_WAVES) void step_kernel(const StepA
       write_obs_half<TASK>(row + O + 4, e, q, act, tx, ty, tz, h1);
     }
 
-    const uint32_t ctr_new = ctr_pack((uint32_t)(step + 1), 0u, (uint32_t)ref_offset);
-    // ---- auto-reset: DEFERRED.  ~2 % of the envs finish per step under random actions, i.e. 3 of
-    // 4 waves would run the (long, transcendental-heavy) reset path for one or two live lanes.  A
-    // finished env only hands its last observation to final_obs here and queues its index in LDS;
-    // the wave resets its queued envs densely after its last tile (or when the queue fills up).
+    uint32_t ctr_new = ctr_pack((uint32_t)(step + 1), 0u, (uint32_t)ref_offset);
+    float4 hist_new = act;  // -> hist[parity ^ 1]: overwrites u(k-2); next step's parity makes it u(k-1)
+    // ---- auto-reset.  ~2 % of the envs finish per step under random actions, i.e. 3 of 4 waves
+    // hold one or two finished envs.  Their last observation goes to final_obs (below, out of the
+    // LDS tile); the reset itself is done densely, 8 lanes per finished env:
+    //  * without observation noise: now, in registers (reset_in_registers), so the fresh state and
+    //    observation leave through the wave's ordinary coalesced stores;
+    //  * with observation noise (the reset needs much more state): deferred to a drain after the
+    //    stores (drain_reset_queue).
     const bool need_reset = a.auto_reset && (done || trunc) && active;
-    unsigned long long done_mask;  // wave-uniform: lanes whose last observation goes to final_obs
-    {
-      unsigned long long m = __ballot(need_reset);
-      if (m != 0ull) {  // wave-uniform
-        const int pos = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    const unsigned long long reset_mask = __ballot(need_reset);  // wave-uniform
+    const unsigned long long done_mask = (a.final_obs != nullptr) ? reset_mask : 0ull;  // -> final_obs
+    if (reset_mask != 0ull) {  // wave-uniform
+      const int pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(reset_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)reset_mask, 0u));
+      qcount = __popcll(reset_mask);
+      if (!MERGED) {
         if (need_reset) queue[pos] = (uint32_t)i | ((uint32_t)ref_offset << 23);
-        qcount += __popcll(m);
+      } else {
+        if (need_reset) queue[pos] = (uint32_t)lane;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float4 u0 = act, mxr = make_float4(xm[0], xm[1], xm[2], xm[3]);
+        if constexpr (MERGED)
+          reset_in_registers<V>(a, ref_lds, queue, qcount, need_reset, pos, lane, wave_base, ref_offset, e, q, u0,
+                                mxr, par, ctr_new);
+        if (need_reset) {
+          hist_new = u0;
+          xm[0] = mxr.x; xm[1] = mxr.y; xm[2] = mxr.z; xm[3] = mxr.w;
+#pragma unroll
+          for (int j = 0; j < 3; ++j) { ps.rate_int[j] = ps.rate_err[j] = ps.att_int[j] = ps.att_err[j] = 0.f; }
+          // written only by resets (no write-after-write with this step's stores)
+          a.st.hist[a.parity][i] = u0;
+          if (V::DR) {
+            a.st.par0[i] = make_float4(par.dt, par.m, par.Jx, par.Jy);
+            a.st.par1[i] = make_float2(par.Jz, par.ftf1);
+            if (V::MOTOR) {
+              a.st.mA[i] = make_float4(par.A[0], par.A[1], par.A[2], par.A[3]);
+              a.st.mK[i] = make_float4(par.K[0], par.K[1], par.K[2], par.K[3]);
+            }
+          }
+        }
       }
-      if (a.final_obs == nullptr) m = 0ull;
-      done_mask = m;
     }
 
     // ---- coalesced stores ----------------------------------------------------------------------
@@ -427,7 +460,7 @@ __global__ __launch_bounds__(kBlock, PDS_MIN_WAVES) void step_kernel(const StepA
       st_store4(a.st.s0 + i, make_float4(e.px, e.py, e.pz, e.vx));
       st_store4(a.st.s1 + i, make_float4(e.vy, e.vz, e.roll, e.pitch));
       st_store4(a.st.s2 + i, make_float4(e.yaw, e.wx, e.wy, e.wz));
-      st_store4(a.st.hist[a.parity ^ 1] + i, act);  // overwrites u(k-2); next step's parity makes it u(k-1)
+      st_store4(a.st.hist[a.parity ^ 1] + i, hist_new);
       a.st.ctr[i] = ctr_new;
       if (V::MOTOR) a.st.mx[i] = make_float4(xm[0], xm[1], xm[2], xm[3]);
       if (V::TN) a.st.ou[i] = make_float4(ns.ou[0], ns.ou[1], ns.ou[2], ns.ou[3]);
@@ -474,6 +507,18 @@ __global__ __launch_bounds__(kBlock, PDS_MIN_WAVES) void step_kernel(const StepA
         m &= m - 1ull;
         if (lane < D) a.final_obs[(wave_base + src_lane) * D + lane] = tile[(src_lane % TR) * D + lane];
       }
+      if (MERGED && reset_mask != 0ull) {  // wave-uniform: the reset envs' rows become [o0, u0, o0, u0]
+        if (need_reset && (TR == kWave || (lane / TR) == pass)) {
+          float tx0, ty0, tz0;
+          target_at<TASK>(k, ref_lds, target_index<TASK>(0, k.agg, (int)ctr_off(ctr_new)), tx0, ty0, tz0);
+          float *dst = tile + (lane % TR) * D;
+          write_obs_half<TASK>(dst, e, q, hist_new, tx0, ty0, tz0, hist_new);
+          write_obs_half<TASK>(dst + O + 4, e, q, hist_new, tx0, ty0, tz0, hist_new);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
       const long long left = rem - pass * TR;
       if (left > 0)
         flush_tile<D, TR>(tile, a.obs + (wave_base + pass * TR) * D, left >= TR ? TR : (int)left, lane);
@@ -481,7 +526,7 @@ __global__ __launch_bounds__(kBlock, PDS_MIN_WAVES) void step_kernel(const StepA
       __builtin_amdgcn_wave_barrier();  // the tile is rewritten by the next pass / the reset drain
     }
   }
-  if (qcount > 0) drain_reset_queue<V>(a, ref_lds, queue, qcount, lane, tile);
+  if (!MERGED && qcount > 0) drain_reset_queue<V>(a, ref_lds, queue, qcount, lane, tile);
 }
 
 // ---- per-task instantiation (one translation unit per task keeps the build parallel) -----------

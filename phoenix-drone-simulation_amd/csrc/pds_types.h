@@ -12,6 +12,9 @@ namespace pds {
 #define PDS_BLOCK 256
 #endif
 constexpr int kBlock = PDS_BLOCK;  // 4 waves; each wave owns a private LDS tile (no block barrier needed)
+#ifndef PDS_MERGED_RESET
+#define PDS_MERGED_RESET 1  // A/B: 0 = deferred drain everywhere
+#endif
 constexpr int kWave = 64;
 // Rows of the per-wave LDS observation tile: the step kernel exists with a full tile (64 rows,
 // 43 KB LDS per block for Hover => 3 blocks per CU) and, for the variants without observation

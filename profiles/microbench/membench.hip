@@ -106,7 +106,8 @@ template <typename F> static float time_ms(F launch, int iters) {
 }
 
 int main(int argc, char **argv) {
-  const long long n = 1 << 20;
+  const long long n = argc > 1 ? atoll(argv[1]) : (1 << 20);  // envs
+  printf("n = %lld envs, %.1f MB per pass\n", n, 346.0 * n / 1e6);
   const int T = 8;  // action slabs, cycled
   Arrs a; a.n = n;
   float4 *act; CK(hipMalloc(&act, n * 16 * T)); CK(hipMemset(act, 0, n * 16 * T));
