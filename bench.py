@@ -44,9 +44,22 @@ def cpu_baseline(task, kw, target_seconds=12.0):
     for s in range(steps):
         orc.step(acts[s % 8], seed=0, tick=2 + s)
     dt = time.perf_counter() - t0
+    # the 1-thread figure SURVEY 8(d) asks for beside the all-core one (about 3 s)
+    n1 = 4096
+    one_t = po.OracleBatch(task, n1, precision="f32", nthreads=1, **kw)
+    one_t.reset(0, 0)
+    a1 = np.ascontiguousarray(acts[:, :n1])
+    one_t.step(a1[0], seed=0, tick=1)
+    t0 = time.perf_counter()
+    k1 = 0
+    while time.perf_counter() - t0 < 3.0:
+        one_t.step(a1[k1 % 8], seed=0, tick=2 + k1)
+        k1 += 1
+    dt1 = time.perf_counter() - t0
     return {"value": n_cpu * steps / dt, "unit": "env-steps/s", "cores": int(threads), "kind": "port",
             "sample": f"oracle/phoenix_oracle.c float32 + OpenMP, {n_cpu} envs x {steps} steps "
-                      f"({dt:.1f} s), same Hover config and action recipe, auto-reset on"}
+                      f"({dt:.1f} s), same Hover config and action recipe, auto-reset on",
+            "value_1_thread": n1 * k1 / dt1}
 
 
 def main():
