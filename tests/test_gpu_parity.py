@@ -255,3 +255,51 @@ def test_ragged_sizes(n):
         assert torch.equal(ib["cost"][:n], is_["cost"])
     big.close()
     small.close()
+
+
+def test_closed_loop_with_reference_policy_500_steps():
+    """SURVEY 8c G3(iii): a policy trained by the reference (exp-07 PWM, 40-dim input, 50-50 ReLU;
+    tests/golden/policy_PWM_seed_00000_model.json) flies the Circle env closed loop for a full
+    500-step episode on the HIP path and on the f64 oracle, each acting on its OWN observations.
+    The closed loop (ReLU controller on the circle) amplifies a 1e-7 difference about 200x per 80
+    steps until it saturates near 1e-2 m (measured: profiles/tools/debug_closed_loop.py; the f32
+    CPU oracle drifts from the f64 one in the same way), so: tight agreement over the first 30
+    steps, bounded drift afterwards, identical episode structure (nobody falls, TimeLimit at step
+    500 for every env) and episode returns that agree statistically."""
+    import os
+    import phoenix_drone_simulation_amd as pds
+    from oracle import oracle as po
+    from phoenix_drone_simulation_amd.policy_io import load_network_json
+    fix = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "policy_PWM_seed_00000_model.json")
+    N, seed = 256, 9
+    base = dict(observation_noise=-1, domain_randomization=-1, motor_thrust_noise=0)
+    env = pds.make("DroneCircleSimpleEnv-v0", num_envs=N, seed=seed, **base)
+    orc = po.OracleBatch("circle", N, precision="f64", **base)
+    pol = load_network_json(fix).to(env.device).double()
+    obs, _ = env.reset()
+    oobs = orc.reset(seed, 0)
+    gu.assert_close(obs.cpu().numpy(), oobs, 1e-5, 1e-5, "reset obs")
+    ret_g = np.zeros(N); ret_o = np.zeros(N)
+    for t in range(500):
+        a_g = pol(obs.double()).float().contiguous()
+        a_o = pol(torch.tensor(oobs, dtype=torch.float64, device=env.device)).float().cpu().numpy()
+        tick = env.tick
+        obs, r, term, trunc, info = env.step(a_g)
+        oobs, orr, oterm, otrunc, _ = orc.step(a_o, seed=seed, tick=tick, auto_reset=True)
+        assert not term.any() and not oterm.any(), f"t{t}: the reference policy must not fall"
+        assert np.array_equal(trunc.cpu().numpy().astype(bool), otrunc.astype(bool))
+        assert bool(trunc.all()) == (t == 499)
+        og = obs.cpu().numpy()
+        if t < 30:
+            # the high-gain rate loop amplifies the f32 rounding of the thrust differences (1/J ~ 6e4)
+            # in the body rates first; positions integrate it two steps later
+            gu.assert_close(og[:, 20:23], oobs[:, 20:23], 0.0, 5e-6, f"t{t} position")
+            gu.assert_close(og, oobs, 0.0, 5e-3, f"t{t} obs")
+            gu.assert_close(r.cpu().numpy(), orr, 0.0, 1e-5, f"t{t} reward")
+        elif t < 499:  # (the last step returns the reset observation)
+            gu.assert_close(og[:, 20:23], oobs[:, 20:23], 0.0, 8e-2, f"t{t} position drift")
+        ret_g += r.cpu().numpy(); ret_o += orr
+    dmean, dmax = abs(ret_g.mean() - ret_o.mean()), np.abs(ret_g - ret_o).max()
+    assert dmean < 0.01 * abs(ret_o.mean()) and dmax < 0.30 * abs(ret_o.mean()), (dmean, dmax, ret_o.mean())
+    gu.assert_close(info["final_obs"].cpu().numpy()[:, 20:23], orc.final_obs[:, 20:23], 0.0, 8e-2, "final_obs")
+    env.close()
