@@ -120,6 +120,27 @@ class ActorCritic(nn.Module):
         self.v = Critic(obs_dim, **ac_kwargs["val"])
         self.ret_oms = OnlineMeanStd(shape=(1,)) if use_scaled_rewards else None
 
+    @classmethod
+    def from_reference_state_dict(cls, sd, pi_activation="relu", val_activation="tanh"):
+        """ActorCritic with the layer sizes of a reference `torch_save/model.pt` state_dict
+        (utils/loggers.py:382-407), loaded strictly.  The checkpoints bundled under experiments/
+        come from an older reference version and also hold a cost critic `c.net.*`, which no
+        algorithm of the path reads: those keys are dropped."""
+        sd = {k: torch.as_tensor(v) for k, v in sd.items() if not k.startswith("c.")}
+
+        def hidden(prefix):
+            idx = sorted(int(k.split(".")[2]) for k in sd if k.startswith(prefix + ".net.") and k.endswith(".weight"))
+            return tuple(int(sd[f"{prefix}.net.{i}.weight"].shape[0]) for i in idx[:-1])
+
+        first = sd["pi.net.0.weight"]
+        last = sd["pi.net.%d.weight" % max(int(k.split(".")[2]) for k in sd if k.startswith("pi.net."))]
+        ac = cls(int(first.shape[1]), int(last.shape[0]),
+                 ac_kwargs={"pi": {"hidden_sizes": hidden("pi"), "activation": pi_activation},
+                            "val": {"hidden_sizes": hidden("v"), "activation": val_activation}},
+                 use_standardized_obs="obs_oms.mean" in sd, use_scaled_rewards="ret_oms.mean" in sd)
+        ac.load_state_dict(sd, strict=True)
+        return ac
+
     @torch.no_grad()
     def step(self, obs):
         """(action, value, log_prob) for raw observations [N, D] (algs/core.py:370-393)."""

@@ -73,3 +73,36 @@ def test_reference_policy_flies_the_batched_circle_env():
         lens[name] = total / count
         env.close()
     assert lens["policy"] > 3 * lens["random"], lens
+
+
+def test_bundled_checkpoint_exports_to_the_bundled_json(tmp_path):
+    """The reference ships both the training checkpoint (checkpoints/PWM/.../seed_00000/torch_save/
+    model.pt; tensors in tests/golden/ckpt_PWM_seed_00000.npz) and the firmware JSON exported from
+    it (models/PWM/PWM_seed_00000_model.json).  Loading the former into our ActorCritic and
+    exporting it must reproduce the latter: weights, scaling parameters and check_sum."""
+    from phoenix_drone_simulation_amd.policy_io import convert_actor_critic_to_json, load_network_json
+    from phoenix_drone_simulation_amd.ppo import ActorCritic
+    ck = np.load(os.path.join(os.path.dirname(FIX), "ckpt_PWM_seed_00000.npz"))
+    ac = ActorCritic.from_reference_state_dict({k: ck[k] for k in ck.files})
+    assert ac.pi.net[0].in_features == 40 and ac.pi.net[4].out_features == 4
+    out = tmp_path / "export.json"
+    mine = convert_actor_critic_to_json(ac, str(out))
+    with open(FIX) as f:
+        ref = json.load(f)
+    assert mine["activation"] == ref["activation"]
+    np.testing.assert_allclose(np.array(mine["scaling_parameters"]), np.array(ref["scaling_parameters"]), rtol=1e-6, atol=1e-7)
+    k = 0
+    while str(k) in ref:
+        assert ref[str(k)]["type"] == mine[str(k)]["type"] == "standard"
+        np.testing.assert_allclose(np.array(mine[str(k)]["weights"]), np.array(ref[str(k)]["weights"]), rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(np.array(mine[str(k)]["biases"]).reshape(-1), np.array(ref[str(k)]["biases"]).reshape(-1), rtol=1e-6, atol=1e-7)
+        k += 1
+    assert str(k) not in mine and k == 3
+    assert abs(float(mine["check_sum"]) - float(ref["check_sum"])) < 1e-4
+    # and the exported file drives the same actions as the bundled one
+    a, b = load_network_json(str(out)), load_network_json(FIX)
+    x = torch.randn(64, 40)
+    assert torch.allclose(a(x), b(x), atol=1e-6)
+    # deterministic (eval) ActorCritic.step == the JSON policy
+    ac.eval()
+    assert torch.allclose(ac.step(x)[0], b(x), atol=1e-5)
