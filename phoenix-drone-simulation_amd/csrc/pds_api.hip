@@ -281,7 +281,7 @@ extern "C" int pds_create(const pds_config *cfg, pds_handle **out) {
   if (cfg->struct_size != (int32_t)sizeof(pds_config)) { snprintf(g_create_err, sizeof(g_create_err), "pds_config size mismatch"); return PDS_EINVAL; }
   if (cfg->task < 0 || cfg->task > 2 || cfg->num_envs < 1 || cfg->aggregate_phy_steps < 1 ||
       cfg->max_episode_steps < 1 || cfg->max_episode_steps > 65535 || cfg->time_step <= 0 ||
-      cfg->num_envs > (1ll << 23)) {  // env index + ref_offset share a 32-bit reset-queue word
+      cfg->num_envs > (1ll << 30)) {  // the Philox counter carries a 32-bit global env id
     snprintf(g_create_err, sizeof(g_create_err), "invalid pds_config");
     return PDS_EINVAL;
   }

@@ -432,7 +432,7 @@ PDS_DEV void reset_store(const StepArgs &a, const float2 *ref_lds, long long i, 
   }
 }
 
-// Pass over the envs a wave queued for auto-reset (queue entry = env index | ref_offset << 23).
+// Pass over the envs a wave queued for auto-reset (queue entry = lane of the env in the wave's tile | ref_offset << 6).
 // Groups of 8 lanes serve one queued env: every lane computes one (or a few) of the env's Philox
 // blocks into an LDS scratch (the wave's observation tile, free after its flush), then the group's
 // first lane assembles the sample from the scratch and finishes the reset.  Without observation
@@ -445,7 +445,7 @@ constexpr int kResetsPerPass = kWave / kLanesPerReset;
 
 template <class V>
 PDS_DEV void drain_reset_queue(const StepArgs &a, const float2 *ref_lds, const uint32_t *queue, int qcount,
-                               int lane, float *tile) {
+                               int lane, long long wave_base, float *tile) {
   static_assert(kResetsPerPass * kScratchBlocks * 16 <= kHalfTileRows * V::D * 4, "scratch must fit in the wave's tile");
   U4 *scratch = reinterpret_cast<U4 *>(tile);
   const int g = lane / kLanesPerReset, b = lane % kLanesPerReset;
@@ -456,7 +456,7 @@ PDS_DEV void drain_reset_queue(const StepArgs &a, const float2 *ref_lds, const u
     const bool on = idx < qcount;
     uint32_t ent = 0;
     if (on) ent = queue[idx];
-    const long long i = (long long)(ent & 0x7FFFFFu);
+    const long long i = wave_base + (long long)(ent & 63u);
     const uint32_t env_id = (uint32_t)(a.env_id_base + (unsigned long long)i);
     if (on) {
       const DirectWords dw{env_id, a.tick_lo, a.tick_hi, a.seed_lo, a.seed_hi};
@@ -486,7 +486,7 @@ PDS_DEV void drain_reset_queue(const StepArgs &a, const float2 *ref_lds, const u
     }
     if (owner) {
       const LdsWords lw{scratch + g * kScratchBlocks};
-      reset_compute<V>(a, ref_lds, lw, ctr_pack(0u, 0u, ent >> 23), nullptr, stale_w, bias, r);
+      reset_compute<V>(a, ref_lds, lw, ctr_pack(0u, 0u, ent >> 6), nullptr, stale_w, bias, r);
     }
     if (!V::ON) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (owner) reset_store<V>(a, ref_lds, i, r);

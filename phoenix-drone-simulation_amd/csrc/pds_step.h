@@ -426,7 +426,7 @@ __global__ __launch_bounds__(kBlock, PDS_MIN_WAVES) void step_kernel(const StepA
       const int pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(reset_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)reset_mask, 0u));
       qcount = __popcll(reset_mask);
       if (!MERGED) {
-        if (need_reset) queue[pos] = (uint32_t)i | ((uint32_t)ref_offset << 23);
+        if (need_reset) queue[pos] = (uint32_t)lane | ((uint32_t)ref_offset << 6);
       } else {
         if (need_reset) queue[pos] = (uint32_t)lane;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(kBlock, PDS_MIN_WAVES) void step_kernel(const StepA
       __builtin_amdgcn_wave_barrier();  // the tile is rewritten by the next pass / the reset drain
     }
   }
-  if (!MERGED && qcount > 0) drain_reset_queue<V>(a, ref_lds, queue, qcount, lane, tile);
+  if (!MERGED && qcount > 0) drain_reset_queue<V>(a, ref_lds, queue, qcount, lane, wave_base, tile);
 }
 
 // ---- per-task instantiation (one translation unit per task keeps the build parallel) -----------

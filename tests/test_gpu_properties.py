@@ -201,3 +201,31 @@ def test_half_and_full_observation_tile_agree_bitwise(task, kw, monkeypatch):
     assert finished > n  # every env hit the 23-step limit at least once
     for e in envs:
         e.close()
+
+
+@pytest.mark.parametrize("kw", [{}, dict(use_motor_dynamics=True, domain_randomization=0.1)])
+def test_more_than_2_pow_23_envs_per_handle(kw):
+    """Env indices beyond 2^23 (the handle is sized for HBM, not for a packed queue word): the head
+    and the tail of an 8.4 M-env batch reproduce small handles with the same global env ids bitwise,
+    through resets (max_episode_steps = 3) on both the merged and the deferred auto-reset path."""
+    import phoenix_drone_simulation_amd as pds
+    n, m = (1 << 23) + 100, 1000
+    base = dict(DET, seed=17, max_episode_steps=3)
+    base.update(kw)
+    big = pds.make(ENV_ID["hover"], num_envs=n, **base)
+    head = pds.make(ENV_ID["hover"], num_envs=m, env_id_base=0, **base)
+    tail = pds.make(ENV_ID["hover"], num_envs=m, env_id_base=n - m, **base)
+    ob, _ = big.reset(); oh, _ = head.reset(); ot, _ = tail.reset()
+    assert torch.equal(ob[:m], oh) and torch.equal(ob[n - m:], ot)
+    g = torch.Generator(device=ob.device); g.manual_seed(4)
+    for k in range(7):
+        a = (-1.0 + 2.0 / 2.25) + 0.1 * torch.randn(n, 4, generator=g, device=ob.device)
+        rb = big.step(a); rh = head.step(a[:m].contiguous()); rt = tail.step(a[n - m:].contiguous())
+        for x, y, z in zip(rb[:4], rh[:4], rt[:4]):
+            assert torch.equal(x[:m], y) and torch.equal(x[n - m:], z)
+        fin = rh[2] | rh[3]
+        assert torch.equal(rb[4]["final_obs"][:m][fin], rh[4]["final_obs"][fin])
+        if k == 2:  # envs that have not fallen yet hit the 3-step limit together
+            assert float(rb[3].float().mean()) > 0.5
+    for e in (big, head, tail):
+        e.close()
