@@ -214,6 +214,41 @@ int pds_gae(const float *d_rew, const float *d_val, const uint8_t *d_terminated,
             float rew_clip, int64_t T, int64_t N, float *d_adv, float *d_target_v, float *d_disc_ret,
             void *stream);
 
+/* ---- caller-side dense kernels on the f32 matrix cores ----------------------
+ * A 3-layer MLP in torch's nn.Linear layout (weights [out][in] row-major, device pointers):
+ * y = W3 act(W2 act(W1 x + b1) + b2) + b3; d_in, h1, h2 <= 64, d_out <= 8; activation 0 relu, 1 tanh.
+ * Mirrors build_mlp_network / MLPGaussianActor.net / MLPCritic.net (algs/core.py:65-103, 228-311). */
+typedef struct pds_mlp {
+  int32_t d_in, h1, h2, d_out, activation;
+  const float *w1, *b1, *w2, *b2, *w3, *b3;
+} pds_mlp;
+
+/* number of parameters; flat gradient layout = [W1, b1, W2, b2, W3, b3] (torch parameter order) */
+int pds_mlp_param_count(const pds_mlp *m);
+/* floats of scratch the *_grad entry points need (per-wave partial sums) */
+int64_t pds_mlp_workspace_floats(const pds_mlp *m);
+
+/* d_y[B, d_out] = MLP(x'), x' = row d_index[g] (or g when d_index is NULL) of d_x[rows, d_in],
+ * standardised as (x - mean) / (std + eps) when d_mean / d_std are given (OnlineMeanStd.forward,
+ * utils/online_mean_std.py:32-43).  Replaces ActorCritic.step's network calls (algs/core.py:370-393). */
+int pds_mlp_forward(const pds_mlp *m, const float *d_x, const int64_t *d_index, int64_t B, const float *d_mean,
+                    const float *d_std, float eps, float *d_y, void *stream);
+
+/* Gradient of the PPO-clip policy loss  -mean(min(r A, clip(r, 1-c, 1+c) A)),  r = exp(logp - logp_old),
+ * logp = Normal(MLP(x), exp(log_std)).log_prob(act).sum(-1)  (compute_loss_pi, algs/ppo/ppo.py:22-40)
+ * with respect to the MLP parameters: d_grads[param_count]; d_stats[4] = {sum of -min(..), sum of r,
+ * sum over samples and actions of 0.5 z^2 (approx_kl numerator), sample count}.  d_x is the
+ * already standardised observation batch [B, d_in]. */
+int pds_ppo_policy_grad(const pds_mlp *m, const float *d_x, const float *d_act, const float *d_adv,
+                        const float *d_logp_old, const float *d_log_std, int64_t B, float clip_ratio, float *d_grads,
+                        float *d_stats, float *d_workspace, void *stream);
+
+/* Gradient of mse_loss(MLP(x[index]), target[index]) (compute_loss_v, algs/iwpg/iwpg.py:272-275) for a
+ * critic (d_out == 1); d_index selects the mini-batch rows (NULL: rows 0..B-1); d_stats[0] = sum of
+ * squared errors, d_stats[3] = sample count. */
+int pds_value_grad(const pds_mlp *m, const float *d_x, const int64_t *d_index, const float *d_target, int64_t B,
+                   float *d_grads, float *d_stats, float *d_workspace, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

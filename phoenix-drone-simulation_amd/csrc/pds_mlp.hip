@@ -1,0 +1,452 @@
+// pds_mlp.hip -- the trainer's dense work on the f32 matrix cores of gfx950:
+// fused 3-layer MLP forward (rollout inference of actor / critic) and fused loss + backward of the
+// PPO-clip policy objective and of the value regression, one pass over the batch per call.
+//
+// Replaces, in the caller of the hot path, the PyTorch op chains of
+//   ActorCritic.step / MLPGaussianActor / MLPCritic        algs/core.py:228-311, 370-393
+//   ProximalPolicyOptimizationAlgorithm.compute_loss_pi     algs/ppo/ppo.py:22-40
+//   IWPGAlgorithm.compute_loss_v / update_value_net         algs/iwpg/iwpg.py:272-275, 487-522
+// (80 full-batch policy iterations + 5 x 16 value mini-batches per epoch, algs/ppo/defaults.py:6-19):
+// autograd materialises ~30 [B, 50] tensors per iteration in HBM; here a wave keeps a 32-sample
+// tile in LDS, runs every GEMM of forward and backward on v_mfma_f32_32x32x2_f32 (exact f32: a
+// k-ordered fmaf chain, so results match an fp32 reference to rounding), accumulates the weight
+// gradients in registers across its tiles and writes one partial per wave; a second tiny kernel
+// sums the partials in a fixed order (deterministic, no atomics).
+//
+// GEMM operands always come from LDS in natural [row][col] images with an odd row stride (65), so
+// the A map (lane l: A[l&31][l>>5]) and the B map (B[l>>5][l&31]) of the instruction read either
+// consecutive words or a conflict-free odd-stride column, whichever way a matrix is walked:
+//   forward      Z1 = X W1^T, Z2 = H1 W2^T, Y = H2 W3^T            (M = samples)
+//   backward     dH2 = dY W3, dH1 = dZ2 W2                          (M = samples)
+//   weight grads dW3 = dY^T H2, dW2 = dZ2^T H1, dW1 = dZ1^T X       (K = the tile's 32 samples)
+// Bound: MFMA f32 (157 TFLOP/s dense peak on MI355X = the f32 vector rate; MI355X_MICROARCH.md).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pds.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kTS = 32;            // samples per wave tile (= M of one MFMA tile)
+constexpr int kLS = 65;            // LDS row stride of every [rows][<= 64] image (odd: conflict-free both ways)
+constexpr int kOS = 9;             // row stride of the [32][<= 8] output / output-gradient tile
+constexpr int kMaxDim = 64;        // d_in, h1, h2 <= 64
+constexpr int kMaxOut = 8;         // d_out <= 8
+constexpr int kWaves = 4;          // waves per block, one per SIMD; 1 block per CU (LDS-bound)
+constexpr int kStats = 4;          // loss sum, ratio sum, kl sum, sample count
+
+enum { LOSS_NONE = 0, LOSS_PPO = 1, LOSS_MSE = 2 };
+
+struct Args {
+  pds_mlp m;
+  const float *x;            // [rows, d_in]
+  const int64_t *index;      // optional gather: sample g reads row index[g]
+  long long B;               // samples
+  const float *mean, *stdv;  // optional input standardisation (x - mean) / (std + eps)
+  float eps;
+  float *y;                  // forward output [B, d_out]
+  const float *act, *adv, *logp_old, *log_std;  // PPO
+  const float *target;                          // MSE
+  float clip;
+  float *partials;           // [waves of the grid][pstride]
+  int pstride;
+};
+
+__device__ __forceinline__ int row_of(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// c[32x32] += A[32 x K] * B[K x 32]; element (m, k) of A at A[m * a_sm + k * a_sk], (k, n) of B at
+// B[k * b_sk + n * b_sn]; lanes whose row index is >= a_rows feed zeros (short matrices).
+__device__ __forceinline__ void mma_tile(f32x16 &c, const float *A, int a_sm, int a_sk, int a_rows, const float *B,
+                                         int b_sk, int b_sn, int K, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  const float *ap = A + r * a_sm + h * a_sk;
+  const float *bp = B + h * b_sk + r * b_sn;
+  const bool a_on = r < a_rows;
+#pragma unroll 2
+  for (int k = 0; k < K; k += 2) {
+    const float a = a_on ? ap[k * a_sk] : 0.f;
+    const float b = bp[k * b_sk];
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ float act_fn(float v, int act) { return act == 0 ? fmaxf(v, 0.f) : tanhf(v); }
+// derivative expressed through the activation's OUTPUT h (relu: h > 0; tanh: 1 - h^2)
+__device__ __forceinline__ float act_grad(float h, int act) { return act == 0 ? (h > 0.f ? 1.f : 0.f) : 1.f - h * h; }
+
+__device__ __forceinline__ int even_up(int v) { return (v + 1) & ~1; }
+
+// flat parameter layout == torch's nn.Sequential order: W1 [h1][d_in], b1, W2 [h2][h1], b2, W3 [d_out][h2], b3
+struct Offsets {
+  int w1, b1, w2, b2, w3, b3, total;
+};
+__host__ __device__ inline Offsets offsets(const pds_mlp &m) {
+  Offsets o;
+  o.w1 = 0;
+  o.b1 = o.w1 + m.h1 * m.d_in;
+  o.w2 = o.b1 + m.h1;
+  o.b2 = o.w2 + m.h2 * m.h1;
+  o.w3 = o.b2 + m.h2;
+  o.b3 = o.w3 + m.d_out * m.h2;
+  o.total = o.b3 + m.d_out;
+  return o;
+}
+
+template <int LOSS>
+__global__ __launch_bounds__(kWaves * 64, 1) void mlp_kernel(const Args a) {
+  // ---- LDS images ---------------------------------------------------------------------------------
+  __shared__ float W1s[kMaxDim * kLS], W2s[kMaxDim * kLS], W3s[kTS * kLS];  // [out][in], zero padded
+  __shared__ float b1s[kMaxDim], b2s[kMaxDim], b3s[kMaxOut], isg[kMaxOut], lsg[kMaxOut];
+  __shared__ float tiles[kWaves * (3 * kTS * kLS + kTS * kOS)];
+  const pds_mlp &m = a.m;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int act = m.activation;
+  for (int i = tid; i < kMaxDim * kLS; i += kWaves * 64) {
+    const int n = i / kLS, k = i - n * kLS;
+    W1s[i] = (n < m.h1 && k < m.d_in) ? m.w1[n * m.d_in + k] : 0.f;
+    W2s[i] = (n < m.h2 && k < m.h1) ? m.w2[n * m.h1 + k] : 0.f;
+    if (i < kTS * kLS) W3s[i] = (n < m.d_out && k < m.h2) ? m.w3[n * m.h2 + k] : 0.f;
+  }
+  if (tid < kMaxDim) {
+    b1s[tid] = tid < m.h1 ? m.b1[tid] : 0.f;
+    b2s[tid] = tid < m.h2 ? m.b2[tid] : 0.f;
+  }
+  if (tid < kMaxOut) {
+    b3s[tid] = tid < m.d_out ? m.b3[tid] : 0.f;
+    const float ls = (LOSS == LOSS_PPO && tid < m.d_out) ? a.log_std[tid] : 0.f;
+    lsg[tid] = ls;
+    isg[tid] = expf(-ls);  // 1 / sigma
+  }
+  float *X = tiles + wave * (3 * kTS * kLS + kTS * kOS);
+  float *H1 = X + kTS * kLS, *H2 = H1 + kTS * kLS, *Y = H2 + kTS * kLS;
+  for (int i = lane; i < 3 * kTS * kLS + kTS * kOS; i += 64) X[i] = 0.f;  // pad columns stay zero
+  __syncthreads();
+
+  const int K1 = even_up(m.d_in), K2 = even_up(m.h1), K3 = even_up(m.h2), KO = even_up(m.d_out);
+  const int col = lane & 31;
+  // weight-gradient accumulators of this wave (over all of its tiles)
+  f32x16 gW1[2][2], gW2[2][2], gW3[2];
+  float gb1[2] = {0.f, 0.f}, gb2[2] = {0.f, 0.f}, gb3 = 0.f;
+  float st_loss = 0.f, st_ratio = 0.f, st_kl = 0.f, st_cnt = 0.f;
+  if (LOSS != LOSS_NONE) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      gW3[i] = (f32x16)(0.f);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) { gW1[i][j] = (f32x16)(0.f); gW2[i][j] = (f32x16)(0.f); }
+    }
+  }
+
+  const long long ntiles = (a.B + kTS - 1) / kTS;
+  const long long wid = (long long)blockIdx.x * kWaves + wave, nw = (long long)gridDim.x * kWaves;
+  for (long long t = wid; t < ntiles; t += nw) {
+    const long long s0 = t * kTS;
+    // ---- stage the input tile (optionally gathered and standardised) -----------------------------
+    {
+      const bool kon = lane < m.d_in;
+      float mu = 0.f, is = 1.f;
+      if (a.mean != nullptr && kon) { mu = a.mean[lane]; is = 1.0f / (a.stdv[lane] + a.eps); }
+#pragma unroll 8
+      for (int s = 0; s < kTS; ++s) {
+        const long long g = s0 + s;
+        float v = 0.f;
+        if (kon && g < a.B) {
+          const long long row = a.index != nullptr ? a.index[g] : g;
+          v = (a.x[row * m.d_in + lane] - mu) * is;
+        }
+        if (lane < kMaxDim) X[s * kLS + lane] = v;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- forward ---------------------------------------------------------------------------------
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {  // H1 = act(X W1^T + b1)
+      f32x16 c = (f32x16)(0.f);
+      mma_tile(c, X, kLS, 1, kTS, W1s + nt * 32 * kLS, 1, kLS, K1, lane);
+      const int n = nt * 32 + col;
+      const float bias = b1s[n];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) H1[row_of(r, lane) * kLS + n] = n < m.h1 ? act_fn(c[r] + bias, act) : 0.f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {  // H2 = act(H1 W2^T + b2)
+      f32x16 c = (f32x16)(0.f);
+      mma_tile(c, H1, kLS, 1, kTS, W2s + nt * 32 * kLS, 1, kLS, K2, lane);
+      const int n = nt * 32 + col;
+      const float bias = b2s[n];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) H2[row_of(r, lane) * kLS + n] = n < m.h2 ? act_fn(c[r] + bias, act) : 0.f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {  // Y = H2 W3^T + b3
+      f32x16 c = (f32x16)(0.f);
+      mma_tile(c, H2, kLS, 1, kTS, W3s, 1, kLS, K3, lane);
+      if (col < kMaxOut) {
+        const float bias = b3s[col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Y[row_of(r, lane) * kOS + col] = col < m.d_out ? c[r] + bias : 0.f;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    if (LOSS == LOSS_NONE) {
+      if (lane < kTS && s0 + lane < a.B)
+        for (int j = 0; j < m.d_out; ++j) a.y[(s0 + lane) * m.d_out + j] = Y[lane * kOS + j];
+      __builtin_amdgcn_wave_barrier();
+      continue;
+    }
+
+    // ---- loss and its gradient with respect to the network output (lanes 0..31: one sample each) ---
+    if (lane < kTS) {
+      const long long g = s0 + lane;
+      float *yr = Y + lane * kOS;
+      if (g < a.B) {
+        if (LOSS == LOSS_PPO) {
+          // compute_loss_pi, algs/ppo/ppo.py:22-40 (Normal(mu, sigma).log_prob(act).sum(-1))
+          float logp = 0.f, kl = 0.f, z[kMaxOut];
+          for (int j = 0; j < m.d_out; ++j) {
+            z[j] = (a.act[g * m.d_out + j] - yr[j]) * isg[j];
+            logp += -0.5f * z[j] * z[j] - lsg[j] - 0.91893853320467274178f;
+            kl += 0.5f * z[j] * z[j];
+          }
+          const float ratio = expf(logp - a.logp_old[g]);
+          const float adv = a.adv[g];
+          const float lo = 1.f - a.clip, hi = 1.f + a.clip;
+          const float obj = fminf(ratio * adv, fminf(fmaxf(ratio, lo), hi) * adv);
+          // d min(r A, clip(r) A) / d r  (torch.min splits ties, clamp passes its range: net A inside
+          // the range, A outside it only on the un-clipped branch)
+          const bool cut = (adv > 0.f && ratio > hi) || (adv < 0.f && ratio < lo);
+          const float gcoef = cut ? 0.f : -adv * ratio;  // d(-obj)/d logp
+          for (int j = 0; j < m.d_out; ++j) yr[j] = gcoef * z[j] * isg[j];
+          st_loss += -obj; st_ratio += ratio; st_kl += kl; st_cnt += 1.f;
+        } else {
+          // compute_loss_v: mse_loss(v(obs), target_v), algs/iwpg/iwpg.py:272-275
+          const long long row = a.index != nullptr ? a.index[g] : g;
+          const float d = yr[0] - a.target[row];
+          st_loss += d * d; st_cnt += 1.f;
+          yr[0] = 2.f * d;
+        }
+      } else {
+        for (int j = 0; j < m.d_out; ++j) yr[j] = 0.f;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- backward --------------------------------------------------------------------------------
+    // dW3 += dY^T H2 (rows = outputs, K = samples); db3 += column sums of dY
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+      mma_tile(gW3[nt], Y, 1, kOS, kMaxOut, H2 + nt * 32, kLS, 1, kTS, lane);
+    if (lane < kMaxOut) {
+      float sacc = 0.f;
+      for (int s = 0; s < kTS; ++s) sacc += Y[s * kOS + lane];
+      gb3 += sacc;
+    }
+    // dZ2 = (dY W3) * act'(H2), in place over H2
+    {
+      f32x16 c[2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        c[nt] = (f32x16)(0.f);
+        mma_tile(c[nt], Y, kOS, 1, kTS, W3s + nt * 32, kLS, 1, KO, lane);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();  // every dW3 read of H2 is done
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int n = nt * 32 + col;
+        float sacc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float *p = H2 + row_of(r, lane) * kLS + n;
+          const float dz = n < m.h2 ? c[nt][r] * act_grad(*p, act) : 0.f;
+          *p = dz;
+          sacc += dz;
+        }
+        gb2[nt] += sacc;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // dW2 += dZ2^T H1
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+        mma_tile(gW2[it][jt], H2 + it * 32, 1, kLS, kTS, H1 + jt * 32, kLS, 1, kTS, lane);
+    // dZ1 = (dZ2 W2) * act'(H1), in place over H1
+    {
+      f32x16 c[2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        c[nt] = (f32x16)(0.f);
+        mma_tile(c[nt], H2, kLS, 1, kTS, W2s + nt * 32, kLS, 1, K3, lane);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();  // every dW2 read of H1 is done
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int n = nt * 32 + col;
+        float sacc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float *p = H1 + row_of(r, lane) * kLS + n;
+          const float dz = n < m.h1 ? c[nt][r] * act_grad(*p, act) : 0.f;
+          *p = dz;
+          sacc += dz;
+        }
+        gb1[nt] += sacc;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // dW1 += dZ1^T X
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+        mma_tile(gW1[it][kt], H1 + it * 32, 1, kLS, kTS, X + kt * 32, kLS, 1, kTS, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // the tile images are restaged by the next iteration
+  }
+
+  if (LOSS == LOSS_NONE) return;
+  // ---- this wave's partial sums -> partials[wid][...] (flat parameter layout + statistics) -----------
+  float *out = a.partials + wid * a.pstride;
+  const Offsets o = offsets(m);
+#pragma unroll
+  for (int it = 0; it < 2; ++it)
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = it * 32 + row_of(r, lane), j = jt * 32 + col;
+        if (i < m.h1 && j < m.d_in) out[o.w1 + i * m.d_in + j] = gW1[it][jt][r];
+        if (i < m.h2 && j < m.h1) out[o.w2 + i * m.h1 + j] = gW2[it][jt][r];
+      }
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = row_of(r, lane), j = jt * 32 + col;
+      if (i < m.d_out && j < m.h2) out[o.w3 + i * m.h2 + j] = gW3[jt][r];
+    }
+  // bias gradients: lanes l and l + 32 hold the two row halves of the same column
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const float v1 = gb1[nt] + __shfl_xor(gb1[nt], 32);
+    const float v2 = gb2[nt] + __shfl_xor(gb2[nt], 32);
+    const int n = nt * 32 + col;
+    if (lane < 32) {
+      if (n < m.h1) out[o.b1 + n] = v1;
+      if (n < m.h2) out[o.b2 + n] = v2;
+    }
+  }
+  if (lane < m.d_out) out[o.b3 + lane] = gb3;
+  // statistics: lanes 0..31 hold per-sample sums
+  float s4[kStats] = {st_loss, st_ratio, st_kl, st_cnt};
+#pragma unroll
+  for (int q = 0; q < kStats; ++q) {
+    float v = s4[q];
+    for (int d = 16; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    if (lane == 0) out[o.total + q] = v;
+  }
+}
+
+// grads[p] = sum over the waves' partials (fixed order) / count; stats likewise
+__global__ __launch_bounds__(256) void reduce_kernel(const float *partials, int pstride, int nwaves, int total,
+                                                     float denom_scale, float *grads, float *stats) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= total + kStats) return;
+  float s = 0.f;
+  for (int w = 0; w < nwaves; ++w) s += partials[(long long)w * pstride + p];
+  if (p < total) grads[p] = s * denom_scale;
+  else stats[p - total] = s;
+}
+
+int check(const pds_mlp *m) {
+  if (!m || m->d_in < 1 || m->d_in > kMaxDim || m->h1 < 1 || m->h1 > kMaxDim || m->h2 < 1 || m->h2 > kMaxDim ||
+      m->d_out < 1 || m->d_out > kMaxOut || (m->activation != 0 && m->activation != 1) || !m->w1 || !m->b1 ||
+      !m->w2 || !m->b2 || !m->w3 || !m->b3)
+    return PDS_EINVAL;
+  return PDS_OK;
+}
+
+int grid_blocks(long long B) {
+  const long long tiles = (B + kTS - 1) / kTS;
+  const long long blocks = (tiles + kWaves - 1) / kWaves;
+  return (int)(blocks < 256 ? blocks : 256);  // one persistent block per CU
+}
+
+constexpr int kMaxGridWaves = 256 * kWaves;
+
+}  // namespace
+
+extern "C" int pds_mlp_param_count(const pds_mlp *m) {
+  if (check(m) != PDS_OK) return PDS_EINVAL;
+  return offsets(*m).total;
+}
+
+extern "C" int64_t pds_mlp_workspace_floats(const pds_mlp *m) {
+  if (check(m) != PDS_OK) return PDS_EINVAL;
+  return (int64_t)kMaxGridWaves * (offsets(*m).total + kStats);
+}
+
+extern "C" int pds_mlp_forward(const pds_mlp *m, const float *d_x, const int64_t *d_index, int64_t B,
+                               const float *d_mean, const float *d_std, float eps, float *d_y, void *stream) {
+  if (check(m) != PDS_OK || !d_x || !d_y || B < 1 || ((d_mean == nullptr) != (d_std == nullptr))) return PDS_EINVAL;
+  Args a{};
+  a.m = *m; a.x = d_x; a.index = d_index; a.B = B; a.mean = d_mean; a.stdv = d_std; a.eps = eps; a.y = d_y;
+  hipLaunchKernelGGL(mlp_kernel<LOSS_NONE>, dim3(grid_blocks(B)), dim3(kWaves * 64), 0, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? PDS_OK : PDS_EHIP;
+}
+
+static int launch_grad(int loss, Args &a, float *d_grads, float *d_stats, float *d_workspace, void *stream) {
+  const Offsets o = offsets(a.m);
+  const int blocks = grid_blocks(a.B);
+  a.partials = d_workspace;
+  a.pstride = o.total + kStats;
+  hipStream_t s = (hipStream_t)stream;
+  if (loss == LOSS_PPO) hipLaunchKernelGGL(mlp_kernel<LOSS_PPO>, dim3(blocks), dim3(kWaves * 64), 0, s, a);
+  else hipLaunchKernelGGL(mlp_kernel<LOSS_MSE>, dim3(blocks), dim3(kWaves * 64), 0, s, a);
+  const int n = o.total + kStats;
+  hipLaunchKernelGGL(reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const float *)d_workspace, a.pstride,
+                     blocks * kWaves, o.total, 1.0f / (float)a.B, d_grads, d_stats);
+  return hipGetLastError() == hipSuccess ? PDS_OK : PDS_EHIP;
+}
+
+extern "C" int pds_ppo_policy_grad(const pds_mlp *m, const float *d_x, const float *d_act, const float *d_adv,
+                                   const float *d_logp_old, const float *d_log_std, int64_t B, float clip_ratio,
+                                   float *d_grads, float *d_stats, float *d_workspace, void *stream) {
+  if (check(m) != PDS_OK || !d_x || !d_act || !d_adv || !d_logp_old || !d_log_std || !d_grads || !d_stats ||
+      !d_workspace || B < 1)
+    return PDS_EINVAL;
+  Args a{};
+  a.m = *m; a.x = d_x; a.B = B; a.act = d_act; a.adv = d_adv; a.logp_old = d_logp_old; a.log_std = d_log_std;
+  a.clip = clip_ratio;
+  return launch_grad(LOSS_PPO, a, d_grads, d_stats, d_workspace, stream);
+}
+
+extern "C" int pds_value_grad(const pds_mlp *m, const float *d_x, const int64_t *d_index, const float *d_target,
+                              int64_t B, float *d_grads, float *d_stats, float *d_workspace, void *stream) {
+  if (check(m) != PDS_OK || m->d_out != 1 || !d_x || !d_target || !d_grads || !d_stats || !d_workspace || B < 1)
+    return PDS_EINVAL;
+  Args a{};
+  a.m = *m; a.x = d_x; a.index = d_index; a.B = B; a.target = d_target;
+  return launch_grad(LOSS_MSE, a, d_grads, d_stats, d_workspace, stream);
+}

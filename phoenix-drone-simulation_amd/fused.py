@@ -1,0 +1,94 @@
+"""Host side of csrc/pds_mlp.hip: the trainer's dense work as fused HIP kernels
+on the f32 matrix cores -- MLP forward for the rollout, PPO-clip policy gradient and value-regression
+gradient for the update.  Each call replaces an autograd op chain of the reference trainer:
+
+    FusedMLP.forward      ActorCritic.step / MLPGaussianActor.net / MLPCritic.net  algs/core.py:228-311,370-393
+    FusedMLP.ppo_grad     compute_loss_pi + backward                                algs/ppo/ppo.py:22-40
+    FusedMLP.value_grad   compute_loss_v + backward                                 algs/iwpg/iwpg.py:272-275
+
+The gradients are written straight into the `.grad` storage of the torch parameters (one flat
+buffer, torch parameter order), so the optimiser step stays torch.optim.Adam like the reference's."""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import native
+
+_ACT = {"relu": 0, "tanh": 1}
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class FusedMLP:
+    """View of `nn.Sequential(Linear, act, Linear, act, Linear[, Identity])` as a struct pds_mlp."""
+
+    def __init__(self, net, activation):
+        lin = [l for l in net if isinstance(l, nn.Linear)]
+        if len(lin) != 3 or activation not in _ACT:
+            raise NotImplementedError("fused kernels cover 2 hidden layers with relu or tanh")
+        self.lin = lin
+        self.params = [p for l in lin for p in (l.weight, l.bias)]
+        for p in self.params:
+            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                raise ValueError("fused kernels need contiguous float32 parameters on the HIP device")
+        self.lib = native.load()
+        m = native.Mlp()
+        m.d_in, m.h1, m.h2, m.d_out = lin[0].in_features, lin[0].out_features, lin[1].out_features, lin[2].out_features
+        m.activation = _ACT[activation]
+        self.m = m
+        self._bind()
+        n = self.lib.pds_mlp_param_count(C.byref(m))
+        if n < 0:
+            raise ValueError("layer sizes outside the fused kernels' range (d_in, h1, h2 <= 64, d_out <= 8)")
+        dev = self.params[0].device
+        self.flat_grad = torch.zeros(n, device=dev)
+        off = 0
+        for p in self.params:  # .grad of every parameter is a view into the flat buffer the kernel fills
+            p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self.stats = torch.zeros(4, device=dev)
+        self.workspace = torch.empty(self.lib.pds_mlp_workspace_floats(C.byref(m)), device=dev)
+
+    def _bind(self):
+        m, l = self.m, self.lin
+        m.w1, m.b1, m.w2, m.b2, m.w3, m.b3 = (p.data_ptr() for p in (l[0].weight, l[0].bias, l[1].weight, l[1].bias,
+                                                                       l[2].weight, l[2].bias))
+
+    @staticmethod
+    def _stream():
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def forward(self, x, index=None, mean=None, std=None, eps=1e-5, out=None):
+        """y[B, d_out] = net(standardise(x[index]))."""
+        self._bind()
+        B = x.shape[0] if index is None else index.shape[0]
+        y = out if out is not None else torch.empty(B, self.m.d_out, device=x.device)
+        rc = self.lib.pds_mlp_forward(C.byref(self.m), _ptr(x), _ptr(index), B, _ptr(mean), _ptr(std), float(eps),
+                                      _ptr(y), self._stream())
+        if rc != native.OK:
+            raise RuntimeError(f"pds_mlp_forward -> {rc}")
+        return y
+
+    def ppo_grad(self, x, act, adv, logp_old, log_std, clip_ratio):
+        """Fills the parameters' .grad with d loss_pi / d theta; returns the stats tensor
+        [sum(-min(..)), sum(ratio), sum(0.5 z^2), B] (device, no sync)."""
+        self._bind()
+        rc = self.lib.pds_ppo_policy_grad(C.byref(self.m), _ptr(x), _ptr(act), _ptr(adv), _ptr(logp_old), _ptr(log_std),
+                                          x.shape[0], float(clip_ratio), _ptr(self.flat_grad), _ptr(self.stats),
+                                          _ptr(self.workspace), self._stream())
+        if rc != native.OK:
+            raise RuntimeError(f"pds_ppo_policy_grad -> {rc}")
+        return self.stats
+
+    def value_grad(self, x, target, index=None):
+        """Fills .grad with d mse(net(x[index]), target[index]) / d theta; stats[0] = sum of squared errors."""
+        self._bind()
+        B = x.shape[0] if index is None else index.shape[0]
+        rc = self.lib.pds_value_grad(C.byref(self.m), _ptr(x), _ptr(index), _ptr(target), B, _ptr(self.flat_grad),
+                                     _ptr(self.stats), _ptr(self.workspace), self._stream())
+        if rc != native.OK:
+            raise RuntimeError(f"pds_value_grad -> {rc}")
+        return self.stats

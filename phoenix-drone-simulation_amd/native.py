@@ -31,7 +31,17 @@ STEP_NOISE_LAYOUT = dict(ou=0, a_bias=4, a_rw=7, a_to=10, obs=13)
 EXPORTS = ["pds_version", "pds_default_config", "pds_create", "pds_destroy", "pds_obs_dim",
            "pds_num_envs", "pds_reset", "pds_reset_from_samples", "pds_step", "pds_step_with_variates",
            "pds_field_width",
-           "pds_get_state", "pds_set_state", "pds_tick", "pds_bytes_per_env_step", "pds_last_error", "pds_gae"]
+           "pds_get_state", "pds_set_state", "pds_tick", "pds_bytes_per_env_step", "pds_last_error", "pds_gae",
+           "pds_mlp_param_count", "pds_mlp_workspace_floats", "pds_mlp_forward", "pds_ppo_policy_grad",
+           "pds_value_grad"]
+
+
+class Mlp(C.Structure):
+    """struct pds_mlp (include/pds.h): 3-layer MLP, torch nn.Linear layout, device pointers."""
+    _fields_ = [("d_in", C.c_int32), ("h1", C.c_int32), ("h2", C.c_int32), ("d_out", C.c_int32),
+                ("activation", C.c_int32),
+                ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
+                ("w3", C.c_void_p), ("b3", C.c_void_p)]
 
 
 class Config(C.Structure):
@@ -88,6 +98,13 @@ def load():
     lib.pds_last_error.argtypes = [vp]
     lib.pds_last_error.restype = C.c_char_p
     lib.pds_gae.argtypes = [vp] * 6 + [C.c_float] * 4 + [i64, i64] + [vp] * 4
+    mp = C.POINTER(Mlp)
+    lib.pds_mlp_param_count.argtypes = [mp]
+    lib.pds_mlp_workspace_floats.argtypes = [mp]
+    lib.pds_mlp_workspace_floats.restype = i64
+    lib.pds_mlp_forward.argtypes = [mp, vp, vp, i64, vp, vp, C.c_float, vp, vp]
+    lib.pds_ppo_policy_grad.argtypes = [mp, vp, vp, vp, vp, vp, i64, C.c_float, vp, vp, vp, vp]
+    lib.pds_value_grad.argtypes = [mp, vp, vp, vp, i64, vp, vp, vp, vp]
     _lib = lib
     return lib
 
