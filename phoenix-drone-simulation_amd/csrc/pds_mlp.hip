@@ -56,25 +56,65 @@ struct Args {
 
 __device__ __forceinline__ int row_of(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
-// c[32x32] += A[32 x K] * B[K x 32]; element (m, k) of A at A[m * a_sm + k * a_sk], (k, n) of B at
-// B[k * b_sk + n * b_sn]; lanes whose row index is >= a_rows feed zeros (short matrices).
-__device__ __forceinline__ void mma_tile(f32x16 &c, const float *A, int a_sm, int a_sk, int a_rows, const float *B,
-                                         int b_sk, int b_sn, int K, int lane) {
+// c[i][j] (32x32 each) += A_i[32 x K] * B_j[K x 32] for NA row tiles of A and NB column tiles of B.
+// Element (m, k) of A tile i at A[i * a_toff + m * a_sm + k * a_sk], (k, n) of B tile j at
+// B[j * b_toff + k * b_sk + n * b_sn]; lanes whose row index is >= a_rows feed zeros (short
+// matrices).  K is walked in chunks of 4 MFMA k-steps (8 k values): the operands of the next chunk
+// are read from LDS while the matrix core works on the current one.  The walk may run up to 7 k
+// values past K: every image is zero padded to 64 columns / rows, so that adds zeros.
+template <int NA, int NB>
+__device__ __forceinline__ void mma_block(f32x16 (&c)[NA][NB], const float *A, int a_sm, int a_sk, int a_toff,
+                                          int a_rows, const float *B, int b_sk, int b_sn, int b_toff, int K, int lane) {
+  constexpr int CH = 4;
   const int r = lane & 31, h = lane >> 5;
   const float *ap = A + r * a_sm + h * a_sk;
   const float *bp = B + h * b_sk + r * b_sn;
   const bool a_on = r < a_rows;
-#pragma unroll 2
-  for (int k = 0; k < K; k += 2) {
-    const float a = a_on ? ap[k * a_sk] : 0.f;
-    const float b = bp[k * b_sk];
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+  float a0[CH][NA], b0[CH][NB];
+#pragma unroll
+  for (int q = 0; q < CH; ++q) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) a0[q][i] = a_on ? ap[i * a_toff + 2 * q * a_sk] : 0.f;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) b0[q][j] = bp[j * b_toff + 2 * q * b_sk];
+  }
+  for (int k0 = 0; k0 < K; k0 += 2 * CH) {
+    float a1[CH][NA], b1[CH][NB];
+    const int kn = k0 + 2 * CH;
+    if (kn < K) {
+#pragma unroll
+      for (int q = 0; q < CH; ++q) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) a1[q][i] = a_on ? ap[i * a_toff + (kn + 2 * q) * a_sk] : 0.f;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) b1[q][j] = bp[j * b_toff + (kn + 2 * q) * b_sk];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < CH; ++q)
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) c[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q][i], b0[q][j], c[i][j], 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < CH; ++q) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) a0[q][i] = a1[q][i];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) b0[q][j] = b1[q][j];
+    }
   }
 }
 
-__device__ __forceinline__ float act_fn(float v, int act) { return act == 0 ? fmaxf(v, 0.f) : tanhf(v); }
+// ACT 0 relu, 1 tanh (branch-free: 1 - 2 / (e^{2v} + 1) on v_exp_f32 / v_rcp_f32, abs error < 3e-7)
+template <int ACT>
+__device__ __forceinline__ float act_fn(float v) {
+  if (ACT == 0) return fmaxf(v, 0.f);
+  return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * v) + 1.f);
+}
 // derivative expressed through the activation's OUTPUT h (relu: h > 0; tanh: 1 - h^2)
-__device__ __forceinline__ float act_grad(float h, int act) { return act == 0 ? (h > 0.f ? 1.f : 0.f) : 1.f - h * h; }
+template <int ACT>
+__device__ __forceinline__ float act_grad(float h) { return ACT == 0 ? (h > 0.f ? 1.f : 0.f) : 1.f - h * h; }
 
 __device__ __forceinline__ int even_up(int v) { return (v + 1) & ~1; }
 
@@ -94,7 +134,7 @@ __host__ __device__ inline Offsets offsets(const pds_mlp &m) {
   return o;
 }
 
-template <int LOSS>
+template <int LOSS, int ACT>
 __global__ __launch_bounds__(kWaves * 64, 1) void mlp_kernel(const Args a) {
   // ---- LDS images ---------------------------------------------------------------------------------
   __shared__ float W1s[kMaxDim * kLS], W2s[kMaxDim * kLS], W3s[kTS * kLS];  // [out][in], zero padded
@@ -102,7 +142,6 @@ __global__ __launch_bounds__(kWaves * 64, 1) void mlp_kernel(const Args a) {
   __shared__ float tiles[kWaves * (3 * kTS * kLS + kTS * kOS)];
   const pds_mlp &m = a.m;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int act = m.activation;
   for (int i = tid; i < kMaxDim * kLS; i += kWaves * 64) {
     const int n = i / kLS, k = i - n * kLS;
     W1s[i] = (n < m.h1 && k < m.d_in) ? m.w1[n * m.d_in + k] : 0.f;
@@ -127,13 +166,13 @@ __global__ __launch_bounds__(kWaves * 64, 1) void mlp_kernel(const Args a) {
   const int K1 = even_up(m.d_in), K2 = even_up(m.h1), K3 = even_up(m.h2), KO = even_up(m.d_out);
   const int col = lane & 31;
   // weight-gradient accumulators of this wave (over all of its tiles)
-  f32x16 gW1[2][2], gW2[2][2], gW3[2];
+  f32x16 gW1[2][2], gW2[2][2], gW3[1][2];
   float gb1[2] = {0.f, 0.f}, gb2[2] = {0.f, 0.f}, gb3 = 0.f;
   float st_loss = 0.f, st_ratio = 0.f, st_kl = 0.f, st_cnt = 0.f;
   if (LOSS != LOSS_NONE) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      gW3[i] = (f32x16)(0.f);
+      gW3[0][i] = (f32x16)(0.f);
 #pragma unroll
       for (int j = 0; j < 2; ++j) { gW1[i][j] = (f32x16)(0.f); gW2[i][j] = (f32x16)(0.f); }
     }
@@ -141,59 +180,74 @@ __global__ __launch_bounds__(kWaves * 64, 1) void mlp_kernel(const Args a) {
 
   const long long ntiles = (a.B + kTS - 1) / kTS;
   const long long wid = (long long)blockIdx.x * kWaves + wave, nw = (long long)gridDim.x * kWaves;
+  // Input rows travel through registers one tile ahead (and the gather indices two tiles ahead), so
+  // their HBM latency hides behind the matrix work of the current tile: lane k holds feature k of
+  // the tile's 32 rows.
+  const bool kon = lane < m.d_in;
+  float x_mu = 0.f, x_is = 1.f;
+  if (a.mean != nullptr && kon) { x_mu = a.mean[lane]; x_is = 1.0f / (a.stdv[lane] + a.eps); }
+  float xr[kTS];
+  int idx_next = 0;  // lane s < 32: source row of sample s of the tile after next (-1: none)
+  auto load_index = [&](long long tt) -> int {
+    const long long g = tt * kTS + (lane & 31);
+    if (tt >= ntiles || g >= a.B) return -1;
+    return a.index != nullptr ? (int)a.index[g] : (int)g;
+  };
+  auto load_rows = [&](int rows_of_tile) {
+#pragma unroll
+    for (int s = 0; s < kTS; ++s) {
+      const int row = __builtin_amdgcn_readlane(rows_of_tile, s);  // scalar
+      xr[s] = (kon && row >= 0) ? a.x[(long long)row * m.d_in + lane] : x_mu;
+    }
+  };
+  load_rows(load_index(wid));
+  idx_next = load_index(wid + nw);
   for (long long t = wid; t < ntiles; t += nw) {
     const long long s0 = t * kTS;
     // ---- stage the input tile (optionally gathered and standardised) -----------------------------
-    {
-      const bool kon = lane < m.d_in;
-      float mu = 0.f, is = 1.f;
-      if (a.mean != nullptr && kon) { mu = a.mean[lane]; is = 1.0f / (a.stdv[lane] + a.eps); }
-#pragma unroll 8
-      for (int s = 0; s < kTS; ++s) {
-        const long long g = s0 + s;
-        float v = 0.f;
-        if (kon && g < a.B) {
-          const long long row = a.index != nullptr ? a.index[g] : g;
-          v = (a.x[row * m.d_in + lane] - mu) * is;
-        }
-        if (lane < kMaxDim) X[s * kLS + lane] = v;
+#pragma unroll
+    for (int s = 0; s < kTS; ++s) X[s * kLS + lane] = (xr[s] - x_mu) * x_is;
+    load_rows(idx_next);
+    idx_next = load_index(t + 2 * nw);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- forward ---------------------------------------------------------------------------------
+    {  // H1 = act(X W1^T + b1)
+      f32x16 c[1][2] = {{(f32x16)(0.f), (f32x16)(0.f)}};
+      mma_block<1, 2>(c, X, kLS, 1, 0, kTS, W1s, 1, kLS, 32 * kLS, K1, lane);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int n = nt * 32 + col;
+        const float bias = b1s[n];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) H1[row_of(r, lane) * kLS + n] = act_fn<ACT>(c[0][nt][r] + bias);  // n >= h1: act(0) = 0
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- forward ---------------------------------------------------------------------------------
+    {  // H2 = act(H1 W2^T + b2)
+      f32x16 c[1][2] = {{(f32x16)(0.f), (f32x16)(0.f)}};
+      mma_block<1, 2>(c, H1, kLS, 1, 0, kTS, W2s, 1, kLS, 32 * kLS, K2, lane);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {  // H1 = act(X W1^T + b1)
-      f32x16 c = (f32x16)(0.f);
-      mma_tile(c, X, kLS, 1, kTS, W1s + nt * 32 * kLS, 1, kLS, K1, lane);
-      const int n = nt * 32 + col;
-      const float bias = b1s[n];
+      for (int nt = 0; nt < 2; ++nt) {
+        const int n = nt * 32 + col;
+        const float bias = b2s[n];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) H1[row_of(r, lane) * kLS + n] = n < m.h1 ? act_fn(c[r] + bias, act) : 0.f;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {  // H2 = act(H1 W2^T + b2)
-      f32x16 c = (f32x16)(0.f);
-      mma_tile(c, H1, kLS, 1, kTS, W2s + nt * 32 * kLS, 1, kLS, K2, lane);
-      const int n = nt * 32 + col;
-      const float bias = b2s[n];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) H2[row_of(r, lane) * kLS + n] = n < m.h2 ? act_fn(c[r] + bias, act) : 0.f;
+        for (int r = 0; r < 16; ++r) H2[row_of(r, lane) * kLS + n] = act_fn<ACT>(c[0][nt][r] + bias);
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     {  // Y = H2 W3^T + b3
-      f32x16 c = (f32x16)(0.f);
-      mma_tile(c, H2, kLS, 1, kTS, W3s, 1, kLS, K3, lane);
+      f32x16 c[1][1] = {{(f32x16)(0.f)}};
+      mma_block<1, 1>(c, H2, kLS, 1, 0, kTS, W3s, 1, kLS, 0, K3, lane);
       if (col < kMaxOut) {
         const float bias = b3s[col];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Y[row_of(r, lane) * kOS + col] = col < m.d_out ? c[r] + bias : 0.f;
+        for (int r = 0; r < 16; ++r) Y[row_of(r, lane) * kOS + col] = c[0][0][r] + bias;  // col >= d_out: 0
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -247,9 +301,7 @@ __global__ __launch_bounds__(kWaves * 64, 1) void mlp_kernel(const Args a) {
 
     // ---- backward --------------------------------------------------------------------------------
     // dW3 += dY^T H2 (rows = outputs, K = samples); db3 += column sums of dY
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-      mma_tile(gW3[nt], Y, 1, kOS, kMaxOut, H2 + nt * 32, kLS, 1, kTS, lane);
+    mma_block<1, 2>(gW3, Y, 1, kOS, 0, kMaxOut, H2, kLS, 1, 32, kTS, lane);
     if (lane < kMaxOut) {
       float sacc = 0.f;
       for (int s = 0; s < kTS; ++s) sacc += Y[s * kOS + lane];
@@ -257,12 +309,8 @@ __global__ __launch_bounds__(kWaves * 64, 1) void mlp_kernel(const Args a) {
     }
     // dZ2 = (dY W3) * act'(H2), in place over H2
     {
-      f32x16 c[2];
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        c[nt] = (f32x16)(0.f);
-        mma_tile(c[nt], Y, kOS, 1, kTS, W3s + nt * 32, kLS, 1, KO, lane);
-      }
+      f32x16 c[1][2] = {{(f32x16)(0.f), (f32x16)(0.f)}};
+      mma_block<1, 2>(c, Y, kOS, 1, 0, kTS, W3s, kLS, 1, 32, KO, lane);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();  // every dW3 read of H2 is done
 #pragma unroll
@@ -272,7 +320,7 @@ __global__ __launch_bounds__(kWaves * 64, 1) void mlp_kernel(const Args a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float *p = H2 + row_of(r, lane) * kLS + n;
-          const float dz = n < m.h2 ? c[nt][r] * act_grad(*p, act) : 0.f;
+          const float dz = c[0][nt][r] * act_grad<ACT>(*p);  // n >= h2: W3 columns are zero
           *p = dz;
           sacc += dz;
         }
@@ -283,19 +331,11 @@ __global__ __launch_bounds__(kWaves * 64, 1) void mlp_kernel(const Args a) {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // dW2 += dZ2^T H1
-#pragma unroll
-    for (int it = 0; it < 2; ++it)
-#pragma unroll
-      for (int jt = 0; jt < 2; ++jt)
-        mma_tile(gW2[it][jt], H2 + it * 32, 1, kLS, kTS, H1 + jt * 32, kLS, 1, kTS, lane);
+    mma_block<2, 2>(gW2, H2, 1, kLS, 32, kTS, H1, kLS, 1, 32, kTS, lane);
     // dZ1 = (dZ2 W2) * act'(H1), in place over H1
     {
-      f32x16 c[2];
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        c[nt] = (f32x16)(0.f);
-        mma_tile(c[nt], H2, kLS, 1, kTS, W2s + nt * 32, kLS, 1, K3, lane);
-      }
+      f32x16 c[1][2] = {{(f32x16)(0.f), (f32x16)(0.f)}};
+      mma_block<1, 2>(c, H2, kLS, 1, 0, kTS, W2s, kLS, 1, 32, K3, lane);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();  // every dW2 read of H1 is done
 #pragma unroll
@@ -305,7 +345,7 @@ __global__ __launch_bounds__(kWaves * 64, 1) void mlp_kernel(const Args a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float *p = H1 + row_of(r, lane) * kLS + n;
-          const float dz = n < m.h1 ? c[nt][r] * act_grad(*p, act) : 0.f;
+          const float dz = c[0][nt][r] * act_grad<ACT>(*p);
           *p = dz;
           sacc += dz;
         }
@@ -316,11 +356,7 @@ __global__ __launch_bounds__(kWaves * 64, 1) void mlp_kernel(const Args a) {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // dW1 += dZ1^T X
-#pragma unroll
-    for (int it = 0; it < 2; ++it)
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-        mma_tile(gW1[it][kt], H1 + it * 32, 1, kLS, kTS, X + kt * 32, kLS, 1, kTS, lane);
+    mma_block<2, 2>(gW1, H1, 1, kLS, 32, kTS, X, kLS, 1, 32, kTS, lane);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();  // the tile images are restaged by the next iteration
   }
@@ -344,7 +380,7 @@ __global__ __launch_bounds__(kWaves * 64, 1) void mlp_kernel(const Args a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = row_of(r, lane), j = jt * 32 + col;
-      if (i < m.d_out && j < m.h2) out[o.w3 + i * m.h2 + j] = gW3[jt][r];
+      if (i < m.d_out && j < m.h2) out[o.w3 + i * m.h2 + j] = gW3[0][jt][r];
     }
   // bias gradients: lanes l and l + 32 hold the two row halves of the same column
 #pragma unroll
@@ -369,14 +405,35 @@ __global__ __launch_bounds__(kWaves * 64, 1) void mlp_kernel(const Args a) {
 }
 
 // grads[p] = sum over the waves' partials (fixed order) / count; stats likewise
-__global__ __launch_bounds__(256) void reduce_kernel(const float *partials, int pstride, int nwaves, int total,
-                                                     float denom_scale, float *grads, float *stats) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= total + kStats) return;
+// block = 64 outputs x 16 slices of the wave range: 16 x fewer dependent loads per thread
+__global__ __launch_bounds__(1024) void reduce_kernel(const float *partials, int pstride, int nwaves, int total,
+                                                      float denom_scale, float *grads, float *stats) {
+  __shared__ float part[16][64];
+  const int px = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int p = blockIdx.x * 64 + px;
   float s = 0.f;
-  for (int w = 0; w < nwaves; ++w) s += partials[(long long)w * pstride + p];
-  if (p < total) grads[p] = s * denom_scale;
-  else stats[p - total] = s;
+  if (p < total + kStats) {
+    const int per = (nwaves + 15) / 16, w0 = sl * per, w1 = min(nwaves, w0 + per);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int w = w0;
+    for (; w + 3 < w1; w += 4) {
+      s0 += partials[(long long)w * pstride + p];
+      s1 += partials[(long long)(w + 1) * pstride + p];
+      s2 += partials[(long long)(w + 2) * pstride + p];
+      s3 += partials[(long long)(w + 3) * pstride + p];
+    }
+    for (; w < w1; ++w) s0 += partials[(long long)w * pstride + p];
+    s = (s0 + s1) + (s2 + s3);
+  }
+  part[sl][px] = s;
+  __syncthreads();
+  if (sl == 0 && p < total + kStats) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += part[q][px];
+    if (p < total) grads[p] = t * denom_scale;
+    else stats[p - total] = t;
+  }
 }
 
 int check(const pds_mlp *m) {
@@ -412,7 +469,8 @@ extern "C" int pds_mlp_forward(const pds_mlp *m, const float *d_x, const int64_t
   if (check(m) != PDS_OK || !d_x || !d_y || B < 1 || ((d_mean == nullptr) != (d_std == nullptr))) return PDS_EINVAL;
   Args a{};
   a.m = *m; a.x = d_x; a.index = d_index; a.B = B; a.mean = d_mean; a.stdv = d_std; a.eps = eps; a.y = d_y;
-  hipLaunchKernelGGL(mlp_kernel<LOSS_NONE>, dim3(grid_blocks(B)), dim3(kWaves * 64), 0, (hipStream_t)stream, a);
+  if (m->activation == 0) hipLaunchKernelGGL((mlp_kernel<LOSS_NONE, 0>), dim3(grid_blocks(B)), dim3(kWaves * 64), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((mlp_kernel<LOSS_NONE, 1>), dim3(grid_blocks(B)), dim3(kWaves * 64), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? PDS_OK : PDS_EHIP;
 }
 
@@ -422,10 +480,16 @@ static int launch_grad(int loss, Args &a, float *d_grads, float *d_stats, float 
   a.partials = d_workspace;
   a.pstride = o.total + kStats;
   hipStream_t s = (hipStream_t)stream;
-  if (loss == LOSS_PPO) hipLaunchKernelGGL(mlp_kernel<LOSS_PPO>, dim3(blocks), dim3(kWaves * 64), 0, s, a);
-  else hipLaunchKernelGGL(mlp_kernel<LOSS_MSE>, dim3(blocks), dim3(kWaves * 64), 0, s, a);
+  const dim3 g(blocks), b(kWaves * 64);
+  if (loss == LOSS_PPO) {
+    if (a.m.activation == 0) hipLaunchKernelGGL((mlp_kernel<LOSS_PPO, 0>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((mlp_kernel<LOSS_PPO, 1>), g, b, 0, s, a);
+  } else {
+    if (a.m.activation == 0) hipLaunchKernelGGL((mlp_kernel<LOSS_MSE, 0>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((mlp_kernel<LOSS_MSE, 1>), g, b, 0, s, a);
+  }
   const int n = o.total + kStats;
-  hipLaunchKernelGGL(reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const float *)d_workspace, a.pstride,
+  hipLaunchKernelGGL(reduce_kernel, dim3((n + 63) / 64), dim3(1024), 0, s, (const float *)d_workspace, a.pstride,
                      blocks * kWaves, o.total, 1.0f / (float)a.B, d_grads, d_stats);
   return hipGetLastError() == hipSuccess ? PDS_OK : PDS_EHIP;
 }
