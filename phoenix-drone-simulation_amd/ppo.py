@@ -213,7 +213,7 @@ class PPOTrainer:
                  train_v_iterations=5, num_mini_batches=16, target_kl=0.01, use_kl_early_stopping=False,
                  use_linear_lr_decay=True, use_exploration_noise_anneal=True, use_reward_scaling=True,
                  use_standardized_obs=True, use_max_grad_norm=False, max_grad_norm=0.5, ac_kwargs=None,
-                 seed=0):
+                 seed=0, fused=None):
         self.env, self.T, self.N = env, int(rollout_len), env.num_envs
         self.epochs, self.gamma, self.lam, self.clip_ratio = epochs, gamma, lam, clip_ratio
         self.entropy_coef = entropy_coef if use_entropy else 0.0
@@ -232,6 +232,15 @@ class PPOTrainer:
         self.pi_opt = torch.optim.Adam(self.ac.pi.net.parameters(), lr=pi_lr)
         self.vf_opt = torch.optim.Adam(self.ac.v.parameters(), lr=vf_lr)
         self.scheduler = torch.optim.lr_scheduler.LambdaLR(self.pi_opt, lambda e: 1 - e / epochs) if use_linear_lr_decay else None
+        # fused MFMA kernels (csrc/pds_mlp.hip) for network inference in the rollout and for the loss
+        # gradients of the update; the PyTorch op chains below stay as the reference path (fused=False)
+        kw = ac_kwargs or {"pi": {"hidden_sizes": (50, 50), "activation": "relu"},
+                           "val": {"hidden_sizes": (64, 64), "activation": "tanh"}}
+        self.fused = (dev.type == "cuda") if fused is None else bool(fused)
+        if self.fused:
+            from .fused import FusedMLP
+            self.fm_pi = FusedMLP(self.ac.pi.net, kw["pi"]["activation"])
+            self.fm_v = FusedMLP(self.ac.v.net, kw["val"]["activation"])
         T, N, D = self.T, self.N, env.obs_dim
         f = dict(device=dev, dtype=torch.float32)
         self.obs_buf = torch.zeros(T, N, D, **f)
@@ -252,14 +261,21 @@ class PPOTrainer:
         done_ret, done_len, done_cnt = 0.0, 0.0, 0.0
         stats = torch.zeros(3, device=o.device)
         for t in range(self.T):
-            a, v, logp = self.ac.step(o)
+            if self.fused:
+                a, logp = self._fused_step(o, t)
+            else:
+                a, v, logp = self.ac.step(o)
+                self.val_buf[t].copy_(v)
             next_o, r, term, trunc, info = self.env.step(a)
             self.obs_buf[t].copy_(o); self.act_buf[t].copy_(a)
-            self.rew_buf[t].copy_(r); self.val_buf[t].copy_(v); self.logp_buf[t].copy_(logp)
+            self.rew_buf[t].copy_(r); self.logp_buf[t].copy_(logp)
             self.term_buf[t].copy_(term.view(torch.uint8)); self.trunc_buf[t].copy_(trunc.view(torch.uint8))
             # V(final obs) for the TimeLimit bootstrap; evaluated for every row to stay sync-free
             # (rows of envs that did not finish are ignored by pds_gae)
-            self.fval_buf[t].copy_(self.ac.value(info["final_obs"]))
+            if self.fused:
+                self._fused_value(info["final_obs"], out=self.fval_buf[t])
+            else:
+                self.fval_buf[t].copy_(self.ac.value(info["final_obs"]))
             self.ep_ret += r
             self.ep_len += 1
             done = term | trunc
@@ -268,8 +284,34 @@ class PPOTrainer:
             self.ep_len = torch.where(done, torch.zeros_like(self.ep_len), self.ep_len)
             o = next_o
         self.obs = o
-        self.last_val = self.ac.value(o)
+        self.last_val = self._fused_value(o) if self.fused else self.ac.value(o)
         return stats
+
+    def _oms(self):
+        oms = self.ac.obs_oms
+        return (oms.mean, oms.std, oms.eps) if oms is not None else (None, None, 0.0)
+
+    @torch.no_grad()
+    def _fused_value(self, obs, out=None):
+        mean, std, eps = self._oms()
+        y = self.fm_v.forward(obs, mean=mean, std=std, eps=eps, out=None if out is None else out.view(-1, 1))
+        return y.view(-1)
+
+    @torch.no_grad()
+    def _fused_step(self, obs, t):
+        """ActorCritic.step (algs/core.py:370-393) on the fused kernels: V(o) -> val_buf[t]; action
+        a = mu + sigma * z with z ~ N(0, 1) and its log-probability -sum(0.5 z^2 + log sigma + 0.5 log 2 pi)."""
+        mean, std, eps = self._oms()
+        self._fused_value(obs, out=self.val_buf[t])
+        mu = self.fm_pi.forward(obs, mean=mean, std=std, eps=eps)
+        log_std = self.ac.pi.log_std
+        if not self.ac.training:
+            z = torch.zeros_like(mu)
+        else:
+            z = torch.randn_like(mu)
+        a = torch.addcmul(mu, z, torch.exp(log_std))
+        logp = (-0.5 * z * z - log_std - 0.5 * math.log(2 * math.pi)).sum(-1)
+        return a, logp
 
     def update(self):
         """algs/iwpg/iwpg.py:398-485."""
@@ -286,6 +328,8 @@ class PPOTrainer:
         # ---- value net: train_v_iterations x num_mini_batches shuffled mini-batches
         B = T * N
         mbs = B // self.num_mini_batches
+        if self.fused:
+            return self._fused_update(data, raw_obs, disc_ret, B, mbs)
         loss_v_before = value_loss(ac, data["obs"], data["target_v"]).item()
         for _ in range(self.train_v_iterations):
             perm = torch.randperm(B, device=obs.device)
@@ -324,6 +368,60 @@ class PPOTrainer:
             ac.ret_oms.update(disc_ret.reshape(-1))
         return dict(loss_pi=float(loss_pi_before), loss_v=loss_v_before, stop_iter=stop_iter,
                     entropy=float(pi_info["ent"].detach()), ratio=float(pi_info["ratio"].detach()))
+
+    def _fused_update(self, data, raw_obs, disc_ret, B, mbs):
+        """The same update with the loss gradients from csrc/pds_mlp.hip: one fused pass over the batch
+        per iteration writes d loss / d theta into the parameters' .grad (a flat buffer, so the
+        gradient averaging over ranks is one RCCL all-reduce of it); Adam stays torch's."""
+        ac = self.ac
+        world = dist.get_world_size() if dist.is_initialized() else 1
+
+        def average(fm):
+            if world > 1:
+                dist.all_reduce(fm.flat_grad)
+                fm.flat_grad /= world
+
+        obs, target_v = data["obs"].contiguous(), data["target_v"].contiguous()
+        with torch.no_grad():
+            loss_v_before = ((self.fm_v.forward(obs).view(-1) - target_v) ** 2).mean()
+        for _ in range(self.train_v_iterations):
+            perm = torch.randperm(B, device=obs.device)
+            for s in range(0, mbs * self.num_mini_batches, mbs):
+                self.fm_v.value_grad(obs, target_v, index=perm[s:s + mbs])
+                average(self.fm_v)
+                self.vf_opt.step()
+        act, adv, logp_old = data["act"].contiguous(), data["adv"].contiguous(), data["log_p"].contiguous()
+        log_std = ac.pi.log_std
+        # entropy of Normal(., sigma): sum(0.5 + 0.5 log 2 pi + log sigma), independent of the network
+        ent = float((0.5 + 0.5 * math.log(2 * math.pi) + log_std).sum())
+        if self.use_kl_early_stopping:
+            with torch.no_grad():
+                mu_old = self.fm_pi.forward(obs)
+        first = None
+        stop_iter = self.train_pi_iterations
+        for i in range(self.train_pi_iterations):
+            stats = self.fm_pi.ppo_grad(obs, act, adv, logp_old, log_std, self.clip_ratio)
+            if first is None:
+                first = stats.clone()
+            if self.use_max_grad_norm:
+                torch.nn.utils.clip_grad_norm_(ac.pi.net.parameters(), self.max_grad_norm)
+            average(self.fm_pi)
+            self.pi_opt.step()
+            if self.use_kl_early_stopping:
+                with torch.no_grad():  # KL(N(mu_old, s) || N(mu_new, s)) = sum (mu_old - mu_new)^2 / (2 s^2)
+                    kl = (((mu_old - self.fm_pi.forward(obs)) ** 2) / (2 * torch.exp(2 * log_std))).sum(-1).mean()
+                    if world > 1:
+                        dist.all_reduce(kl); kl /= world
+                if kl.item() > self.target_kl:
+                    stop_iter = i + 1
+                    break
+        if self.use_standardized_obs:
+            ac.obs_oms.update(raw_obs)
+        if self.use_reward_scaling:
+            ac.ret_oms.update(disc_ret.reshape(-1))
+        f = first.tolist()
+        return dict(loss_pi=f[0] / f[3] - self.entropy_coef * ent, loss_v=float(loss_v_before), stop_iter=stop_iter,
+                    entropy=ent, ratio=f[1] / f[3])
 
     def learn_one_epoch(self):
         t0 = time.time()
