@@ -249,6 +249,25 @@ int pds_ppo_policy_grad(const pds_mlp *m, const float *d_x, const float *d_act, 
 int pds_value_grad(const pds_mlp *m, const float *d_x, const int64_t *d_index, const float *d_target, int64_t B,
                    float *d_grads, float *d_stats, float *d_workspace, void *stream);
 
+/* a[n, d_out] = mu + exp(log_std) z with z ~ N(0, 1) (Philox4x32-10, key = seed, counter = (global
+ * sample id = id_base + row, call)), logp[n] = Normal(mu, sigma).log_prob(a).sum(-1); deterministic != 0
+ * gives a = mu (evaluation mode).  dist.sample() + log_prob of ActorCritic.step, algs/core.py:370-393. */
+int pds_gaussian_sample(const float *d_mu, const float *d_log_std, int64_t n, int d_out, uint64_t seed, uint64_t call,
+                        uint64_t id_base, int deterministic, float *d_act, float *d_logp, void *stream);
+
+/* One rollout step's bookkeeping (buf.store + episode statistics of IWPGAlgorithm.roll_out,
+ * algs/iwpg/iwpg.py:350-385): copies reward / terminated / truncated [n] into their [T, N] slices, adds
+ * the reward to the running episode return and 1 to the length, and for finished envs adds
+ * (return, length, 1) to d_stats[0..2] and zeroes their running values. */
+int pds_rollout_record(const float *d_rew, const uint8_t *d_term, const uint8_t *d_trunc, int64_t n, float *d_rew_buf,
+                       uint8_t *d_term_buf, uint8_t *d_trunc_buf, float *d_ep_ret, float *d_ep_len, float *d_stats,
+                       void *stream);
+
+/* torch.optim.Adam.step (no weight decay / amsgrad) for the six tensors of `m` from their flat gradient;
+ * d_exp_avg / d_exp_avg_sq [param_count] are the optimiser state, step counts from 1. */
+int pds_adam_step(const pds_mlp *m, const float *d_grads, float *d_exp_avg, float *d_exp_avg_sq, int64_t step, float lr,
+                  float beta1, float beta2, float eps, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

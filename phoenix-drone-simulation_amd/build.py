@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 _UNITS = ["pds_api.hip", "pds_task_hover.hip", "pds_task_circle.hip", "pds_task_takeoff.hip", "pds_gae.hip",
-          "pds_mlp.hip"]
+          "pds_mlp.hip", "pds_train.hip"]
 _HEADERS = ["pds_device.h", "pds_types.h", "pds_reset.h", "pds_step.h"]
 _DEPS = [os.path.join(_CSRC, f) for f in _UNITS + _HEADERS] + [os.path.join(_HERE, "..", "include", "pds.h")]
 _LIB = os.path.join(_HERE, "libpds_hip.so")
@@ -55,7 +55,7 @@ def build_library(force=False, verbose=False, extra_flags=(), out=None):
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
 
-    with concurrent.futures.ThreadPoolExecutor(max_workers=6) as ex:
+    with concurrent.futures.ThreadPoolExecutor(max_workers=7) as ex:
         list(ex.map(compile_unit, zip(_UNITS, objs)))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out + ".tmp"] + objs
     if verbose:

@@ -98,6 +98,7 @@ class DroneVecEnv:
         cfg = native.default_config(_TASKS[self.task])
         cfg.num_envs = int(num_envs)
         cfg.env_id_base = int(env_id_base)
+        self.env_id_base = int(env_id_base)
         cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         cfg.device = self.device.index
         cfg.use_motor_dynamics = int(bool(use_motor_dynamics))

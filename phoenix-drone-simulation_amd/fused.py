@@ -83,6 +83,20 @@ class FusedMLP:
             raise RuntimeError(f"pds_ppo_policy_grad -> {rc}")
         return self.stats
 
+    def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8):
+        """torch.optim.Adam.step for this network's parameters from the flat gradient, in one launch."""
+        if not hasattr(self, "exp_avg"):
+            self.exp_avg = torch.zeros_like(self.flat_grad)
+            self.exp_avg_sq = torch.zeros_like(self.flat_grad)
+            self.adam_steps = 0
+        self.adam_steps += 1
+        self._bind()
+        rc = self.lib.pds_adam_step(C.byref(self.m), _ptr(self.flat_grad), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
+                                    self.adam_steps, float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                    self._stream())
+        if rc != native.OK:
+            raise RuntimeError(f"pds_adam_step -> {rc}")
+
     def value_grad(self, x, target, index=None):
         """Fills .grad with d mse(net(x[index]), target[index]) / d theta; stats[0] = sum of squared errors."""
         self._bind()
@@ -92,3 +106,21 @@ class FusedMLP:
         if rc != native.OK:
             raise RuntimeError(f"pds_value_grad -> {rc}")
         return self.stats
+
+
+def gaussian_sample(mu, log_std, act_out, logp_out, seed, call, id_base=0, deterministic=False):
+    """act_out[n, d] = mu + exp(log_std) * z, logp_out[n] = log N(act | mu, sigma) summed over d."""
+    rc = native.load().pds_gaussian_sample(_ptr(mu), _ptr(log_std), mu.shape[0], mu.shape[1], int(seed), int(call),
+                                           int(id_base), int(bool(deterministic)), _ptr(act_out), _ptr(logp_out),
+                                           FusedMLP._stream())
+    if rc != native.OK:
+        raise RuntimeError(f"pds_gaussian_sample -> {rc}")
+
+
+def rollout_record(rew, term, trunc, rew_buf_t, term_buf_t, trunc_buf_t, ep_ret, ep_len, stats):
+    """One step of the rollout bookkeeping (see include/pds.h pds_rollout_record)."""
+    rc = native.load().pds_rollout_record(_ptr(rew), _ptr(term), _ptr(trunc), rew.shape[0], _ptr(rew_buf_t),
+                                          _ptr(term_buf_t), _ptr(trunc_buf_t), _ptr(ep_ret), _ptr(ep_len), _ptr(stats),
+                                          FusedMLP._stream())
+    if rc != native.OK:
+        raise RuntimeError(f"pds_rollout_record -> {rc}")

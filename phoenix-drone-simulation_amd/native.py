@@ -33,7 +33,7 @@ EXPORTS = ["pds_version", "pds_default_config", "pds_create", "pds_destroy", "pd
            "pds_field_width",
            "pds_get_state", "pds_set_state", "pds_tick", "pds_bytes_per_env_step", "pds_last_error", "pds_gae",
            "pds_mlp_param_count", "pds_mlp_workspace_floats", "pds_mlp_forward", "pds_ppo_policy_grad",
-           "pds_value_grad"]
+           "pds_value_grad", "pds_gaussian_sample", "pds_rollout_record", "pds_adam_step"]
 
 
 class Mlp(C.Structure):
@@ -105,6 +105,10 @@ def load():
     lib.pds_mlp_forward.argtypes = [mp, vp, vp, i64, vp, vp, C.c_float, vp, vp]
     lib.pds_ppo_policy_grad.argtypes = [mp, vp, vp, vp, vp, vp, i64, C.c_float, vp, vp, vp, vp]
     lib.pds_value_grad.argtypes = [mp, vp, vp, vp, i64, vp, vp, vp, vp]
+    u64 = C.c_uint64
+    lib.pds_gaussian_sample.argtypes = [vp, vp, i64, i32, u64, u64, u64, i32, vp, vp, vp]
+    lib.pds_rollout_record.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp]
+    lib.pds_adam_step.argtypes = [mp, vp, vp, vp, i64, C.c_float, C.c_float, C.c_float, C.c_float, vp]
     _lib = lib
     return lib
 

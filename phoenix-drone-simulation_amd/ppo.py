@@ -25,6 +25,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from . import native
+from .fused import gaussian_sample, rollout_record
 
 
 class OnlineMeanStd(nn.Module):
@@ -237,6 +238,7 @@ class PPOTrainer:
         kw = ac_kwargs or {"pi": {"hidden_sizes": (50, 50), "activation": "relu"},
                            "val": {"hidden_sizes": (64, 64), "activation": "tanh"}}
         self.fused = (dev.type == "cuda") if fused is None else bool(fused)
+        self._sample_seed, self._sample_calls = (seed + 10000 * rank) & 0xFFFFFFFFFFFFFFFF, 0
         if self.fused:
             from .fused import FusedMLP
             self.fm_pi = FusedMLP(self.ac.pi.net, kw["pi"]["activation"])
@@ -267,15 +269,19 @@ class PPOTrainer:
                 a, v, logp = self.ac.step(o)
                 self.val_buf[t].copy_(v)
             next_o, r, term, trunc, info = self.env.step(a)
-            self.obs_buf[t].copy_(o); self.act_buf[t].copy_(a)
-            self.rew_buf[t].copy_(r); self.logp_buf[t].copy_(logp)
-            self.term_buf[t].copy_(term.view(torch.uint8)); self.trunc_buf[t].copy_(trunc.view(torch.uint8))
+            self.obs_buf[t].copy_(o)
             # V(final obs) for the TimeLimit bootstrap; evaluated for every row to stay sync-free
             # (rows of envs that did not finish are ignored by pds_gae)
-            if self.fused:
+            if self.fused:  # action / log-prob were sampled straight into their buffer rows
                 self._fused_value(info["final_obs"], out=self.fval_buf[t])
-            else:
-                self.fval_buf[t].copy_(self.ac.value(info["final_obs"]))
+                rollout_record(r, term.view(torch.uint8), trunc.view(torch.uint8), self.rew_buf[t], self.term_buf[t],
+                               self.trunc_buf[t], self.ep_ret, self.ep_len, stats)
+                o = next_o
+                continue
+            self.act_buf[t].copy_(a)
+            self.rew_buf[t].copy_(r); self.logp_buf[t].copy_(logp)
+            self.term_buf[t].copy_(term.view(torch.uint8)); self.trunc_buf[t].copy_(trunc.view(torch.uint8))
+            self.fval_buf[t].copy_(self.ac.value(info["final_obs"]))
             self.ep_ret += r
             self.ep_len += 1
             done = term | trunc
@@ -304,14 +310,10 @@ class PPOTrainer:
         mean, std, eps = self._oms()
         self._fused_value(obs, out=self.val_buf[t])
         mu = self.fm_pi.forward(obs, mean=mean, std=std, eps=eps)
-        log_std = self.ac.pi.log_std
-        if not self.ac.training:
-            z = torch.zeros_like(mu)
-        else:
-            z = torch.randn_like(mu)
-        a = torch.addcmul(mu, z, torch.exp(log_std))
-        logp = (-0.5 * z * z - log_std - 0.5 * math.log(2 * math.pi)).sum(-1)
-        return a, logp
+        self._sample_calls += 1
+        gaussian_sample(mu, self.ac.pi.log_std, self.act_buf[t], self.logp_buf[t], self._sample_seed, self._sample_calls,
+                        id_base=self.env.env_id_base, deterministic=not self.ac.training)
+        return self.act_buf[t], self.logp_buf[t]
 
     def update(self):
         """algs/iwpg/iwpg.py:398-485."""
@@ -389,7 +391,7 @@ class PPOTrainer:
             for s in range(0, mbs * self.num_mini_batches, mbs):
                 self.fm_v.value_grad(obs, target_v, index=perm[s:s + mbs])
                 average(self.fm_v)
-                self.vf_opt.step()
+                self.fm_v.adam_step(self.vf_opt.param_groups[0]["lr"])
         act, adv, logp_old = data["act"].contiguous(), data["adv"].contiguous(), data["log_p"].contiguous()
         log_std = ac.pi.log_std
         # entropy of Normal(., sigma): sum(0.5 + 0.5 log 2 pi + log sigma), independent of the network
@@ -406,7 +408,7 @@ class PPOTrainer:
             if self.use_max_grad_norm:
                 torch.nn.utils.clip_grad_norm_(ac.pi.net.parameters(), self.max_grad_norm)
             average(self.fm_pi)
-            self.pi_opt.step()
+            self.fm_pi.adam_step(self.pi_opt.param_groups[0]["lr"])  # lr follows the LambdaLR schedule
             if self.use_kl_early_stopping:
                 with torch.no_grad():  # KL(N(mu_old, s) || N(mu_new, s)) = sum (mu_old - mu_new)^2 / (2 s^2)
                     kl = (((mu_old - self.fm_pi.forward(obs)) ** 2) / (2 * torch.exp(2 * log_std))).sum(-1).mean()

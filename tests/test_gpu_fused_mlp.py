@@ -99,3 +99,66 @@ def test_gradients_are_deterministic_and_size_limits_are_checked():
     assert torch.equal(g1, g2)
     with pytest.raises((ValueError, NotImplementedError)):
         FusedMLP(_net(70, 50, 50, 4, "relu", 0), "relu")
+
+
+def test_adam_step_matches_torch_adam():
+    from phoenix_drone_simulation_amd.fused import FusedMLP
+    net = _net(34, 50, 50, 4, "relu", 7)
+    ref = _net(34, 50, 50, 4, "relu", 7)
+    fm = FusedMLP(net, "relu")
+    opt = torch.optim.Adam(ref.parameters(), lr=3e-4)
+    g = torch.Generator(device="cuda"); g.manual_seed(0)
+    for k in range(25):
+        flat = torch.randn(fm.flat_grad.numel(), device="cuda", generator=g) * (0.1 if k % 3 else 10.0)
+        fm.flat_grad.copy_(flat)
+        off = 0
+        for p in ref.parameters():
+            p.grad = flat[off:off + p.numel()].view_as(p).clone(); off += p.numel()
+        lr = 3e-4 * (1 - k / 50)
+        for gr in opt.param_groups:
+            gr["lr"] = lr
+        opt.step(); fm.adam_step(lr)
+    for a, b in zip(net.parameters(), ref.parameters()):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), float((a - b).abs().max())
+
+
+def test_gaussian_sample_and_rollout_record():
+    from phoenix_drone_simulation_amd.fused import gaussian_sample, rollout_record
+    n, d = 200000, 4
+    mu = torch.randn(n, d, device="cuda")
+    log_std = torch.tensor([-1.0, -0.5, 0.0, 0.3], device="cuda")
+    a, lp = torch.empty(n, d, device="cuda"), torch.empty(n, device="cuda")
+    gaussian_sample(mu, log_std, a, lp, seed=3, call=1)
+    z = (a - mu) / torch.exp(log_std)
+    assert abs(float(z.mean())) < 0.01 and abs(float(z.std()) - 1) < 0.01
+    assert abs(float((z ** 3).mean())) < 0.03 and abs(float((z ** 4).mean()) - 3) < 0.06
+    c = torch.corrcoef(z.T)
+    assert float((c - torch.eye(d, device="cuda")).abs().max()) < 0.01
+    want = torch.distributions.Normal(mu, torch.exp(log_std)).log_prob(a).sum(-1)
+    assert torch.allclose(lp, want, atol=1e-4)
+    a2, lp2 = torch.empty_like(a), torch.empty_like(lp)
+    gaussian_sample(mu, log_std, a2, lp2, seed=3, call=1)
+    assert torch.equal(a, a2)                         # counter-based: reproducible
+    gaussian_sample(mu, log_std, a2, lp2, seed=3, call=2)
+    assert not torch.equal(a, a2)
+    gaussian_sample(mu[100:], log_std, a2[100:], lp2[100:], seed=3, call=1, id_base=100)
+    assert torch.equal(a[100:], a2[100:])             # keyed by the global sample id (sharding)
+    gaussian_sample(mu, log_std, a2, lp2, seed=3, call=5, deterministic=True)
+    assert torch.equal(a2, mu)
+    # bookkeeping
+    T = 3
+    rew_buf = torch.zeros(T, n, device="cuda"); term_buf = torch.zeros(T, n, dtype=torch.uint8, device="cuda")
+    trunc_buf = torch.zeros_like(term_buf)
+    ep_ret, ep_len, stats = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda"), torch.zeros(3, device="cuda")
+    er, el, st = ep_ret.clone(), ep_len.clone(), torch.zeros(3, device="cuda", dtype=torch.float64)
+    for t in range(T):
+        r = torch.randn(n, device="cuda")
+        te = (torch.rand(n, device="cuda") < 0.1).to(torch.uint8); tr = (torch.rand(n, device="cuda") < 0.05).to(torch.uint8)
+        rollout_record(r, te, tr, rew_buf[t], term_buf[t], trunc_buf[t], ep_ret, ep_len, stats)
+        er += r; el += 1
+        done = (te | tr).bool()
+        st += torch.stack([(er * done).sum().double(), (el * done).sum().double(), done.sum().double()])
+        er = torch.where(done, torch.zeros_like(er), er); el = torch.where(done, torch.zeros_like(el), el)
+        assert torch.equal(rew_buf[t], r) and torch.equal(term_buf[t], te) and torch.equal(trunc_buf[t], tr)
+    assert torch.allclose(ep_ret, er) and torch.equal(ep_len, el)
+    assert torch.allclose(stats.double(), st, rtol=1e-4, atol=1e-2)
