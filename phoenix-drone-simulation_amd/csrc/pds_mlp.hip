@@ -7,18 +7,22 @@
 //   ProximalPolicyOptimizationAlgorithm.compute_loss_pi     algs/ppo/ppo.py:22-40
 //   IWPGAlgorithm.compute_loss_v / update_value_net         algs/iwpg/iwpg.py:272-275, 487-522
 // (80 full-batch policy iterations + 5 x 16 value mini-batches per epoch, algs/ppo/defaults.py:6-19):
-// autograd materialises ~30 [B, 50] tensors per iteration in HBM; here a wave keeps a 32-sample
-// tile in LDS, runs every GEMM of forward and backward on v_mfma_f32_32x32x2_f32 (exact f32: a
+// autograd materialises ~30 [B, 50] tensors per iteration in HBM; here a wave keeps a 16-sample
+// tile in LDS, runs every GEMM of forward and backward on v_mfma_f32_16x16x4_f32 (exact f32: a
 // k-ordered fmaf chain, so results match an fp32 reference to rounding), accumulates the weight
 // gradients in registers across its tiles and writes one partial per wave; a second tiny kernel
 // sums the partials in a fixed order (deterministic, no atomics).
 //
+// A wave's GEMM -> epilogue -> GEMM phases depend on each other, so one wave cannot keep the matrix
+// core and the vector ALU busy at once: the block runs TWO waves per SIMD (8 waves, 16-sample tiles,
+// <= 256 registers each) and the hardware interleaves one wave's epilogues with the other's MFMAs.
+//
 // GEMM operands always come from LDS in natural [row][col] images with an odd row stride (65), so
-// the A map (lane l: A[l&31][l>>5]) and the B map (B[l>>5][l&31]) of the instruction read either
+// the A map (lane l: A[l&15][l>>4]) and the B map (B[l>>4][l&15]) of the instruction read either
 // consecutive words or a conflict-free odd-stride column, whichever way a matrix is walked:
 //   forward      Z1 = X W1^T, Z2 = H1 W2^T, Y = H2 W3^T            (M = samples)
 //   backward     dH2 = dY W3, dH1 = dZ2 W2                          (M = samples)
-//   weight grads dW3 = dY^T H2, dW2 = dZ2^T H1, dW1 = dZ1^T X       (K = the tile's 32 samples)
+//   weight grads dW3 = dY^T H2, dW2 = dZ2^T H1, dW1 = dZ1^T X       (K = the tile's 16 samples)
 // Bound: MFMA f32 (157 TFLOP/s dense peak on MI355X = the f32 vector rate; MI355X_MICROARCH.md).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -27,15 +31,18 @@
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kTS = 32;            // samples per wave tile (= M of one MFMA tile)
+constexpr int kTS = 16;            // samples per wave tile (= M of one MFMA tile)
+constexpr int kTW = 16;            // tile width
+constexpr int kNT = 4;             // 16-wide tiles per 64-wide dimension
 constexpr int kLS = 65;            // LDS row stride of every [rows][<= 64] image (odd: conflict-free both ways)
-constexpr int kOS = 9;             // row stride of the [32][<= 8] output / output-gradient tile
+constexpr int kOS = 9;             // row stride of the [16][<= 8] output / output-gradient tile
 constexpr int kMaxDim = 64;        // d_in, h1, h2 <= 64
 constexpr int kMaxOut = 8;         // d_out <= 8
-constexpr int kWaves = 4;          // waves per block, one per SIMD; 1 block per CU (LDS-bound)
+constexpr int kWaves = 8;          // waves per block, two per SIMD; 1 block per CU (LDS-bound)
 constexpr int kStats = 4;          // loss sum, ratio sum, kl sum, sample count
+constexpr int kTileFloats = 3 * kTS * kLS + kTS * kOS;
 
 enum { LOSS_NONE = 0, LOSS_PPO = 1, LOSS_MSE = 2 };
 
@@ -54,19 +61,21 @@ struct Args {
   int pstride;
 };
 
-__device__ __forceinline__ int row_of(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+// C/D map of v_mfma_f32_16x16x4_f32: lane l holds column l & 15 of rows 4 * (l >> 4) + r, r = 0..3
+__device__ __forceinline__ int row_of(int r, int lane) { return (lane >> 4) * 4 + r; }
 
-// c[i][j] (32x32 each) += A_i[32 x K] * B_j[K x 32] for NA row tiles of A and NB column tiles of B.
-// Element (m, k) of A tile i at A[i * a_toff + m * a_sm + k * a_sk], (k, n) of B tile j at
-// B[j * b_toff + k * b_sk + n * b_sn]; lanes whose row index is >= a_rows feed zeros (short
-// matrices).  K is walked in chunks of 4 MFMA k-steps (8 k values): the operands of the next chunk
-// are read from LDS while the matrix core works on the current one.  The walk may run up to 7 k
-// values past K: every image is zero padded to 64 columns / rows, so that adds zeros.
+// c[i][j] (16x16 each) += A_i[16 x K] * B_j[K x 16] for the first na / nb of NA row tiles of A and NB
+// column tiles of B.  Element (m, k) of A tile i at A[i * a_toff + m * a_sm + k * a_sk], (k, n) of
+// B tile j at B[j * b_toff + k * b_sk + n * b_sn]; lanes whose row index is >= a_rows feed zeros
+// (short matrices).  K is walked in chunks of 2 MFMA k-steps (8 k values): the operands of the
+// next chunk are read from LDS while the matrix core works on the current one.  The walk may run up
+// to 7 k values past K: every image is zero padded to 64 columns / rows, so that adds zeros.
 template <int NA, int NB>
-__device__ __forceinline__ void mma_block(f32x16 (&c)[NA][NB], const float *A, int a_sm, int a_sk, int a_toff,
-                                          int a_rows, const float *B, int b_sk, int b_sn, int b_toff, int K, int lane) {
-  constexpr int CH = 4;
-  const int r = lane & 31, h = lane >> 5;
+__device__ __forceinline__ void mma_block(f32x4 (&c)[NA][NB], int na, int nb, const float *A, int a_sm, int a_sk,
+                                          int a_toff, int a_rows, const float *B, int b_sk, int b_sn, int b_toff,
+                                          int K, int lane) {
+  constexpr int CH = 2;
+  const int r = lane & 15, h = lane >> 4;
   const float *ap = A + r * a_sm + h * a_sk;
   const float *bp = B + h * b_sk + r * b_sn;
   const bool a_on = r < a_rows;
@@ -74,20 +83,20 @@ __device__ __forceinline__ void mma_block(f32x16 (&c)[NA][NB], const float *A, i
 #pragma unroll
   for (int q = 0; q < CH; ++q) {
 #pragma unroll
-    for (int i = 0; i < NA; ++i) a0[q][i] = a_on ? ap[i * a_toff + 2 * q * a_sk] : 0.f;
+    for (int i = 0; i < NA; ++i) a0[q][i] = a_on ? ap[i * a_toff + 4 * q * a_sk] : 0.f;
 #pragma unroll
-    for (int j = 0; j < NB; ++j) b0[q][j] = bp[j * b_toff + 2 * q * b_sk];
+    for (int j = 0; j < NB; ++j) b0[q][j] = bp[j * b_toff + 4 * q * b_sk];
   }
-  for (int k0 = 0; k0 < K; k0 += 2 * CH) {
+  for (int k0 = 0; k0 < K; k0 += 4 * CH) {
     float a1[CH][NA], b1[CH][NB];
-    const int kn = k0 + 2 * CH;
+    const int kn = k0 + 4 * CH;
     if (kn < K) {
 #pragma unroll
       for (int q = 0; q < CH; ++q) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) a1[q][i] = a_on ? ap[i * a_toff + (kn + 2 * q) * a_sk] : 0.f;
+        for (int i = 0; i < NA; ++i) a1[q][i] = a_on ? ap[i * a_toff + (kn + 4 * q) * a_sk] : 0.f;
 #pragma unroll
-        for (int j = 0; j < NB; ++j) b1[q][j] = bp[j * b_toff + (kn + 2 * q) * b_sk];
+        for (int j = 0; j < NB; ++j) b1[q][j] = bp[j * b_toff + (kn + 4 * q) * b_sk];
       }
     }
 #pragma unroll
@@ -95,7 +104,8 @@ __device__ __forceinline__ void mma_block(f32x16 (&c)[NA][NB], const float *A, i
 #pragma unroll
       for (int i = 0; i < NA; ++i)
 #pragma unroll
-        for (int j = 0; j < NB; ++j) c[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q][i], b0[q][j], c[i][j], 0, 0, 0);
+        for (int j = 0; j < NB; ++j)
+          c[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q][i], b0[q][j], c[i][j], 0, 0, 0);
 #pragma unroll
     for (int q = 0; q < CH; ++q) {
 #pragma unroll
@@ -116,7 +126,7 @@ __device__ __forceinline__ float act_fn(float v) {
 template <int ACT>
 __device__ __forceinline__ float act_grad(float h) { return ACT == 0 ? (h > 0.f ? 1.f : 0.f) : 1.f - h * h; }
 
-__device__ __forceinline__ int even_up(int v) { return (v + 1) & ~1; }
+__device__ __forceinline__ int tiles_of(int v) { return (v + kTW - 1) / kTW; }
 
 // flat parameter layout == torch's nn.Sequential order: W1 [h1][d_in], b1, W2 [h2][h1], b2, W3 [d_out][h2], b3
 struct Offsets {
@@ -134,19 +144,26 @@ __host__ __device__ inline Offsets offsets(const pds_mlp &m) {
   return o;
 }
 
+#define PDS_WAVE_SYNC()                                          \
+  do {                                                           \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       \
+    __builtin_amdgcn_wave_barrier();                             \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       \
+  } while (0)
+
 template <int LOSS, int ACT>
-__global__ __launch_bounds__(kWaves * 64, 1) void mlp_kernel(const Args a) {
+__global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
   // ---- LDS images ---------------------------------------------------------------------------------
-  __shared__ float W1s[kMaxDim * kLS], W2s[kMaxDim * kLS], W3s[kTS * kLS];  // [out][in], zero padded
+  __shared__ float W1s[kMaxDim * kLS], W2s[kMaxDim * kLS], W3s[kTW * kLS];  // [out][in], zero padded
   __shared__ float b1s[kMaxDim], b2s[kMaxDim], b3s[kMaxOut], isg[kMaxOut], lsg[kMaxOut];
-  __shared__ float tiles[kWaves * (3 * kTS * kLS + kTS * kOS)];
+  __shared__ float tiles[kWaves * kTileFloats];
   const pds_mlp &m = a.m;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < kMaxDim * kLS; i += kWaves * 64) {
     const int n = i / kLS, k = i - n * kLS;
     W1s[i] = (n < m.h1 && k < m.d_in) ? m.w1[n * m.d_in + k] : 0.f;
     W2s[i] = (n < m.h2 && k < m.h1) ? m.w2[n * m.h1 + k] : 0.f;
-    if (i < kTS * kLS) W3s[i] = (n < m.d_out && k < m.h2) ? m.w3[n * m.h2 + k] : 0.f;
+    if (i < kTW * kLS) W3s[i] = (n < m.d_out && k < m.h2) ? m.w3[n * m.h2 + k] : 0.f;
   }
   if (tid < kMaxDim) {
     b1s[tid] = tid < m.h1 ? m.b1[tid] : 0.f;
@@ -158,38 +175,37 @@ __global__ __launch_bounds__(kWaves * 64, 1) void mlp_kernel(const Args a) {
     lsg[tid] = ls;
     isg[tid] = expf(-ls);  // 1 / sigma
   }
-  float *X = tiles + wave * (3 * kTS * kLS + kTS * kOS);
+  float *X = tiles + wave * kTileFloats;
   float *H1 = X + kTS * kLS, *H2 = H1 + kTS * kLS, *Y = H2 + kTS * kLS;
-  for (int i = lane; i < 3 * kTS * kLS + kTS * kOS; i += 64) X[i] = 0.f;  // pad columns stay zero
+  for (int i = lane; i < kTileFloats; i += 64) X[i] = 0.f;  // pad columns stay zero
   __syncthreads();
 
-  const int K1 = even_up(m.d_in), K2 = even_up(m.h1), K3 = even_up(m.h2), KO = even_up(m.d_out);
-  const int col = lane & 31;
-  // weight-gradient accumulators of this wave (over all of its tiles)
-  f32x16 gW1[2][2], gW2[2][2], gW3[1][2];
-  float gb1[2] = {0.f, 0.f}, gb2[2] = {0.f, 0.f}, gb3 = 0.f;
+  const int n_in = tiles_of(m.d_in), n_h1 = tiles_of(m.h1), n_h2 = tiles_of(m.h2);
+  const int col = lane & 15;
+  // weight-gradient accumulators of this wave (over all of its tiles); the column tiles in two halves
+  f32x4 gW1a[kNT][2], gW1b[kNT][2], gW2a[kNT][2], gW2b[kNT][2], gW3[1][kNT];
+  float gb1[kNT], gb2[kNT], gb3 = 0.f;
   float st_loss = 0.f, st_ratio = 0.f, st_kl = 0.f, st_cnt = 0.f;
-  if (LOSS != LOSS_NONE) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      gW3[0][i] = (f32x16)(0.f);
+  for (int i = 0; i < kNT; ++i) {
+    gb1[i] = 0.f; gb2[i] = 0.f;
+    gW3[0][i] = (f32x4)(0.f);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) { gW1[i][j] = (f32x16)(0.f); gW2[i][j] = (f32x16)(0.f); }
+    for (int j = 0; j < 2; ++j) {
+      gW1a[i][j] = (f32x4)(0.f); gW1b[i][j] = (f32x4)(0.f); gW2a[i][j] = (f32x4)(0.f); gW2b[i][j] = (f32x4)(0.f);
     }
   }
 
   const long long ntiles = (a.B + kTS - 1) / kTS;
   const long long wid = (long long)blockIdx.x * kWaves + wave, nw = (long long)gridDim.x * kWaves;
-  // Input rows travel through registers one tile ahead (and the gather indices two tiles ahead), so
-  // their HBM latency hides behind the matrix work of the current tile: lane k holds feature k of
-  // the tile's 32 rows.
+  // lane k holds feature k of the tile's 16 rows
   const bool kon = lane < m.d_in;
   float x_mu = 0.f, x_is = 1.f;
   if (a.mean != nullptr && kon) { x_mu = a.mean[lane]; x_is = 1.0f / (a.stdv[lane] + a.eps); }
   float xr[kTS];
-  int idx_next = 0;  // lane s < 32: source row of sample s of the tile after next (-1: none)
+  int idx_next = 0;  // lane s < 16: source row of sample s of the tile after next (-1: none)
   auto load_index = [&](long long tt) -> int {
-    const long long g = tt * kTS + (lane & 31);
+    const long long g = tt * kTS + (lane & (kTS - 1));
     if (tt >= ntiles || g >= a.B) return -1;
     return a.index != nullptr ? (int)a.index[g] : (int)g;
   };
@@ -200,59 +216,56 @@ __global__ __launch_bounds__(kWaves * 64, 1) void mlp_kernel(const Args a) {
       xr[s] = (kon && row >= 0) ? a.x[(long long)row * m.d_in + lane] : x_mu;
     }
   };
-  load_rows(load_index(wid));
-  idx_next = load_index(wid + nw);
+  idx_next = load_index(wid);
   for (long long t = wid; t < ntiles; t += nw) {
     const long long s0 = t * kTS;
     // ---- stage the input tile (optionally gathered and standardised) -----------------------------
+    // (the gather indices travel one tile ahead; the rows' HBM latency is covered by the SIMD's
+    // other wave -- a register prefetch of the rows does not fit the 256-register budget)
+    load_rows(idx_next);
+    idx_next = load_index(t + nw);
 #pragma unroll
     for (int s = 0; s < kTS; ++s) X[s * kLS + lane] = (xr[s] - x_mu) * x_is;
-    load_rows(idx_next);
-    idx_next = load_index(t + 2 * nw);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    PDS_WAVE_SYNC();
     // ---- forward ---------------------------------------------------------------------------------
-    {  // H1 = act(X W1^T + b1)
-      f32x16 c[1][2] = {{(f32x16)(0.f), (f32x16)(0.f)}};
-      mma_block<1, 2>(c, X, kLS, 1, 0, kTS, W1s, 1, kLS, 32 * kLS, K1, lane);
+    {  // H1 = act(X W1^T + b1); columns >= h1 come out as act(0) = 0 (zero-padded weights and biases)
+      f32x4 c[1][kNT];
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const int n = nt * 32 + col;
+      for (int j = 0; j < kNT; ++j) c[0][j] = (f32x4)(0.f);
+      mma_block<1, kNT>(c, 1, n_h1, X, kLS, 1, 0, kTS, W1s, 1, kLS, kTW * kLS, m.d_in, lane);
+#pragma unroll
+      for (int nt = 0; nt < kNT; ++nt) {
+        const int n = nt * kTW + col;
         const float bias = b1s[n];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) H1[row_of(r, lane) * kLS + n] = act_fn<ACT>(c[0][nt][r] + bias);  // n >= h1: act(0) = 0
+        for (int r = 0; r < 4; ++r) H1[row_of(r, lane) * kLS + n] = act_fn<ACT>(c[0][nt][r] + bias);
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    PDS_WAVE_SYNC();
     {  // H2 = act(H1 W2^T + b2)
-      f32x16 c[1][2] = {{(f32x16)(0.f), (f32x16)(0.f)}};
-      mma_block<1, 2>(c, H1, kLS, 1, 0, kTS, W2s, 1, kLS, 32 * kLS, K2, lane);
+      f32x4 c[1][kNT];
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const int n = nt * 32 + col;
+      for (int j = 0; j < kNT; ++j) c[0][j] = (f32x4)(0.f);
+      mma_block<1, kNT>(c, 1, n_h2, H1, kLS, 1, 0, kTS, W2s, 1, kLS, kTW * kLS, m.h1, lane);
+#pragma unroll
+      for (int nt = 0; nt < kNT; ++nt) {
+        const int n = nt * kTW + col;
         const float bias = b2s[n];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) H2[row_of(r, lane) * kLS + n] = act_fn<ACT>(c[0][nt][r] + bias);
+        for (int r = 0; r < 4; ++r) H2[row_of(r, lane) * kLS + n] = act_fn<ACT>(c[0][nt][r] + bias);
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    {  // Y = H2 W3^T + b3
-      f32x16 c[1][1] = {{(f32x16)(0.f)}};
-      mma_block<1, 1>(c, H2, kLS, 1, 0, kTS, W3s, 1, kLS, 0, K3, lane);
+    PDS_WAVE_SYNC();
+    {  // Y = H2 W3^T + b3 (columns >= d_out: 0)
+      f32x4 c[1][1] = {{(f32x4)(0.f)}};
+      mma_block<1, 1>(c, 1, 1, H2, kLS, 1, 0, kTS, W3s, 1, kLS, 0, m.h2, lane);
       if (col < kMaxOut) {
         const float bias = b3s[col];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Y[row_of(r, lane) * kOS + col] = c[0][0][r] + bias;  // col >= d_out: 0
+        for (int r = 0; r < 4; ++r) Y[row_of(r, lane) * kOS + col] = c[0][0][r] + bias;
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    PDS_WAVE_SYNC();
 
     if (LOSS == LOSS_NONE) {
       if (lane < kTS && s0 + lane < a.B)
@@ -261,7 +274,7 @@ __global__ __launch_bounds__(kWaves * 64, 1) void mlp_kernel(const Args a) {
       continue;
     }
 
-    // ---- loss and its gradient with respect to the network output (lanes 0..31: one sample each) ---
+    // ---- loss and its gradient with respect to the network output (lanes 0..15: one sample each) ---
     if (lane < kTS) {
       const long long g = s0 + lane;
       float *yr = Y + lane * kOS;
@@ -295,55 +308,57 @@ __global__ __launch_bounds__(kWaves * 64, 1) void mlp_kernel(const Args a) {
         for (int j = 0; j < m.d_out; ++j) yr[j] = 0.f;
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    PDS_WAVE_SYNC();
 
     // ---- backward --------------------------------------------------------------------------------
     // dW3 += dY^T H2 (rows = outputs, K = samples); db3 += column sums of dY
-    mma_block<1, 2>(gW3, Y, 1, kOS, 0, kMaxOut, H2, kLS, 1, 32, kTS, lane);
+    mma_block<1, kNT>(gW3, 1, n_h2, Y, 1, kOS, 0, kMaxOut, H2, kLS, 1, kTW, kTS, lane);
     if (lane < kMaxOut) {
       float sacc = 0.f;
+#pragma unroll
       for (int s = 0; s < kTS; ++s) sacc += Y[s * kOS + lane];
       gb3 += sacc;
     }
-    // dZ2 = (dY W3) * act'(H2), in place over H2
+    // dZ2 = (dY W3) * act'(H2), in place over H2 (columns >= h2: W3 columns are zero)
     {
-      f32x16 c[1][2] = {{(f32x16)(0.f), (f32x16)(0.f)}};
-      mma_block<1, 2>(c, Y, kOS, 1, 0, kTS, W3s, kLS, 1, 32, KO, lane);
+      f32x4 c[1][kNT];
+#pragma unroll
+      for (int j = 0; j < kNT; ++j) c[0][j] = (f32x4)(0.f);
+      mma_block<1, kNT>(c, 1, n_h2, Y, kOS, 1, 0, kTS, W3s, kLS, 1, kTW, m.d_out, lane);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();  // every dW3 read of H2 is done
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const int n = nt * 32 + col;
+      for (int nt = 0; nt < kNT; ++nt) {
+        const int n = nt * kTW + col;
         float sacc = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 0; r < 4; ++r) {
           float *p = H2 + row_of(r, lane) * kLS + n;
-          const float dz = c[0][nt][r] * act_grad<ACT>(*p);  // n >= h2: W3 columns are zero
+          const float dz = c[0][nt][r] * act_grad<ACT>(*p);
           *p = dz;
           sacc += dz;
         }
         gb2[nt] += sacc;
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    PDS_WAVE_SYNC();
     // dW2 += dZ2^T H1
-    mma_block<2, 2>(gW2, H2, 1, kLS, 32, kTS, H1, kLS, 1, 32, kTS, lane);
+    mma_block<kNT, 2>(gW2a, n_h2, min(n_h1, 2), H2, 1, kLS, kTW, kTS, H1, kLS, 1, kTW, kTS, lane);
+    mma_block<kNT, 2>(gW2b, n_h2, n_h1 - 2, H2, 1, kLS, kTW, kTS, H1 + 2 * kTW, kLS, 1, kTW, kTS, lane);
     // dZ1 = (dZ2 W2) * act'(H1), in place over H1
     {
-      f32x16 c[1][2] = {{(f32x16)(0.f), (f32x16)(0.f)}};
-      mma_block<1, 2>(c, H2, kLS, 1, 0, kTS, W2s, kLS, 1, 32, K3, lane);
+      f32x4 c[1][kNT];
+#pragma unroll
+      for (int j = 0; j < kNT; ++j) c[0][j] = (f32x4)(0.f);
+      mma_block<1, kNT>(c, 1, n_h1, H2, kLS, 1, 0, kTS, W2s, kLS, 1, kTW, m.h2, lane);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();  // every dW2 read of H1 is done
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const int n = nt * 32 + col;
+      for (int nt = 0; nt < kNT; ++nt) {
+        const int n = nt * kTW + col;
         float sacc = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 0; r < 4; ++r) {
           float *p = H1 + row_of(r, lane) * kLS + n;
           const float dz = c[0][nt][r] * act_grad<ACT>(*p);
           *p = dz;
@@ -352,11 +367,10 @@ __global__ __launch_bounds__(kWaves * 64, 1) void mlp_kernel(const Args a) {
         gb1[nt] += sacc;
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    PDS_WAVE_SYNC();
     // dW1 += dZ1^T X
-    mma_block<2, 2>(gW1, H1, 1, kLS, 32, kTS, X, kLS, 1, 32, kTS, lane);
+    mma_block<kNT, 2>(gW1a, n_h1, min(n_in, 2), H1, 1, kLS, kTW, kTS, X, kLS, 1, kTW, kTS, lane);
+    mma_block<kNT, 2>(gW1b, n_h1, n_in - 2, H1, 1, kLS, kTW, kTS, X + 2 * kTW, kLS, 1, kTW, kTS, lane);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();  // the tile images are restaged by the next iteration
   }
@@ -366,45 +380,47 @@ __global__ __launch_bounds__(kWaves * 64, 1) void mlp_kernel(const Args a) {
   float *out = a.partials + wid * a.pstride;
   const Offsets o = offsets(m);
 #pragma unroll
-  for (int it = 0; it < 2; ++it)
+  for (int it = 0; it < kNT; ++it)
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
+    for (int jt = 0; jt < kNT; ++jt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = it * 32 + row_of(r, lane), j = jt * 32 + col;
-        if (i < m.h1 && j < m.d_in) out[o.w1 + i * m.d_in + j] = gW1[it][jt][r];
-        if (i < m.h2 && j < m.h1) out[o.w2 + i * m.h1 + j] = gW2[it][jt][r];
+      for (int r = 0; r < 4; ++r) {
+        const int i = it * kTW + row_of(r, lane), j = jt * kTW + col;
+        const float w1v = jt < 2 ? gW1a[it][jt & 1][r] : gW1b[it][jt & 1][r];
+        const float w2v = jt < 2 ? gW2a[it][jt & 1][r] : gW2b[it][jt & 1][r];
+        if (i < m.h1 && j < m.d_in) out[o.w1 + i * m.d_in + j] = w1v;
+        if (i < m.h2 && j < m.h1) out[o.w2 + i * m.h1 + j] = w2v;
       }
 #pragma unroll
-  for (int jt = 0; jt < 2; ++jt)
+  for (int jt = 0; jt < kNT; ++jt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = row_of(r, lane), j = jt * 32 + col;
+    for (int r = 0; r < 4; ++r) {
+      const int i = row_of(r, lane), j = jt * kTW + col;
       if (i < m.d_out && j < m.h2) out[o.w3 + i * m.h2 + j] = gW3[0][jt][r];
     }
-  // bias gradients: lanes l and l + 32 hold the two row halves of the same column
+  // bias gradients: lanes l, l + 16, l + 32, l + 48 hold the four row groups of the same column
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const float v1 = gb1[nt] + __shfl_xor(gb1[nt], 32);
-    const float v2 = gb2[nt] + __shfl_xor(gb2[nt], 32);
-    const int n = nt * 32 + col;
-    if (lane < 32) {
+  for (int nt = 0; nt < kNT; ++nt) {
+    float v1 = gb1[nt], v2 = gb2[nt];
+    v1 += __shfl_xor(v1, 16); v1 += __shfl_xor(v1, 32);
+    v2 += __shfl_xor(v2, 16); v2 += __shfl_xor(v2, 32);
+    const int n = nt * kTW + col;
+    if (lane < kTW) {
       if (n < m.h1) out[o.b1 + n] = v1;
       if (n < m.h2) out[o.b2 + n] = v2;
     }
   }
   if (lane < m.d_out) out[o.b3 + lane] = gb3;
-  // statistics: lanes 0..31 hold per-sample sums
+  // statistics: lanes 0..15 hold per-sample sums
   float s4[kStats] = {st_loss, st_ratio, st_kl, st_cnt};
 #pragma unroll
   for (int q = 0; q < kStats; ++q) {
     float v = s4[q];
-    for (int d = 16; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    for (int d = 8; d >= 1; d >>= 1) v += __shfl_xor(v, d);
     if (lane == 0) out[o.total + q] = v;
   }
 }
 
-// grads[p] = sum over the waves' partials (fixed order) / count; stats likewise
 // block = 64 outputs x 16 slices of the wave range: 16 x fewer dependent loads per thread
 __global__ __launch_bounds__(1024) void reduce_kernel(const float *partials, int pstride, int nwaves, int total,
                                                       float denom_scale, float *grads, float *stats) {
