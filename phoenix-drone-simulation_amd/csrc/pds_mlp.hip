@@ -151,7 +151,9 @@ __host__ __device__ inline Offsets offsets(const pds_mlp &m) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       \
   } while (0)
 
-template <int LOSS, int ACT>
+// NINB: 16-wide column tiles of dW1 beyond the first two (1: d_in <= 48, 2: d_in <= 64) -- 16 accumulator
+// registers that decide whether the gradient kernels fit the 256-register budget of two waves per SIMD
+template <int LOSS, int ACT, int NINB>
 __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
   // ---- LDS images ---------------------------------------------------------------------------------
   __shared__ float W1s[kMaxDim * kLS], W2s[kMaxDim * kLS], W3s[kTW * kLS];  // [out][in], zero padded
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
   const int n_in = tiles_of(m.d_in), n_h1 = tiles_of(m.h1), n_h2 = tiles_of(m.h2);
   const int col = lane & 15;
   // weight-gradient accumulators of this wave (over all of its tiles); the column tiles in two halves
-  f32x4 gW1a[kNT][2], gW1b[kNT][2], gW2a[kNT][2], gW2b[kNT][2], gW3[1][kNT];
+  f32x4 gW1a[kNT][2], gW1b[kNT][NINB], gW2a[kNT][2], gW2b[kNT][2], gW3[1][kNT];
   float gb1[kNT], gb2[kNT], gb3 = 0.f;
   float st_loss = 0.f, st_ratio = 0.f, st_kl = 0.f, st_cnt = 0.f;
 #pragma unroll
@@ -192,7 +194,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
     gW3[0][i] = (f32x4)(0.f);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      gW1a[i][j] = (f32x4)(0.f); gW1b[i][j] = (f32x4)(0.f); gW2a[i][j] = (f32x4)(0.f); gW2b[i][j] = (f32x4)(0.f);
+      gW1a[i][j] = (f32x4)(0.f); gW2a[i][j] = (f32x4)(0.f); gW2b[i][j] = (f32x4)(0.f);
+      if (j < NINB) gW1b[i][j] = (f32x4)(0.f);
     }
   }
 
@@ -217,15 +220,37 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
     }
   };
   idx_next = load_index(wid);
+  if (LOSS == LOSS_NONE) {  // forward only: registers to spare, the rows travel one tile ahead
+    load_rows(idx_next);
+    idx_next = load_index(wid + nw);
+  }
   for (long long t = wid; t < ntiles; t += nw) {
     const long long s0 = t * kTS;
     // ---- stage the input tile (optionally gathered and standardised) -----------------------------
-    // (the gather indices travel one tile ahead; the rows' HBM latency is covered by the SIMD's
-    // other wave -- a register prefetch of the rows does not fit the 256-register budget)
-    load_rows(idx_next);
-    idx_next = load_index(t + nw);
+    // (gradient kernels: the gather indices travel one tile ahead; the rows' HBM latency is covered
+    // by the SIMD's other wave -- a register prefetch of the rows does not fit their 256-register budget)
+    if (LOSS != LOSS_NONE) load_rows(idx_next);
+    const int my_row = idx_next;  // lanes 0..15: source row of this lane's sample
+    if (LOSS != LOSS_NONE) idx_next = load_index(t + nw);
+    // the loss inputs are requested now and consumed after the three forward GEMMs
+    float c_act[4] = {0.f, 0.f, 0.f, 0.f}, c_adv = 0.f, c_old = 0.f, c_tgt = 0.f;
+    if (LOSS != LOSS_NONE && lane < kTS && s0 + lane < a.B) {
+      const long long g = s0 + lane;
+      if (LOSS == LOSS_PPO) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j < m.d_out) c_act[j] = a.act[g * m.d_out + j];
+        c_adv = a.adv[g]; c_old = a.logp_old[g];
+      } else {
+        c_tgt = a.target[my_row];
+      }
+    }
 #pragma unroll
     for (int s = 0; s < kTS; ++s) X[s * kLS + lane] = (xr[s] - x_mu) * x_is;
+    if (LOSS == LOSS_NONE) {
+      load_rows(idx_next);
+      idx_next = load_index(t + 2 * nw);
+    }
     PDS_WAVE_SYNC();
     // ---- forward ---------------------------------------------------------------------------------
     {  // H1 = act(X W1^T + b1); columns >= h1 come out as act(0) = 0 (zero-padded weights and biases)
@@ -283,12 +308,13 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
           // compute_loss_pi, algs/ppo/ppo.py:22-40 (Normal(mu, sigma).log_prob(act).sum(-1))
           float logp = 0.f, kl = 0.f, z[kMaxOut];
           for (int j = 0; j < m.d_out; ++j) {
-            z[j] = (a.act[g * m.d_out + j] - yr[j]) * isg[j];
+            const float aj = j < 4 ? c_act[j & 3] : a.act[g * m.d_out + j];
+            z[j] = (aj - yr[j]) * isg[j];
             logp += -0.5f * z[j] * z[j] - lsg[j] - 0.91893853320467274178f;
             kl += 0.5f * z[j] * z[j];
           }
-          const float ratio = expf(logp - a.logp_old[g]);
-          const float adv = a.adv[g];
+          const float ratio = expf(logp - c_old);
+          const float adv = c_adv;
           const float lo = 1.f - a.clip, hi = 1.f + a.clip;
           const float obj = fminf(ratio * adv, fminf(fmaxf(ratio, lo), hi) * adv);
           // d min(r A, clip(r) A) / d r  (torch.min splits ties, clamp passes its range: net A inside
@@ -299,8 +325,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
           st_loss += -obj; st_ratio += ratio; st_kl += kl; st_cnt += 1.f;
         } else {
           // compute_loss_v: mse_loss(v(obs), target_v), algs/iwpg/iwpg.py:272-275
-          const long long row = a.index != nullptr ? a.index[g] : g;
-          const float d = yr[0] - a.target[row];
+          const float d = yr[0] - c_tgt;
           st_loss += d * d; st_cnt += 1.f;
           yr[0] = 2.f * d;
         }
@@ -370,7 +395,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
     PDS_WAVE_SYNC();
     // dW1 += dZ1^T X
     mma_block<kNT, 2>(gW1a, n_h1, min(n_in, 2), H1, 1, kLS, kTW, kTS, X, kLS, 1, kTW, kTS, lane);
-    mma_block<kNT, 2>(gW1b, n_h1, n_in - 2, H1, 1, kLS, kTW, kTS, X + 2 * kTW, kLS, 1, kTW, kTS, lane);
+    mma_block<kNT, NINB>(gW1b, n_h1, n_in - 2, H1, 1, kLS, kTW, kTS, X + 2 * kTW, kLS, 1, kTW, kTS, lane);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();  // the tile images are restaged by the next iteration
   }
@@ -386,7 +411,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = it * kTW + row_of(r, lane), j = jt * kTW + col;
-        const float w1v = jt < 2 ? gW1a[it][jt & 1][r] : gW1b[it][jt & 1][r];
+        const float w1v = jt < 2 ? gW1a[it][jt & 1][r] : (jt - 2 < NINB ? gW1b[it][(jt - 2) < NINB ? (jt - 2) : 0][r] : 0.f);
         const float w2v = jt < 2 ? gW2a[it][jt & 1][r] : gW2b[it][jt & 1][r];
         if (i < m.h1 && j < m.d_in) out[o.w1 + i * m.d_in + j] = w1v;
         if (i < m.h2 && j < m.h1) out[o.w2 + i * m.h1 + j] = w2v;
@@ -485,8 +510,8 @@ extern "C" int pds_mlp_forward(const pds_mlp *m, const float *d_x, const int64_t
   if (check(m) != PDS_OK || !d_x || !d_y || B < 1 || ((d_mean == nullptr) != (d_std == nullptr))) return PDS_EINVAL;
   Args a{};
   a.m = *m; a.x = d_x; a.index = d_index; a.B = B; a.mean = d_mean; a.stdv = d_std; a.eps = eps; a.y = d_y;
-  if (m->activation == 0) hipLaunchKernelGGL((mlp_kernel<LOSS_NONE, 0>), dim3(grid_blocks(B)), dim3(kWaves * 64), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((mlp_kernel<LOSS_NONE, 1>), dim3(grid_blocks(B)), dim3(kWaves * 64), 0, (hipStream_t)stream, a);
+  if (m->activation == 0) hipLaunchKernelGGL((mlp_kernel<LOSS_NONE, 0, 1>), dim3(grid_blocks(B)), dim3(kWaves * 64), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((mlp_kernel<LOSS_NONE, 1, 1>), dim3(grid_blocks(B)), dim3(kWaves * 64), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? PDS_OK : PDS_EHIP;
 }
 
@@ -497,13 +522,18 @@ static int launch_grad(int loss, Args &a, float *d_grads, float *d_stats, float 
   a.pstride = o.total + kStats;
   hipStream_t s = (hipStream_t)stream;
   const dim3 g(blocks), b(kWaves * 64);
+  const bool wide = a.m.d_in > 3 * kTW;
+#define PDS_MLP_LAUNCH(L, A)                                                             \
+  do {                                                                                   \
+    if (wide) hipLaunchKernelGGL((mlp_kernel<L, A, 2>), g, b, 0, s, a);                  \
+    else hipLaunchKernelGGL((mlp_kernel<L, A, 1>), g, b, 0, s, a);                       \
+  } while (0)
   if (loss == LOSS_PPO) {
-    if (a.m.activation == 0) hipLaunchKernelGGL((mlp_kernel<LOSS_PPO, 0>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((mlp_kernel<LOSS_PPO, 1>), g, b, 0, s, a);
+    if (a.m.activation == 0) PDS_MLP_LAUNCH(LOSS_PPO, 0); else PDS_MLP_LAUNCH(LOSS_PPO, 1);
   } else {
-    if (a.m.activation == 0) hipLaunchKernelGGL((mlp_kernel<LOSS_MSE, 0>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((mlp_kernel<LOSS_MSE, 1>), g, b, 0, s, a);
+    if (a.m.activation == 0) PDS_MLP_LAUNCH(LOSS_MSE, 0); else PDS_MLP_LAUNCH(LOSS_MSE, 1);
   }
+#undef PDS_MLP_LAUNCH
   const int n = o.total + kStats;
   hipLaunchKernelGGL(reduce_kernel, dim3((n + 63) / 64), dim3(1024), 0, s, (const float *)d_workspace, a.pstride,
                      blocks * kWaves, o.total, 1.0f / (float)a.B, d_grads, d_stats);
