@@ -17,7 +17,7 @@
 
 #include "../../include/pds.h"
 
-namespace {
+namespace pds_gae_detail {  // named (not anonymous) so that profiler kernel names are readable
 
 __global__ __launch_bounds__(256) void gae_kernel(const float *__restrict__ rew, const float *__restrict__ val,
                                                   const uint8_t *__restrict__ term, const uint8_t *__restrict__ trunc,
@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256) void gae_kernel(const float *__restrict__ rew,
   }
 }
 
-}  // namespace
+}  // namespace pds_gae_detail
+using namespace pds_gae_detail;
 
 extern "C" int pds_gae(const float *d_rew, const float *d_val, const uint8_t *d_terminated,
                        const uint8_t *d_truncated, const float *d_final_val, const float *d_last_val,

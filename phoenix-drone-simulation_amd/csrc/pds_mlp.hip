@@ -29,7 +29,7 @@
 
 #include "../../include/pds.h"
 
-namespace {
+namespace pds_mlp_detail {  // named (not anonymous) so that profiler kernel names are readable
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -493,7 +493,8 @@ int grid_blocks(long long B) {
 
 constexpr int kMaxGridWaves = 256 * kWaves;
 
-}  // namespace
+}  // namespace pds_mlp_detail
+using namespace pds_mlp_detail;
 
 extern "C" int pds_mlp_param_count(const pds_mlp *m) {
   if (check(m) != PDS_OK) return PDS_EINVAL;

@@ -10,7 +10,7 @@
 #include "../../include/pds.h"
 #include "pds_device.h"
 
-namespace {
+namespace pds_train_detail {  // named (not anonymous) so that profiler kernel names are readable
 
 // a = mu + sigma z, z ~ N(0,1) from Philox4x32-10 keyed by (seed, call counter); one thread per env
 // (d_out <= 8: at most 2 blocks).  logp = -sum(0.5 z^2 + log sigma + 0.5 log 2 pi).
@@ -92,7 +92,8 @@ __global__ __launch_bounds__(256) void adam_kernel(pds_mlp m, const float *g, fl
   *dst = *dst - (lr / bc1) * (mm / denom);
 }
 
-}  // namespace
+}  // namespace pds_train_detail
+using namespace pds_train_detail;
 
 extern "C" int pds_gaussian_sample(const float *d_mu, const float *d_log_std, int64_t n, int d_out, uint64_t seed,
                                    uint64_t call, uint64_t id_base, int deterministic, float *d_act, float *d_logp,
