@@ -33,16 +33,17 @@ namespace pds_mlp_detail {  // named (not anonymous) so that profiler kernel nam
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kTS = 16;            // samples per wave tile (= M of one MFMA tile)
-constexpr int kTW = 16;            // tile width
+constexpr int kTS = 16;            // samples per wave tile (= N of every activation GEMM)
+constexpr int kTW = 16;            // feature tile width
 constexpr int kNT = 4;             // 16-wide tiles per 64-wide dimension
-constexpr int kLS = 65;            // LDS row stride of every [rows][<= 64] image (odd: conflict-free both ways)
-constexpr int kOS = 9;             // row stride of the [16][<= 8] output / output-gradient tile
+constexpr int kS = 68;             // image row stride: 16-B aligned rows (b128 access) and 4 * kS == 16 (mod 32),
+                                   // so the sample-slot walk of the dword reads below is bank-conflict free
+constexpr int kSY = 20;            // row stride of the [16 samples][16 outputs] output-gradient image (same rule)
 constexpr int kMaxDim = 64;        // d_in, h1, h2 <= 64
 constexpr int kMaxOut = 8;         // d_out <= 8
 constexpr int kWaves = 8;          // waves per block, two per SIMD; 1 block per CU (LDS-bound)
 constexpr int kStats = 4;          // loss sum, ratio sum, kl sum, sample count
-constexpr int kTileFloats = 3 * kTS * kLS + kTS * kOS;
+constexpr int kWaveFloats = 3 * kTS * kS + kTS * kSY;
 
 enum { LOSS_NONE = 0, LOSS_PPO = 1, LOSS_MSE = 2 };
 
@@ -61,61 +62,6 @@ struct Args {
   int pstride;
 };
 
-// C/D map of v_mfma_f32_16x16x4_f32: lane l holds column l & 15 of rows 4 * (l >> 4) + r, r = 0..3
-__device__ __forceinline__ int row_of(int r, int lane) { return (lane >> 4) * 4 + r; }
-
-// c[i][j] (16x16 each) += A_i[16 x K] * B_j[K x 16] for the first na / nb of NA row tiles of A and NB
-// column tiles of B.  Element (m, k) of A tile i at A[i * a_toff + m * a_sm + k * a_sk], (k, n) of
-// B tile j at B[j * b_toff + k * b_sk + n * b_sn]; lanes whose row index is >= a_rows feed zeros
-// (short matrices).  K is walked in chunks of 2 MFMA k-steps (8 k values): the operands of the
-// next chunk are read from LDS while the matrix core works on the current one.  The walk may run up
-// to 7 k values past K: every image is zero padded to 64 columns / rows, so that adds zeros.
-template <int NA, int NB>
-__device__ __forceinline__ void mma_block(f32x4 (&c)[NA][NB], int na, int nb, const float *A, int a_sm, int a_sk,
-                                          int a_toff, int a_rows, const float *B, int b_sk, int b_sn, int b_toff,
-                                          int K, int lane) {
-  constexpr int CH = 2;
-  const int r = lane & 15, h = lane >> 4;
-  const float *ap = A + r * a_sm + h * a_sk;
-  const float *bp = B + h * b_sk + r * b_sn;
-  const bool a_on = r < a_rows;
-  float a0[CH][NA], b0[CH][NB];
-#pragma unroll
-  for (int q = 0; q < CH; ++q) {
-#pragma unroll
-    for (int i = 0; i < NA; ++i) a0[q][i] = a_on ? ap[i * a_toff + 4 * q * a_sk] : 0.f;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) b0[q][j] = bp[j * b_toff + 4 * q * b_sk];
-  }
-  for (int k0 = 0; k0 < K; k0 += 4 * CH) {
-    float a1[CH][NA], b1[CH][NB];
-    const int kn = k0 + 4 * CH;
-    if (kn < K) {
-#pragma unroll
-      for (int q = 0; q < CH; ++q) {
-#pragma unroll
-        for (int i = 0; i < NA; ++i) a1[q][i] = a_on ? ap[i * a_toff + (kn + 4 * q) * a_sk] : 0.f;
-#pragma unroll
-        for (int j = 0; j < NB; ++j) b1[q][j] = bp[j * b_toff + (kn + 4 * q) * b_sk];
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < CH; ++q)
-#pragma unroll
-      for (int i = 0; i < NA; ++i)
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-          c[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q][i], b0[q][j], c[i][j], 0, 0, 0);
-#pragma unroll
-    for (int q = 0; q < CH; ++q) {
-#pragma unroll
-      for (int i = 0; i < NA; ++i) a0[q][i] = a1[q][i];
-#pragma unroll
-      for (int j = 0; j < NB; ++j) b0[q][j] = b1[q][j];
-    }
-  }
-}
-
 // ACT 0 relu, 1 tanh (branch-free: 1 - 2 / (e^{2v} + 1) on v_exp_f32 / v_rcp_f32, abs error < 3e-7)
 template <int ACT>
 __device__ __forceinline__ float act_fn(float v) {
@@ -125,8 +71,6 @@ __device__ __forceinline__ float act_fn(float v) {
 // derivative expressed through the activation's OUTPUT h (relu: h > 0; tanh: 1 - h^2)
 template <int ACT>
 __device__ __forceinline__ float act_grad(float h) { return ACT == 0 ? (h > 0.f ? 1.f : 0.f) : 1.f - h * h; }
-
-__device__ __forceinline__ int tiles_of(int v) { return (v + kTW - 1) / kTW; }
 
 // flat parameter layout == torch's nn.Sequential order: W1 [h1][d_in], b1, W2 [h2][h1], b2, W3 [d_out][h2], b3
 struct Offsets {
@@ -151,253 +95,261 @@ __host__ __device__ inline Offsets offsets(const pds_mlp &m) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       \
   } while (0)
 
-// NINB: 16-wide column tiles of dW1 beyond the first two (1: d_in <= 48, 2: d_in <= 64) -- 16 accumulator
-// registers that decide whether the gradient kernels fit the 256-register budget of two waves per SIMD
+#define PDS_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ f32x4 lds4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+__device__ __forceinline__ void sts4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
+
+// Z^T tile `it` (16 output features x 16 samples) = W[16 it .. +16][:] * In^T, with In^T given as NK
+// register tiles in the C/D layout: the k-slot (step j, lane group h) of feature tile kt carries
+// feature 16 kt + 4 h + j, which is register j of that tile in every lane of group h -- no movement.
+// The matching A operands are 4 consecutive floats of a weight row: one ds_read_b128 per (it, kt).
+template <int NK>
+__device__ __forceinline__ f32x4 gemm_wt(const float *Ws, int it, const f32x4 (&in)[NK], int n, int g) {
+  f32x4 c = (f32x4)(0.f);
+  const float *wp = Ws + (it * kTW + n) * kS + 4 * g;
+#pragma unroll
+  for (int kt = 0; kt < NK; ++kt) {
+    const f32x4 a = lds4(wp + kt * kTW);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = PDS_MFMA(a[j], in[kt][j], c);
+  }
+  return c;
+}
+
+// NINB: 16-wide tiles of the input dimension beyond the first two (1: d_in <= 48, 2: d_in <= 64) -- 16
+// accumulator registers that decide whether the gradient kernels fit 256 registers (two waves per SIMD)
 template <int LOSS, int ACT, int NINB>
 __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
+  constexpr int NIN = 2 + NINB;
   // ---- LDS images ---------------------------------------------------------------------------------
-  __shared__ float W1s[kMaxDim * kLS], W2s[kMaxDim * kLS], W3s[kTW * kLS];  // [out][in], zero padded
-  __shared__ float b1s[kMaxDim], b2s[kMaxDim], b3s[kMaxOut], isg[kMaxOut], lsg[kMaxOut];
-  __shared__ float tiles[kWaves * kTileFloats];
+  __shared__ __attribute__((aligned(16))) float W1s[kMaxDim * kS];  // [out][in], zero padded
+  __shared__ __attribute__((aligned(16))) float W2s[kMaxDim * kS];
+  __shared__ __attribute__((aligned(16))) float W3s[kTW * kS];
+  __shared__ __attribute__((aligned(16))) float b1s[kMaxDim], b2s[kMaxDim], b3s[kTW], mus[kMaxDim], iss[kMaxDim];
+  __shared__ float isg[kTW], lsg[kTW];
+  __shared__ __attribute__((aligned(16))) float images[kWaves * kWaveFloats];
   const pds_mlp &m = a.m;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < kMaxDim * kLS; i += kWaves * 64) {
-    const int n = i / kLS, k = i - n * kLS;
-    W1s[i] = (n < m.h1 && k < m.d_in) ? m.w1[n * m.d_in + k] : 0.f;
-    W2s[i] = (n < m.h2 && k < m.h1) ? m.w2[n * m.h1 + k] : 0.f;
-    if (i < kTW * kLS) W3s[i] = (n < m.d_out && k < m.h2) ? m.w3[n * m.h2 + k] : 0.f;
+  const int n = lane & 15, g = lane >> 4;  // C/D layout: column (sample) n, rows 4 g + q
+  for (int i = tid; i < kMaxDim * kS; i += kWaves * 64) {
+    const int r = i / kS, k = i - r * kS;
+    W1s[i] = (r < m.h1 && k < m.d_in) ? m.w1[r * m.d_in + k] : 0.f;
+    W2s[i] = (r < m.h2 && k < m.h1) ? m.w2[r * m.h1 + k] : 0.f;
+    if (i < kTW * kS) W3s[i] = (r < m.d_out && k < m.h2) ? m.w3[r * m.h2 + k] : 0.f;
   }
   if (tid < kMaxDim) {
     b1s[tid] = tid < m.h1 ? m.b1[tid] : 0.f;
     b2s[tid] = tid < m.h2 ? m.b2[tid] : 0.f;
+    const bool std_on = a.mean != nullptr && tid < m.d_in;
+    mus[tid] = std_on ? a.mean[tid] : 0.f;
+    iss[tid] = std_on ? 1.0f / (a.stdv[tid] + a.eps) : 1.f;
   }
-  if (tid < kMaxOut) {
+  if (tid < kTW) {
     b3s[tid] = tid < m.d_out ? m.b3[tid] : 0.f;
     const float ls = (LOSS == LOSS_PPO && tid < m.d_out) ? a.log_std[tid] : 0.f;
     lsg[tid] = ls;
     isg[tid] = expf(-ls);  // 1 / sigma
   }
-  float *X = tiles + wave * kTileFloats;
-  float *H1 = X + kTS * kLS, *H2 = H1 + kTS * kLS, *Y = H2 + kTS * kLS;
-  for (int i = lane; i < kTileFloats; i += 64) X[i] = 0.f;  // pad columns stay zero
+  float *Ximg = images + wave * kWaveFloats;  // [sample][feature] images for the weight-gradient GEMMs
+  float *H1img = Ximg + kTS * kS, *H2img = H1img + kTS * kS, *dYimg = H2img + kTS * kS;
+  for (int i = lane; i < kWaveFloats; i += 64) Ximg[i] = 0.f;
   __syncthreads();
 
-  const int n_in = tiles_of(m.d_in), n_h1 = tiles_of(m.h1), n_h2 = tiles_of(m.h2);
-  const int col = lane & 15;
-  // weight-gradient accumulators of this wave (over all of its tiles); the column tiles in two halves
-  f32x4 gW1a[kNT][2], gW1b[kNT][NINB], gW2a[kNT][2], gW2b[kNT][2], gW3[1][kNT];
-  float gb1[kNT], gb2[kNT], gb3 = 0.f;
+  // weight-gradient accumulators of this wave (over all of its tiles), C/D layout; bias gradients as
+  // per-lane partial sums over this lane's sample column
+  f32x4 gW1[kNT][NIN], gW2[kNT][kNT], gW3[kNT], gb1[kNT], gb2[kNT], gb3 = (f32x4)(0.f);
   float st_loss = 0.f, st_ratio = 0.f, st_kl = 0.f, st_cnt = 0.f;
 #pragma unroll
   for (int i = 0; i < kNT; ++i) {
-    gb1[i] = 0.f; gb2[i] = 0.f;
-    gW3[0][i] = (f32x4)(0.f);
+    gW3[i] = (f32x4)(0.f); gb1[i] = (f32x4)(0.f); gb2[i] = (f32x4)(0.f);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      gW1a[i][j] = (f32x4)(0.f); gW2a[i][j] = (f32x4)(0.f); gW2b[i][j] = (f32x4)(0.f);
-      if (j < NINB) gW1b[i][j] = (f32x4)(0.f);
-    }
+    for (int j = 0; j < kNT; ++j) gW2[i][j] = (f32x4)(0.f);
+#pragma unroll
+    for (int j = 0; j < NIN; ++j) gW1[i][j] = (f32x4)(0.f);
   }
 
   const long long ntiles = (a.B + kTS - 1) / kTS;
   const long long wid = (long long)blockIdx.x * kWaves + wave, nw = (long long)gridDim.x * kWaves;
-  // lane k holds feature k of the tile's 16 rows
-  const bool kon = lane < m.d_in;
-  float x_mu = 0.f, x_is = 1.f;
-  if (a.mean != nullptr && kon) { x_mu = a.mean[lane]; x_is = 1.0f / (a.stdv[lane] + a.eps); }
-  float xr[kTS];
-  int idx_next = 0;  // lane s < 16: source row of sample s of the tile after next (-1: none)
-  auto load_index = [&](long long tt) -> int {
-    const long long g = tt * kTS + (lane & (kTS - 1));
-    if (tt >= ntiles || g >= a.B) return -1;
-    return a.index != nullptr ? (int)a.index[g] : (int)g;
+  auto load_index = [&](long long tt) -> long long {  // source row of this lane's sample, -1: none
+    const long long s = tt * kTS + n;
+    if (tt >= ntiles || s >= a.B) return -1;
+    return a.index != nullptr ? a.index[s] : s;
   };
-  auto load_rows = [&](int rows_of_tile) {
-#pragma unroll
-    for (int s = 0; s < kTS; ++s) {
-      const int row = __builtin_amdgcn_readlane(rows_of_tile, s);  // scalar
-      xr[s] = (kon && row >= 0) ? a.x[(long long)row * m.d_in + lane] : x_mu;
-    }
-  };
-  idx_next = load_index(wid);
-  if (LOSS == LOSS_NONE) {  // forward only: registers to spare, the rows travel one tile ahead
-    load_rows(idx_next);
-    idx_next = load_index(wid + nw);
-  }
+  long long row_next = load_index(wid);
   for (long long t = wid; t < ntiles; t += nw) {
     const long long s0 = t * kTS;
-    // ---- stage the input tile (optionally gathered and standardised) -----------------------------
-    // (gradient kernels: the gather indices travel one tile ahead; the rows' HBM latency is covered
-    // by the SIMD's other wave -- a register prefetch of the rows does not fit their 256-register budget)
-    if (LOSS != LOSS_NONE) load_rows(idx_next);
-    const int my_row = idx_next;  // lanes 0..15: source row of this lane's sample
-    if (LOSS != LOSS_NONE) idx_next = load_index(t + nw);
-    // the loss inputs are requested now and consumed after the three forward GEMMs
+    const long long row = row_next;
+    const bool valid = row >= 0;
+    row_next = load_index(t + nw);
+    // ---- input: lane (n, g) holds features 16 kt + 4 g + q of its sample = the B operands of layer 1 --
+    f32x4 xin[NIN];
+#pragma unroll
+    for (int kt = 0; kt < NIN; ++kt) {
+      const int k0 = kt * kTW + 4 * g;
+      const f32x4 mu = lds4(mus + k0), is = lds4(iss + k0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float v = (valid && k0 + q < m.d_in) ? a.x[row * m.d_in + k0 + q] : mu[q];
+        xin[kt][q] = (v - mu[q]) * is[q];
+      }
+    }
+    // loss inputs, consumed after the forward GEMMs
     float c_act[4] = {0.f, 0.f, 0.f, 0.f}, c_adv = 0.f, c_old = 0.f, c_tgt = 0.f;
-    if (LOSS != LOSS_NONE && lane < kTS && s0 + lane < a.B) {
-      const long long g = s0 + lane;
-      if (LOSS == LOSS_PPO) {
+    if (LOSS == LOSS_PPO && valid) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (j < m.d_out) c_act[j] = a.act[g * m.d_out + j];
-        c_adv = a.adv[g]; c_old = a.logp_old[g];
-      } else {
-        c_tgt = a.target[my_row];
-      }
+      for (int q = 0; q < 4; ++q)
+        if (4 * g + q < m.d_out) c_act[q] = a.act[(s0 + n) * m.d_out + 4 * g + q];
+      c_adv = a.adv[s0 + n]; c_old = a.logp_old[s0 + n];
+    }
+    if (LOSS == LOSS_MSE && valid) c_tgt = a.target[row];
+    if (LOSS != LOSS_NONE) {
+#pragma unroll
+      for (int kt = 0; kt < NIN; ++kt) sts4(Ximg + n * kS + kt * kTW + 4 * g, xin[kt]);
+    }
+    // ---- forward: activations stay in registers from layer to layer -------------------------------
+    f32x4 h1r[kNT], h2r[kNT];
+#pragma unroll
+    for (int it = 0; it < kNT; ++it) {  // H1^T = act(W1 X^T + b1); rows >= h1: act(0) = 0
+      const f32x4 c = gemm_wt<NIN>(W1s, it, xin, n, g);
+      const f32x4 b = lds4(b1s + it * kTW + 4 * g);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) h1r[it][q] = act_fn<ACT>(c[q] + b[q]);
+      if (LOSS != LOSS_NONE) sts4(H1img + n * kS + it * kTW + 4 * g, h1r[it]);
     }
 #pragma unroll
-    for (int s = 0; s < kTS; ++s) X[s * kLS + lane] = (xr[s] - x_mu) * x_is;
+    for (int it = 0; it < kNT; ++it) {  // H2^T = act(W2 H1^T + b2)
+      const f32x4 c = gemm_wt<kNT>(W2s, it, h1r, n, g);
+      const f32x4 b = lds4(b2s + it * kTW + 4 * g);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) h2r[it][q] = act_fn<ACT>(c[q] + b[q]);
+      if (LOSS != LOSS_NONE) sts4(H2img + n * kS + it * kTW + 4 * g, h2r[it]);
+    }
+    f32x4 y;  // Y^T = W3 H2^T + b3: lane (n, g) holds outputs 4 g + q of sample n (rows >= d_out: 0)
+    {
+      const f32x4 c = gemm_wt<kNT>(W3s, 0, h2r, n, g);
+      const f32x4 b = lds4(b3s + 4 * g);
+      y = c + b;
+    }
     if (LOSS == LOSS_NONE) {
-      load_rows(idx_next);
-      idx_next = load_index(t + 2 * nw);
-    }
-    PDS_WAVE_SYNC();
-    // ---- forward ---------------------------------------------------------------------------------
-    {  // H1 = act(X W1^T + b1); columns >= h1 come out as act(0) = 0 (zero-padded weights and biases)
-      f32x4 c[1][kNT];
+      if (valid) {
 #pragma unroll
-      for (int j = 0; j < kNT; ++j) c[0][j] = (f32x4)(0.f);
-      mma_block<1, kNT>(c, 1, n_h1, X, kLS, 1, 0, kTS, W1s, 1, kLS, kTW * kLS, m.d_in, lane);
-#pragma unroll
-      for (int nt = 0; nt < kNT; ++nt) {
-        const int n = nt * kTW + col;
-        const float bias = b1s[n];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) H1[row_of(r, lane) * kLS + n] = act_fn<ACT>(c[0][nt][r] + bias);
+        for (int q = 0; q < 4; ++q)
+          if (4 * g + q < m.d_out) a.y[(s0 + n) * m.d_out + 4 * g + q] = y[q];
       }
-    }
-    PDS_WAVE_SYNC();
-    {  // H2 = act(H1 W2^T + b2)
-      f32x4 c[1][kNT];
-#pragma unroll
-      for (int j = 0; j < kNT; ++j) c[0][j] = (f32x4)(0.f);
-      mma_block<1, kNT>(c, 1, n_h2, H1, kLS, 1, 0, kTS, W2s, 1, kLS, kTW * kLS, m.h1, lane);
-#pragma unroll
-      for (int nt = 0; nt < kNT; ++nt) {
-        const int n = nt * kTW + col;
-        const float bias = b2s[n];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) H2[row_of(r, lane) * kLS + n] = act_fn<ACT>(c[0][nt][r] + bias);
-      }
-    }
-    PDS_WAVE_SYNC();
-    {  // Y = H2 W3^T + b3 (columns >= d_out: 0)
-      f32x4 c[1][1] = {{(f32x4)(0.f)}};
-      mma_block<1, 1>(c, 1, 1, H2, kLS, 1, 0, kTS, W3s, 1, kLS, 0, m.h2, lane);
-      if (col < kMaxOut) {
-        const float bias = b3s[col];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Y[row_of(r, lane) * kOS + col] = c[0][0][r] + bias;
-      }
-    }
-    PDS_WAVE_SYNC();
-
-    if (LOSS == LOSS_NONE) {
-      if (lane < kTS && s0 + lane < a.B)
-        for (int j = 0; j < m.d_out; ++j) a.y[(s0 + lane) * m.d_out + j] = Y[lane * kOS + j];
-      __builtin_amdgcn_wave_barrier();
       continue;
     }
 
-    // ---- loss and its gradient with respect to the network output (lanes 0..15: one sample each) ---
-    if (lane < kTS) {
-      const long long g = s0 + lane;
-      float *yr = Y + lane * kOS;
-      if (g < a.B) {
-        if (LOSS == LOSS_PPO) {
-          // compute_loss_pi, algs/ppo/ppo.py:22-40 (Normal(mu, sigma).log_prob(act).sum(-1))
-          float logp = 0.f, kl = 0.f, z[kMaxOut];
-          for (int j = 0; j < m.d_out; ++j) {
-            const float aj = j < 4 ? c_act[j & 3] : a.act[g * m.d_out + j];
-            z[j] = (aj - yr[j]) * isg[j];
-            logp += -0.5f * z[j] * z[j] - lsg[j] - 0.91893853320467274178f;
-            kl += 0.5f * z[j] * z[j];
-          }
-          const float ratio = expf(logp - c_old);
-          const float adv = c_adv;
-          const float lo = 1.f - a.clip, hi = 1.f + a.clip;
-          const float obj = fminf(ratio * adv, fminf(fmaxf(ratio, lo), hi) * adv);
-          // d min(r A, clip(r) A) / d r  (torch.min splits ties, clamp passes its range: net A inside
-          // the range, A outside it only on the un-clipped branch)
-          const bool cut = (adv > 0.f && ratio > hi) || (adv < 0.f && ratio < lo);
-          const float gcoef = cut ? 0.f : -adv * ratio;  // d(-obj)/d logp
-          for (int j = 0; j < m.d_out; ++j) yr[j] = gcoef * z[j] * isg[j];
-          st_loss += -obj; st_ratio += ratio; st_kl += kl; st_cnt += 1.f;
-        } else {
-          // compute_loss_v: mse_loss(v(obs), target_v), algs/iwpg/iwpg.py:272-275
-          const float d = yr[0] - c_tgt;
-          st_loss += d * d; st_cnt += 1.f;
-          yr[0] = 2.f * d;
+    // ---- loss and its gradient with respect to the network output -------------------------------
+    f32x4 dy = (f32x4)(0.f);  // dY^T: lane (n, g) holds d loss / d output (4 g + q) of sample n
+    if (LOSS == LOSS_PPO) {
+      // compute_loss_pi, algs/ppo/ppo.py:22-40 (Normal(mu, sigma).log_prob(act).sum(-1)); every lane
+      // of a sample column evaluates the scalar part, the 4 lane groups share the outputs
+      float lp = 0.f, kl = 0.f;
+      f32x4 zs = (f32x4)(0.f);  // z / sigma
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int j = 4 * g + q;
+        if (j < m.d_out) {
+          const float z = (c_act[q] - y[q]) * isg[j];
+          lp += -0.5f * z * z - lsg[j] - 0.91893853320467274178f;
+          kl += 0.5f * z * z;
+          zs[q] = z * isg[j];
         }
-      } else {
-        for (int j = 0; j < m.d_out; ++j) yr[j] = 0.f;
+      }
+      lp += __shfl_xor(lp, 16); lp += __shfl_xor(lp, 32);
+      kl += __shfl_xor(kl, 16); kl += __shfl_xor(kl, 32);
+      const float ratio = expf(lp - c_old);
+      const float lo = 1.f - a.clip, hi = 1.f + a.clip;
+      const float obj = fminf(ratio * c_adv, fminf(fmaxf(ratio, lo), hi) * c_adv);
+      // d min(r A, clip(r) A) / d r  (torch.min splits ties, clamp passes its range: net A inside
+      // the range, A outside it only on the un-clipped branch)
+      const bool cut = (c_adv > 0.f && ratio > hi) || (c_adv < 0.f && ratio < lo);
+      const float gcoef = (cut || !valid) ? 0.f : -c_adv * ratio;  // d(-obj)/d logp
+      dy = gcoef * zs;
+      if (valid && g == 0) { st_loss += -obj; st_ratio += ratio; st_kl += kl; st_cnt += 1.f; }
+    } else {
+      // compute_loss_v: mse_loss(v(obs), target_v), algs/iwpg/iwpg.py:272-275
+      if (valid && g == 0) {
+        const float d = y[0] - c_tgt;
+        st_loss += d * d; st_cnt += 1.f;
+        dy[0] = 2.f * d;
       }
     }
+    gb3 += dy;
+    sts4(dYimg + n * kSY + 4 * g, dy);
     PDS_WAVE_SYNC();
 
-    // ---- backward --------------------------------------------------------------------------------
-    // dW3 += dY^T H2 (rows = outputs, K = samples); db3 += column sums of dY
-    mma_block<1, kNT>(gW3, 1, n_h2, Y, 1, kOS, 0, kMaxOut, H2, kLS, 1, kTW, kTS, lane);
-    if (lane < kMaxOut) {
-      float sacc = 0.f;
+    // ---- backward.  Weight-gradient GEMMs take K = the tile's 16 samples: k-slot (j, h) carries
+    // sample 4 h + j, both operands are dword reads of [sample][feature] images (conflict free). -----
+    const int r = n, h = g;  // A-operand lane roles
+    {  // dW3 += dY^T H2 (rows = outputs)
 #pragma unroll
-      for (int s = 0; s < kTS; ++s) sacc += Y[s * kOS + lane];
-      gb3 += sacc;
-    }
-    // dZ2 = (dY W3) * act'(H2), in place over H2 (columns >= h2: W3 columns are zero)
-    {
-      f32x4 c[1][kNT];
+      for (int j = 0; j < 4; ++j) {
+        const float av = dYimg[(4 * h + j) * kSY + r];
 #pragma unroll
-      for (int j = 0; j < kNT; ++j) c[0][j] = (f32x4)(0.f);
-      mma_block<1, kNT>(c, 1, n_h2, Y, kOS, 1, 0, kTS, W3s, kLS, 1, kTW, m.d_out, lane);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();  // every dW3 read of H2 is done
-#pragma unroll
-      for (int nt = 0; nt < kNT; ++nt) {
-        const int n = nt * kTW + col;
-        float sacc = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float *p = H2 + row_of(r, lane) * kLS + n;
-          const float dz = c[0][nt][r] * act_grad<ACT>(*p);
-          *p = dz;
-          sacc += dz;
-        }
-        gb2[nt] += sacc;
+        for (int jt = 0; jt < kNT; ++jt) gW3[jt] = PDS_MFMA(av, H2img[(4 * h + j) * kS + jt * kTW + n], gW3[jt]);
       }
     }
+    // dZ2^T = (W3^T dY^T) * act'(H2^T); the k-slot (j, h) carries output 4 h + j = register j of dy
+    f32x4 dz2[kNT];
+#pragma unroll
+    for (int it = 0; it < kNT; ++it) {
+      f32x4 c = (f32x4)(0.f);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) c = PDS_MFMA(W3s[(4 * h + j) * kS + it * kTW + r], dy[j], c);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dz2[it][q] = c[q] * act_grad<ACT>(h2r[it][q]);
+      gb2[it] += dz2[it];
+    }
+#pragma unroll
+    for (int it = 0; it < kNT; ++it) sts4(H2img + n * kS + it * kTW + 4 * g, dz2[it]);  // after the dW3 reads (in order)
     PDS_WAVE_SYNC();
     // dW2 += dZ2^T H1
-    mma_block<kNT, 2>(gW2a, n_h2, min(n_h1, 2), H2, 1, kLS, kTW, kTS, H1, kLS, 1, kTW, kTS, lane);
-    mma_block<kNT, 2>(gW2b, n_h2, n_h1 - 2, H2, 1, kLS, kTW, kTS, H1 + 2 * kTW, kLS, 1, kTW, kTS, lane);
-    // dZ1 = (dZ2 W2) * act'(H1), in place over H1
-    {
-      f32x4 c[1][kNT];
 #pragma unroll
-      for (int j = 0; j < kNT; ++j) c[0][j] = (f32x4)(0.f);
-      mma_block<1, kNT>(c, 1, n_h1, H2, kLS, 1, 0, kTS, W2s, kLS, 1, kTW, m.h2, lane);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();  // every dW2 read of H1 is done
+    for (int j = 0; j < 4; ++j) {
+      float av[kNT], bv[kNT];
 #pragma unroll
-      for (int nt = 0; nt < kNT; ++nt) {
-        const int n = nt * kTW + col;
-        float sacc = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float *p = H1 + row_of(r, lane) * kLS + n;
-          const float dz = c[0][nt][r] * act_grad<ACT>(*p);
-          *p = dz;
-          sacc += dz;
-        }
-        gb1[nt] += sacc;
+      for (int i = 0; i < kNT; ++i) {
+        av[i] = H2img[(4 * h + j) * kS + i * kTW + r];
+        bv[i] = H1img[(4 * h + j) * kS + i * kTW + n];
       }
+#pragma unroll
+      for (int it = 0; it < kNT; ++it)
+#pragma unroll
+        for (int jt = 0; jt < kNT; ++jt) gW2[it][jt] = PDS_MFMA(av[it], bv[jt], gW2[it][jt]);
     }
+    // dZ1^T = (W2^T dZ2^T) * act'(H1^T): A = W2^T read column-wise (4 dwords per k-tile)
+    f32x4 dz1[kNT];
+#pragma unroll
+    for (int jt = 0; jt < kNT; ++jt) {
+      f32x4 c = (f32x4)(0.f);
+#pragma unroll
+      for (int kt = 0; kt < kNT; ++kt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c = PDS_MFMA(W2s[(kt * kTW + 4 * h + j) * kS + jt * kTW + r], dz2[kt][j], c);
+      const f32x4 hv = lds4(H1img + n * kS + jt * kTW + 4 * g);  // this lane's own H1 values
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dz1[jt][q] = c[q] * act_grad<ACT>(hv[q]);
+      gb1[jt] += dz1[jt];
+    }
+#pragma unroll
+    for (int jt = 0; jt < kNT; ++jt) sts4(H1img + n * kS + jt * kTW + 4 * g, dz1[jt]);  // after the dW2 reads
     PDS_WAVE_SYNC();
     // dW1 += dZ1^T X
-    mma_block<kNT, 2>(gW1a, n_h1, min(n_in, 2), H1, 1, kLS, kTW, kTS, X, kLS, 1, kTW, kTS, lane);
-    mma_block<kNT, NINB>(gW1b, n_h1, n_in - 2, H1, 1, kLS, kTW, kTS, X + 2 * kTW, kLS, 1, kTW, kTS, lane);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();  // the tile images are restaged by the next iteration
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float av[kNT], bv[NIN];
+#pragma unroll
+      for (int i = 0; i < kNT; ++i) av[i] = H1img[(4 * h + j) * kS + i * kTW + r];
+#pragma unroll
+      for (int i = 0; i < NIN; ++i) bv[i] = Ximg[(4 * h + j) * kS + i * kTW + n];
+#pragma unroll
+      for (int it = 0; it < kNT; ++it)
+#pragma unroll
+        for (int kt = 0; kt < NIN; ++kt) gW1[it][kt] = PDS_MFMA(av[it], bv[kt], gW1[it][kt]);
+    }
+    PDS_WAVE_SYNC();  // the images are rewritten by the next tile
   }
 
   if (LOSS == LOSS_NONE) return;
@@ -405,38 +357,40 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
   float *out = a.partials + wid * a.pstride;
   const Offsets o = offsets(m);
 #pragma unroll
-  for (int it = 0; it < kNT; ++it)
+  for (int it = 0; it < kNT; ++it) {
 #pragma unroll
-    for (int jt = 0; jt < kNT; ++jt)
+    for (int q = 0; q < 4; ++q) {
+      const int i = it * kTW + 4 * g + q;  // row of the C/D layout
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = it * kTW + row_of(r, lane), j = jt * kTW + col;
-        const float w1v = jt < 2 ? gW1a[it][jt & 1][r] : (jt - 2 < NINB ? gW1b[it][(jt - 2) < NINB ? (jt - 2) : 0][r] : 0.f);
-        const float w2v = jt < 2 ? gW2a[it][jt & 1][r] : gW2b[it][jt & 1][r];
-        if (i < m.h1 && j < m.d_in) out[o.w1 + i * m.d_in + j] = w1v;
-        if (i < m.h2 && j < m.h1) out[o.w2 + i * m.h1 + j] = w2v;
+      for (int jt = 0; jt < kNT; ++jt) {
+        const int j = jt * kTW + n;
+        if (jt < NIN && i < m.h1 && j < m.d_in) out[o.w1 + i * m.d_in + j] = gW1[it][jt < NIN ? jt : 0][q];
+        if (i < m.h2 && j < m.h1) out[o.w2 + i * m.h1 + j] = gW2[it][jt][q];
       }
+      // bias gradients: sum of the per-lane partials over the 16 sample columns of the lane group
+      float v1 = gb1[it][q], v2 = gb2[it][q];
 #pragma unroll
-  for (int jt = 0; jt < kNT; ++jt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = row_of(r, lane), j = jt * kTW + col;
-      if (i < m.d_out && j < m.h2) out[o.w3 + i * m.h2 + j] = gW3[0][jt][r];
-    }
-  // bias gradients: lanes l, l + 16, l + 32, l + 48 hold the four row groups of the same column
-#pragma unroll
-  for (int nt = 0; nt < kNT; ++nt) {
-    float v1 = gb1[nt], v2 = gb2[nt];
-    v1 += __shfl_xor(v1, 16); v1 += __shfl_xor(v1, 32);
-    v2 += __shfl_xor(v2, 16); v2 += __shfl_xor(v2, 32);
-    const int n = nt * kTW + col;
-    if (lane < kTW) {
-      if (n < m.h1) out[o.b1 + n] = v1;
-      if (n < m.h2) out[o.b2 + n] = v2;
+      for (int d = 8; d >= 1; d >>= 1) { v1 += __shfl_xor(v1, d); v2 += __shfl_xor(v2, d); }
+      if (n == 0) {
+        if (i < m.h1) out[o.b1 + i] = v1;
+        if (i < m.h2) out[o.b2 + i] = v2;
+      }
     }
   }
-  if (lane < m.d_out) out[o.b3 + lane] = gb3;
-  // statistics: lanes 0..15 hold per-sample sums
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = 4 * g + q;
+#pragma unroll
+    for (int jt = 0; jt < kNT; ++jt) {
+      const int j = jt * kTW + n;
+      if (i < m.d_out && j < m.h2) out[o.w3 + i * m.h2 + j] = gW3[jt][q];
+    }
+    float v3 = gb3[q];
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) v3 += __shfl_xor(v3, d);
+    if (n == 0 && i < m.d_out) out[o.b3 + i] = v3;
+  }
+  // statistics: lanes of group 0 hold per-sample sums
   float s4[kStats] = {st_loss, st_ratio, st_kl, st_cnt};
 #pragma unroll
   for (int q = 0; q < kStats; ++q) {
@@ -511,8 +465,16 @@ extern "C" int pds_mlp_forward(const pds_mlp *m, const float *d_x, const int64_t
   if (check(m) != PDS_OK || !d_x || !d_y || B < 1 || ((d_mean == nullptr) != (d_std == nullptr))) return PDS_EINVAL;
   Args a{};
   a.m = *m; a.x = d_x; a.index = d_index; a.B = B; a.mean = d_mean; a.stdv = d_std; a.eps = eps; a.y = d_y;
-  if (m->activation == 0) hipLaunchKernelGGL((mlp_kernel<LOSS_NONE, 0, 1>), dim3(grid_blocks(B)), dim3(kWaves * 64), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((mlp_kernel<LOSS_NONE, 1, 1>), dim3(grid_blocks(B)), dim3(kWaves * 64), 0, (hipStream_t)stream, a);
+  const dim3 g(grid_blocks(B)), b(kWaves * 64);
+  hipStream_t s = (hipStream_t)stream;
+  const bool wide = m->d_in > 3 * kTW;
+  if (m->activation == 0) {
+    if (wide) hipLaunchKernelGGL((mlp_kernel<LOSS_NONE, 0, 2>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((mlp_kernel<LOSS_NONE, 0, 1>), g, b, 0, s, a);
+  } else {
+    if (wide) hipLaunchKernelGGL((mlp_kernel<LOSS_NONE, 1, 2>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((mlp_kernel<LOSS_NONE, 1, 1>), g, b, 0, s, a);
+  }
   return hipGetLastError() == hipSuccess ? PDS_OK : PDS_EHIP;
 }
 
