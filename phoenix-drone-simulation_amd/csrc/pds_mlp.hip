@@ -119,7 +119,11 @@ __device__ __forceinline__ f32x4 gemm_wt(const float *Ws, int it, const f32x4 (&
 
 // NINB: 16-wide tiles of the input dimension beyond the first two (1: d_in <= 48, 2: d_in <= 64) -- 16
 // accumulator registers that decide whether the gradient kernels fit 256 registers (two waves per SIMD)
-template <int LOSS, int ACT, int NINB>
+// GB: bias gradients as per-lane partial sums (36 registers).  Otherwise they come for free out of
+// the weight-gradient GEMMs: the first padding column of each [sample][feature] image (column d_in
+// of X, h1 of H1, h2 of H2) is set to 1, so column d_in / h1 / h2 of dW1 / dW2 / dW3 accumulates
+// sum_s dZ[s][i] -- possible whenever the dimension leaves a padding column (not a multiple of 16).
+template <int LOSS, int ACT, int NINB, bool GB>
 __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
   constexpr int NIN = 2 + NINB;
   // ---- LDS images ---------------------------------------------------------------------------------
@@ -158,11 +162,12 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
 
   // weight-gradient accumulators of this wave (over all of its tiles), C/D layout; bias gradients as
   // per-lane partial sums over this lane's sample column
-  f32x4 gW1[kNT][NIN], gW2[kNT][kNT], gW3[kNT], gb1[kNT], gb2[kNT], gb3 = (f32x4)(0.f);
+  f32x4 gW1[kNT][NIN], gW2[kNT][kNT], gW3[kNT], gb1[GB ? kNT : 1], gb2[GB ? kNT : 1], gb3 = (f32x4)(0.f);
   float st_loss = 0.f, st_ratio = 0.f, st_kl = 0.f, st_cnt = 0.f;
 #pragma unroll
   for (int i = 0; i < kNT; ++i) {
-    gW3[i] = (f32x4)(0.f); gb1[i] = (f32x4)(0.f); gb2[i] = (f32x4)(0.f);
+    gW3[i] = (f32x4)(0.f);
+    if (GB) { gb1[i] = (f32x4)(0.f); gb2[i] = (f32x4)(0.f); }
 #pragma unroll
     for (int j = 0; j < kNT; ++j) gW2[i][j] = (f32x4)(0.f);
 #pragma unroll
@@ -205,7 +210,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
     if (LOSS == LOSS_MSE && valid) c_tgt = a.target[row];
     if (LOSS != LOSS_NONE) {
 #pragma unroll
-      for (int kt = 0; kt < NIN; ++kt) sts4(Ximg + n * kS + kt * kTW + 4 * g, xin[kt]);
+      for (int kt = 0; kt < NIN; ++kt) {
+        f32x4 v = xin[kt];
+        if (!GB) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) if (kt * kTW + 4 * g + q == m.d_in) v[q] = 1.f;
+        }
+        sts4(Ximg + n * kS + kt * kTW + 4 * g, v);
+      }
     }
     // ---- forward: activations stay in registers from layer to layer -------------------------------
     f32x4 h1r[kNT], h2r[kNT];
@@ -215,7 +227,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
       const f32x4 b = lds4(b1s + it * kTW + 4 * g);
 #pragma unroll
       for (int q = 0; q < 4; ++q) h1r[it][q] = act_fn<ACT>(c[q] + b[q]);
-      if (LOSS != LOSS_NONE) sts4(H1img + n * kS + it * kTW + 4 * g, h1r[it]);
+      if (LOSS != LOSS_NONE) {
+        f32x4 v = h1r[it];
+        if (!GB) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) if (it * kTW + 4 * g + q == m.h1) v[q] = 1.f;
+        }
+        sts4(H1img + n * kS + it * kTW + 4 * g, v);
+      }
     }
 #pragma unroll
     for (int it = 0; it < kNT; ++it) {  // H2^T = act(W2 H1^T + b2)
@@ -223,7 +242,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
       const f32x4 b = lds4(b2s + it * kTW + 4 * g);
 #pragma unroll
       for (int q = 0; q < 4; ++q) h2r[it][q] = act_fn<ACT>(c[q] + b[q]);
-      if (LOSS != LOSS_NONE) sts4(H2img + n * kS + it * kTW + 4 * g, h2r[it]);
+      if (LOSS != LOSS_NONE) {
+        f32x4 v = h2r[it];
+        if (!GB) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) if (it * kTW + 4 * g + q == m.h2) v[q] = 1.f;
+        }
+        sts4(H2img + n * kS + it * kTW + 4 * g, v);
+      }
     }
     f32x4 y;  // Y^T = W3 H2^T + b3: lane (n, g) holds outputs 4 g + q of sample n (rows >= d_out: 0)
     {
@@ -276,7 +302,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
         dy[0] = 2.f * d;
       }
     }
-    gb3 += dy;
+    if (GB) gb3 += dy;
     sts4(dYimg + n * kSY + 4 * g, dy);
     PDS_WAVE_SYNC();
 
@@ -300,7 +326,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
       for (int j = 0; j < 4; ++j) c = PDS_MFMA(W3s[(4 * h + j) * kS + it * kTW + r], dy[j], c);
 #pragma unroll
       for (int q = 0; q < 4; ++q) dz2[it][q] = c[q] * act_grad<ACT>(h2r[it][q]);
-      gb2[it] += dz2[it];
+      if (GB) gb2[it] += dz2[it];
     }
 #pragma unroll
     for (int it = 0; it < kNT; ++it) sts4(H2img + n * kS + it * kTW + 4 * g, dz2[it]);  // after the dW3 reads (in order)
@@ -331,7 +357,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
       const f32x4 hv = lds4(H1img + n * kS + jt * kTW + 4 * g);  // this lane's own H1 values
 #pragma unroll
       for (int q = 0; q < 4; ++q) dz1[jt][q] = c[q] * act_grad<ACT>(hv[q]);
-      gb1[jt] += dz1[jt];
+      if (GB) gb1[jt] += dz1[jt];
     }
 #pragma unroll
     for (int jt = 0; jt < kNT; ++jt) sts4(H1img + n * kS + jt * kTW + 4 * g, dz1[jt]);  // after the dW2 reads
@@ -366,14 +392,19 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
         const int j = jt * kTW + n;
         if (jt < NIN && i < m.h1 && j < m.d_in) out[o.w1 + i * m.d_in + j] = gW1[it][jt < NIN ? jt : 0][q];
         if (i < m.h2 && j < m.h1) out[o.w2 + i * m.h1 + j] = gW2[it][jt][q];
+        if (!GB) {  // the ones columns
+          if (jt < NIN && i < m.h1 && j == m.d_in) out[o.b1 + i] = gW1[it][jt < NIN ? jt : 0][q];
+          if (i < m.h2 && j == m.h1) out[o.b2 + i] = gW2[it][jt][q];
+        }
       }
-      // bias gradients: sum of the per-lane partials over the 16 sample columns of the lane group
-      float v1 = gb1[it][q], v2 = gb2[it][q];
+      if (GB) {  // sum of the per-lane partials over the 16 sample columns of the lane group
+        float v1 = gb1[it][q], v2 = gb2[it][q];
 #pragma unroll
-      for (int d = 8; d >= 1; d >>= 1) { v1 += __shfl_xor(v1, d); v2 += __shfl_xor(v2, d); }
-      if (n == 0) {
-        if (i < m.h1) out[o.b1 + i] = v1;
-        if (i < m.h2) out[o.b2 + i] = v2;
+        for (int d = 8; d >= 1; d >>= 1) { v1 += __shfl_xor(v1, d); v2 += __shfl_xor(v2, d); }
+        if (n == 0) {
+          if (i < m.h1) out[o.b1 + i] = v1;
+          if (i < m.h2) out[o.b2 + i] = v2;
+        }
       }
     }
   }
@@ -384,11 +415,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
     for (int jt = 0; jt < kNT; ++jt) {
       const int j = jt * kTW + n;
       if (i < m.d_out && j < m.h2) out[o.w3 + i * m.h2 + j] = gW3[jt][q];
+      if (!GB && i < m.d_out && j == m.h2) out[o.b3 + i] = gW3[jt][q];
     }
-    float v3 = gb3[q];
+    if (GB) {
+      float v3 = gb3[q];
 #pragma unroll
-    for (int d = 8; d >= 1; d >>= 1) v3 += __shfl_xor(v3, d);
-    if (n == 0 && i < m.d_out) out[o.b3 + i] = v3;
+      for (int d = 8; d >= 1; d >>= 1) v3 += __shfl_xor(v3, d);
+      if (n == 0 && i < m.d_out) out[o.b3 + i] = v3;
+    }
   }
   // statistics: lanes of group 0 hold per-sample sums
   float s4[kStats] = {st_loss, st_ratio, st_kl, st_cnt};
@@ -469,11 +503,11 @@ extern "C" int pds_mlp_forward(const pds_mlp *m, const float *d_x, const int64_t
   hipStream_t s = (hipStream_t)stream;
   const bool wide = m->d_in > 3 * kTW;
   if (m->activation == 0) {
-    if (wide) hipLaunchKernelGGL((mlp_kernel<LOSS_NONE, 0, 2>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((mlp_kernel<LOSS_NONE, 0, 1>), g, b, 0, s, a);
+    if (wide) hipLaunchKernelGGL((mlp_kernel<LOSS_NONE, 0, 2, false>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((mlp_kernel<LOSS_NONE, 0, 1, false>), g, b, 0, s, a);
   } else {
-    if (wide) hipLaunchKernelGGL((mlp_kernel<LOSS_NONE, 1, 2>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((mlp_kernel<LOSS_NONE, 1, 1>), g, b, 0, s, a);
+    if (wide) hipLaunchKernelGGL((mlp_kernel<LOSS_NONE, 1, 2, false>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((mlp_kernel<LOSS_NONE, 1, 1, false>), g, b, 0, s, a);
   }
   return hipGetLastError() == hipSuccess ? PDS_OK : PDS_EHIP;
 }
@@ -485,11 +519,19 @@ static int launch_grad(int loss, Args &a, float *d_grads, float *d_stats, float 
   a.pstride = o.total + kStats;
   hipStream_t s = (hipStream_t)stream;
   const dim3 g(blocks), b(kWaves * 64);
-  const bool wide = a.m.d_in > 3 * kTW;
+  // bias gradients out of the GEMMs' padding columns when every dimension leaves one (d_in = 48 then
+  // takes the 4-tile input variant); per-lane partial sums otherwise (e.g. the 64-64 critic)
+  const bool gb = a.m.h1 == kMaxDim || a.m.h2 == kMaxDim || a.m.d_in == kMaxDim;
+  const bool wide = gb ? a.m.d_in > 3 * kTW : a.m.d_in >= 3 * kTW;
 #define PDS_MLP_LAUNCH(L, A)                                                             \
   do {                                                                                   \
-    if (wide) hipLaunchKernelGGL((mlp_kernel<L, A, 2>), g, b, 0, s, a);                  \
-    else hipLaunchKernelGGL((mlp_kernel<L, A, 1>), g, b, 0, s, a);                       \
+    if (gb) {                                                                            \
+      if (wide) hipLaunchKernelGGL((mlp_kernel<L, A, 2, true>), g, b, 0, s, a);          \
+      else hipLaunchKernelGGL((mlp_kernel<L, A, 1, true>), g, b, 0, s, a);               \
+    } else {                                                                             \
+      if (wide) hipLaunchKernelGGL((mlp_kernel<L, A, 2, false>), g, b, 0, s, a);         \
+      else hipLaunchKernelGGL((mlp_kernel<L, A, 1, false>), g, b, 0, s, a);              \
+    }                                                                                    \
   } while (0)
   if (loss == LOSS_PPO) {
     if (a.m.activation == 0) PDS_MLP_LAUNCH(LOSS_PPO, 0); else PDS_MLP_LAUNCH(LOSS_PPO, 1);

@@ -32,7 +32,8 @@ def test_forward_matches_torch(d_in, h1, h2, d_out, act, B):
     assert torch.allclose(fm.forward(x, index=idx), ref[idx], rtol=1e-5, atol=2e-6)
 
 
-@pytest.mark.parametrize("d_in,h,act,B", [(34, 50, "relu", 5000), (40, 50, "relu", 31), (42, 64, "tanh", 2048 + 5)])
+@pytest.mark.parametrize("d_in,h,act,B", [(34, 50, "relu", 5000), (40, 50, "relu", 31), (42, 64, "tanh", 2048 + 5),
+                                          (48, 50, "relu", 777), (64, 33, "tanh", 1500), (17, 16, "relu", 100)])
 def test_ppo_policy_grad_matches_autograd(d_in, h, act, B):
     from phoenix_drone_simulation_amd.fused import FusedMLP
     A, clip = 4, 0.2
