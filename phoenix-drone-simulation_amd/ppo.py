@@ -243,6 +243,8 @@ class PPOTrainer:
             from .fused import FusedMLP
             self.fm_pi = FusedMLP(self.ac.pi.net, kw["pi"]["activation"])
             self.fm_v = FusedMLP(self.ac.v.net, kw["val"]["activation"])
+            # Adam runs in pds_adam_step; the torch optimisers only carry the learning rate (LambdaLR)
+            self.pi_opt._opt_called = True
         T, N, D = self.T, self.N, env.obs_dim
         f = dict(device=dev, dtype=torch.float32)
         self.obs_buf = torch.zeros(T, N, D, **f)
