@@ -196,6 +196,11 @@ int pds_set_state(pds_handle *h, int field, const void *d_in, void *stream);
 
 /* Number of reset/step ticks issued so far (the Philox counter word). */
 uint64_t pds_tick(const pds_handle *h);
+/* Restore the tick of a checkpoint: a handle created with the same config whose fields were all set
+ * with pds_set_state and whose tick was set to the saved one continues the saved run bit for bit
+ * (there is no other hidden state: the reference offers no checkpointing of its envs; its trainer
+ * checkpoints are model.pt / state.pkl, utils/loggers.py:382-407). */
+int pds_set_tick(pds_handle *h, uint64_t tick);
 
 /* Algorithmic HBM bytes one pds_step moves per env for this configuration. */
 int pds_bytes_per_env_step(const pds_handle *h);

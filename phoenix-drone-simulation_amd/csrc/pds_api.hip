@@ -377,6 +377,11 @@ extern "C" int pds_destroy(pds_handle *h) {
 extern "C" int pds_obs_dim(const pds_handle *h) { return h ? h->obs_dim : PDS_EINVAL; }
 extern "C" int64_t pds_num_envs(const pds_handle *h) { return h ? h->cfg.num_envs : PDS_EINVAL; }
 extern "C" uint64_t pds_tick(const pds_handle *h) { return h ? h->tick : 0; }
+extern "C" int pds_set_tick(pds_handle *h, uint64_t tick) {
+  if (!h) return PDS_EINVAL;
+  h->tick = tick;
+  return PDS_OK;
+}
 extern "C" const char *pds_last_error(const pds_handle *h) { return h ? h->err : g_create_err; }
 
 // read action 16 + dyn state 48 + action history 32 + counter 4; write dyn state 48

@@ -263,6 +263,20 @@ class DroneVecEnv:
         native.check(self._handle, rc, f"pds_set_state({name})")
         torch.cuda.current_stream(self.device).synchronize()  # `v` may be a temporary
 
+    def state_dict(self):
+        """Everything a bit-exact continuation needs: every state field (`pds_get_state`) + the RNG tick.
+        Load it into an env created with the same kwargs (`load_state_dict`)."""
+        sd = {name: self.get_state(name) for name in native.FIELDS if name != "quat"}  # quat is derived
+        sd["tick"] = int(self.tick)
+        return sd
+
+    def load_state_dict(self, sd):
+        for name, v in sd.items():
+            if name != "tick":
+                self.set_state(name, v)
+        rc = self.lib.pds_set_tick(self._handle, int(sd["tick"]))
+        native.check(self._handle, rc, "pds_set_tick")
+
     @property
     def bytes_per_env_step(self):
         return self.lib.pds_bytes_per_env_step(self._handle)
