@@ -237,6 +237,7 @@ class PPOTrainer:
         # gradients of the update; the PyTorch op chains below stay as the reference path (fused=False)
         kw = ac_kwargs or {"pi": {"hidden_sizes": (50, 50), "activation": "relu"},
                            "val": {"hidden_sizes": (64, 64), "activation": "tanh"}}
+        self._pi_activation = kw["pi"]["activation"]
         self.fused = (dev.type == "cuda") if fused is None else bool(fused)
         self._sample_seed, self._sample_calls = (seed + 10000 * rank) & 0xFFFFFFFFFFFFFFFF, 0
         if self.fused:
@@ -426,6 +427,18 @@ class PPOTrainer:
         f = first.tolist()
         return dict(loss_pi=f[0] / f[3] - self.entropy_coef * ent, loss_v=float(loss_v_before), stop_iter=stop_iter,
                     entropy=ent, ratio=f[1] / f[3])
+
+    def save_checkpoint(self, log_dir, activation=None):
+        """The artefacts the reference's logger leaves per run (utils/loggers.py:382-407,
+        utils/export.py:83-98): `torch_save/model.pt` = ActorCritic.state_dict() with the reference's
+        keys, and the firmware JSON of the actor next to it."""
+        import os
+        from .policy_io import convert_actor_critic_to_json
+        os.makedirs(os.path.join(log_dir, "torch_save"), exist_ok=True)
+        path = os.path.join(log_dir, "torch_save", "model.pt")
+        torch.save({k: v.detach().cpu() for k, v in self.ac.state_dict().items()}, path)
+        convert_actor_critic_to_json(self.ac, os.path.join(log_dir, "model.json"), activation or self._pi_activation)
+        return path
 
     def learn_one_epoch(self):
         t0 = time.time()

@@ -239,3 +239,26 @@ def test_gradient_averaging_and_running_stats_world2_gloo(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert f"rank {r} ok" in o
+
+
+@pytest.mark.gpu
+def test_save_checkpoint_roundtrip(tmp_path):
+    """save_checkpoint writes a reference-layout model.pt and the firmware JSON; both reload and drive
+    the same deterministic actions as the trained ActorCritic."""
+    import phoenix_drone_simulation_amd as pds
+    from phoenix_drone_simulation_amd.policy_io import load_network_json
+    from phoenix_drone_simulation_amd.ppo import ActorCritic, PPOTrainer
+    env = pds.make("DroneCircleSimpleEnv-v0", num_envs=512, seed=4)
+    tr = PPOTrainer(env, rollout_len=16, epochs=3, train_pi_iterations=5, seed=4)
+    tr.learn(2)
+    path = tr.save_checkpoint(str(tmp_path))
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    assert set(sd) == set(tr.ac.state_dict())
+    ac2 = ActorCritic.from_reference_state_dict(sd).to(env.device)
+    pol = load_network_json(str(tmp_path / "model.json")).to(env.device)
+    obs, _ = env.reset()
+    tr.ac.eval(); ac2.eval()
+    a1 = tr.ac.step(obs)[0]
+    assert torch.allclose(ac2.step(obs)[0], a1, atol=1e-6)
+    assert torch.allclose(pol(obs), a1, atol=1e-5)
+    env.close()
