@@ -82,8 +82,9 @@ class DroneVecEnv:
                  render_mode=None, debug=False, max_episode_steps=500):
         if control_mode not in native.CONTROL_MODES:
             raise AssertionError(f'Control={control_mode} not found.')  # envs/agents.py:70-71
-        if observation_history_size != 2:
-            raise NotImplementedError("observation_history_size != 2 is not on the accelerated path")
+        if int(observation_history_size) < 1:
+            raise AssertionError("observation_history_size >= 1")  # envs/base.py:135
+        self.observation_history_size = int(observation_history_size)
         if render_mode not in (None, 'rgb_array'):
             raise NotImplementedError("rendering is out of scope (no Bullet world on this path)")
         if int(aggregate_phy_steps) < 1:
@@ -142,12 +143,22 @@ class DroneVecEnv:
             rc = self.lib.pds_create(C.byref(cfg), C.byref(self._handle))
         native.check(None, rc, "pds_create")
         self.obs_dim = self.lib.pds_obs_dim(self._handle)
+        # The kernel produces the reference's default history of 2: [o(k-1), u(k-2), o(k), u(k-1)].  Other
+        # sizes H (experiments/04_*: 1, 2, 4, 6, 8; envs/base.py:303-319) are composed on the device from
+        # the kernel's newest half [o(k), u(k-1)]: `_hist` keeps the last H halves of every env.
+        self._half = self.obs_dim // 2
+        self._hist = None
+        if self.observation_history_size != 2:
+            self.obs_dim = self.observation_history_size * self._half
+            self._hist = torch.zeros(self.num_envs, self.observation_history_size, self._half,
+                                     dtype=torch.float32, device=self.device)
+        self._auto_reset = bool(auto_reset)
         self.act_dim = 4
         o_lim = 1000 * np.ones((self.obs_dim,), dtype=np.float32)  # envs/base.py:147-150
         a_lim = np.ones((self.act_dim,), dtype=np.float32)
         self.observation_space = self.single_observation_space = _box(-o_lim, o_lim)
         self.action_space = self.single_action_space = _box(-a_lim, a_lim)
-        N, D = self.num_envs, self.obs_dim
+        N, D = self.num_envs, 2 * self._half
         f32 = dict(dtype=torch.float32, device=self.device)
         # two output sets so that `o` and `next_o` of a rollout loop can be alive together
         self._bufs = [dict(obs=torch.zeros(N, D, **f32), reward=torch.zeros(N, **f32),
@@ -189,6 +200,8 @@ class DroneVecEnv:
         rc = self.lib.pds_reset(self._handle, C.c_void_p(m.data_ptr()) if m is not None else None,
                                 C.c_void_p(b["obs"].data_ptr()), self._stream())
         native.check(self._handle, rc, "pds_reset")
+        if self._hist is not None:
+            return self._refill_history(b["obs"], m), {}
         return b["obs"], {}
 
     def reset_from_samples(self, samples, mask=None):
@@ -203,7 +216,39 @@ class DroneVecEnv:
             self._handle, C.c_void_p(m.data_ptr()) if m is not None else None,
             C.c_void_p(s.data_ptr()), C.c_void_p(b["obs"].data_ptr()), self._stream())
         native.check(self._handle, rc, "pds_reset_from_samples")
+        if self._hist is not None:
+            return self._refill_history(b["obs"], m), {}
         return b["obs"], {}
+
+    # ---- observation_history_size != 2 -------------------------------------------------------
+    def _reset_rows(self, row2):
+        """History right after a reset (envs/base.py:417-431): H - 1 copies of the first reset
+        observation, then the observation compute_history() appends -- the two halves of the kernel's
+        reset row [o0, u0, o0', u0]."""
+        H, half = self.observation_history_size, self._half
+        old, new = row2[:, :half], row2[:, half:]
+        return torch.cat([old[:, None].expand(-1, H - 1, -1), new[:, None]], 1)
+
+    def _refill_history(self, row2, mask):
+        fresh = self._reset_rows(row2)
+        self._hist = fresh if mask is None else torch.where(mask.bool()[:, None, None], fresh, self._hist)
+        return self._hist.reshape(self.num_envs, -1)
+
+    def _advance_history(self, ret):
+        obs2, reward, term, trunc, info = ret
+        half, N = self._half, self.num_envs
+        done = (term | trunc)[:, None]
+        new = obs2[:, half:]
+        # newest half of the observation the reference returns for this step: the terminal one for an
+        # env that finished (the kernel has already reset it; its last observation is in final_obs)
+        newest = torch.where(done, info["final_obs"][:, half:], new) if self._auto_reset else new
+        final_hist = torch.cat([self._hist[:, 1:], newest[:, None]], 1)
+        if self._auto_reset:
+            self._hist = torch.where(done[:, :, None], self._reset_rows(obs2), final_hist)
+        else:
+            self._hist = final_hist
+        return (self._hist.reshape(N, -1), reward, term, trunc,
+                {"cost": info["cost"], "final_obs": final_hist.reshape(N, -1)})
 
     def step(self, action, noise_variates=None):
         """env.step(action).  `noise_variates` [N, 37] (native.STEP_NOISE_LAYOUT) replaces the in-kernel
@@ -226,6 +271,8 @@ class DroneVecEnv:
                                              torch.cuda.current_stream(self.device).cuda_stream)
         if rc != 0:
             native.check(self._handle, rc, "pds_step")
+        if self._hist is not None:
+            return self._advance_history(b["_ret"])
         return b["_ret"]
 
     def close(self):
@@ -268,11 +315,15 @@ class DroneVecEnv:
         Load it into an env created with the same kwargs (`load_state_dict`)."""
         sd = {name: self.get_state(name) for name in native.FIELDS if name != "quat"}  # quat is derived
         sd["tick"] = int(self.tick)
+        if self._hist is not None:
+            sd["observation_history"] = self._hist.clone()
         return sd
 
     def load_state_dict(self, sd):
         for name, v in sd.items():
-            if name != "tick":
+            if name == "observation_history":
+                self._hist = v.to(self.device).clone()
+            elif name != "tick":
                 self.set_state(name, v)
         rc = self.lib.pds_set_tick(self._handle, int(sd["tick"]))
         native.check(self._handle, rc, "pds_set_tick")

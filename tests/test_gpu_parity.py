@@ -303,3 +303,36 @@ def test_closed_loop_with_reference_policy_500_steps():
     assert dmean < 0.01 * abs(ret_o.mean()) and dmax < 0.30 * abs(ret_o.mean()), (dmean, dmax, ret_o.mean())
     gu.assert_close(info["final_obs"].cpu().numpy()[:, 20:23], orc.final_obs[:, 20:23], 0.0, 8e-2, "final_obs")
     env.close()
+
+
+@pytest.mark.parametrize("task,H", [("hover", 1), ("hover", 4), ("circle", 4), ("circle", 6), ("takeoff", 8), ("hover", 2)])
+def test_observation_history_sizes_vs_reference_trajectories(task, H):
+    """observation_history_size = 1, 4, 6, 8 (experiments/04_*; envs/base.py:303-319), composed on the
+    device from the kernel's newest half: whole trajectories of the reference env (reset, recorded
+    actions, terminations followed by reset(); tests/golden/history.npz from
+    oracle/refgen/gen_golden_history.py) against the HIP env with same-step auto-reset."""
+    import os
+    import phoenix_drone_simulation_amd as pds
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "history.npz"))
+    k = f"{task}_h{H}_"
+    env = pds.make(ENV_ID[task], num_envs=3, observation_history_size=H, observation_noise=-1, domain_randomization=-1,
+                   motor_thrust_noise=0.0, enable_reset_distribution=False)
+    obs, _ = env.reset()
+    assert obs.shape == (3, g[k + "obs0"].shape[0]) == (3, env.obs_dim)
+    gu.assert_close(obs[1].cpu().numpy(), g[k + "obs0"], 1e-6, 2e-6, "reset obs")
+    ndone = 0
+    for t in range(g[k + "actions"].shape[0]):
+        a = torch.tensor(np.tile(g[k + "actions"][t], (3, 1)), dtype=torch.float32)
+        obs, r, term, trunc, info = env.step(a)
+        done = bool(g[k + "terminated"][t] or g[k + "truncated"][t])
+        assert bool(term[1]) == bool(g[k + "terminated"][t]), t
+        gu.assert_close(float(r[1]), g[k + "reward"][t], 1e-4, 2e-4, f"t{t} reward")
+        gu.assert_close(float(info["cost"][1]), g[k + "cost"][t], 0, 0, f"t{t} cost")
+        if done:
+            ndone += 1
+            gu.assert_close(info["final_obs"][1].cpu().numpy(), g[k + "obs"][t], 1e-4, 2e-4, f"t{t} terminal obs")
+            gu.assert_close(obs[1].cpu().numpy(), g[k + "reset_obs"][t], 1e-6, 2e-6, f"t{t} reset obs")
+        else:
+            gu.assert_close(obs[1].cpu().numpy(), g[k + "obs"][t], 1e-4, 2e-4, f"t{t} obs")
+    assert ndone == int(g[k + "terminated"].sum())
+    env.close()
