@@ -82,6 +82,11 @@ class DroneVecEnv:
                  render_mode=None, debug=False, max_episode_steps=500):
         if control_mode not in native.CONTROL_MODES:
             raise AssertionError(f'Control={control_mode} not found.')  # envs/agents.py:70-71
+        if observation_noise > 0 and int(100 // observation_frequency) != 1:
+            # obs_rate = sim_freq // observation_frequency (envs/base.py:108) with sim_freq = 100 on the
+            # Simple envs (envs/hover.py:262): the Kalman-hold branch of compute_observation
+            # (envs/hover.py:150-156) is never taken at the reference's defaults and is not built
+            raise NotImplementedError("observation_frequency != 100 with observation noise is not on the accelerated path")
         if int(observation_history_size) < 1:
             raise AssertionError("observation_history_size >= 1")  # envs/base.py:135
         self.observation_history_size = int(observation_history_size)
