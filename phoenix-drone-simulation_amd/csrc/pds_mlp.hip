@@ -379,8 +379,51 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
   }
 
   if (LOSS == LOSS_NONE) return;
-  // ---- this wave's partial sums -> partials[wid][...] (flat parameter layout + statistics) -----------
-  float *out = a.partials + wid * a.pstride;
+  // ---- the block's 8 waves add their accumulators up through LDS (the images are free now): rounds
+  // 6->2 7->3, 4->0 5->1, 2->0 3->1, 1->0, two register images in flight per round (an image is
+  // up to 184 floats per lane).  One partial per BLOCK instead of one per wave leaves the second
+  // kernel 8 x less to read.
+  {
+    float *red = images;
+    constexpr int kRegs = 4 * (kNT * NIN + kNT * kNT + kNT + (GB ? 2 * kNT + 1 : 0)) + kStats;
+    static_assert(2 * kRegs * 64 <= kWaves * kWaveFloats, "two register images must fit in the tile images");
+    auto xfer = [&](float *slot, bool add) {
+      int r = 0;
+      auto one = [&](float &v) {
+        if (add) v += slot[r * 64 + lane]; else slot[r * 64 + lane] = v;
+        ++r;
+      };
+      auto four = [&](f32x4 &v) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { float t = v[q]; one(t); v[q] = t; }
+      };
+#pragma unroll
+      for (int i = 0; i < kNT; ++i) {
+#pragma unroll
+        for (int j = 0; j < NIN; ++j) four(gW1[i][j]);
+#pragma unroll
+        for (int j = 0; j < kNT; ++j) four(gW2[i][j]);
+        four(gW3[i]);
+        if (GB) { four(gb1[i]); four(gb2[i]); }
+      }
+      if (GB) four(gb3);
+      one(st_loss); one(st_ratio); one(st_kl); one(st_cnt);
+    };
+    __syncthreads();
+#pragma unroll
+    for (int round = 0; round < 4; ++round) {
+      const int src0 = round == 0 ? 6 : (round == 1 ? 4 : (round == 2 ? 2 : 1));
+      const int nsrc = round == 3 ? 1 : 2;
+      const int dst0 = round == 0 ? 2 : 0;
+      if (wave >= src0 && wave < src0 + nsrc) xfer(red + (wave - src0) * kRegs * 64, false);
+      __syncthreads();
+      if (wave >= dst0 && wave < dst0 + nsrc) xfer(red + (wave - dst0) * kRegs * 64, true);
+      __syncthreads();
+    }
+    if (wave != 0) return;
+  }
+  // ---- the block's partial sums -> partials[block][...] (flat parameter layout + statistics) ----------
+  float *out = a.partials + (long long)blockIdx.x * a.pstride;
   const Offsets o = offsets(m);
 #pragma unroll
   for (int it = 0; it < kNT; ++it) {
@@ -479,7 +522,7 @@ int grid_blocks(long long B) {
   return (int)(blocks < 256 ? blocks : 256);  // one persistent block per CU
 }
 
-constexpr int kMaxGridWaves = 256 * kWaves;
+constexpr int kMaxGridBlocks = 256;  // one partial per block
 
 }  // namespace pds_mlp_detail
 using namespace pds_mlp_detail;
@@ -491,7 +534,7 @@ extern "C" int pds_mlp_param_count(const pds_mlp *m) {
 
 extern "C" int64_t pds_mlp_workspace_floats(const pds_mlp *m) {
   if (check(m) != PDS_OK) return PDS_EINVAL;
-  return (int64_t)kMaxGridWaves * (offsets(*m).total + kStats);
+  return (int64_t)kMaxGridBlocks * (offsets(*m).total + kStats);
 }
 
 extern "C" int pds_mlp_forward(const pds_mlp *m, const float *d_x, const int64_t *d_index, int64_t B,
@@ -541,7 +584,7 @@ static int launch_grad(int loss, Args &a, float *d_grads, float *d_stats, float 
 #undef PDS_MLP_LAUNCH
   const int n = o.total + kStats;
   hipLaunchKernelGGL(reduce_kernel, dim3((n + 63) / 64), dim3(1024), 0, s, (const float *)d_workspace, a.pstride,
-                     blocks * kWaves, o.total, 1.0f / (float)a.B, d_grads, d_stats);
+                     blocks, o.total, 1.0f / (float)a.B, d_grads, d_stats);
   return hipGetLastError() == hipSuccess ? PDS_OK : PDS_EHIP;
 }
 
