@@ -452,12 +452,26 @@ class PPOTrainer:
             dist.all_reduce(stats)
         s = stats.tolist()
         world = dist.get_world_size() if dist.is_initialized() else 1
+        self._t_total = getattr(self, "_t_total", 0.0) + (time.time() - t0)
         info.update(epoch=self.epoch + 1, ep_ret=s[0] / max(s[2], 1.0), ep_len=s[1] / max(s[2], 1.0),
                     episodes=s[2], fps=self.T * self.N * world / (time.time() - t0),
-                    noise_std=float(torch.exp(self.ac.pi.log_std[0])))
+                    noise_std=float(torch.exp(self.ac.pi.log_std[0])), lr=self.pi_opt.param_groups[0]["lr"],
+                    total_env_steps=(self.epoch + 1) * self.T * self.N * world, time=self._t_total)
         self.log.append(info)
         self.epoch += 1
         return info
+
+    def write_progress_csv(self, path):
+        """The per-epoch log in the column names of the reference's progress.csv (utils/loggers.py;
+        IWPGAlgorithm.log, algs/iwpg/iwpg.py:524-563) -- the subset of its columns this trainer tracks."""
+        cols = [("Epoch", "epoch"), ("EpRet/Mean", "ep_ret"), ("EpLen/Mean", "ep_len"), ("Loss/Pi", "loss_pi"),
+                ("Loss/Value", "loss_v"), ("Entropy", "entropy"), ("Misc/StopIter", "stop_iter"), ("PolicyRatio", "ratio"),
+                ("LR", "lr"), ("Misc/ExplorationNoiseStd", "noise_std"), ("TotalEnvSteps", "total_env_steps"),
+                ("Time", "time"), ("FPS", "fps")]
+        with open(path, "w") as f:
+            f.write(",".join(c for c, _ in cols) + "\n")
+            for row in self.log:
+                f.write(",".join(str(row.get(k, "")) for _, k in cols) + "\n")
 
     def learn(self, epochs=None, verbose=False):
         for _ in range(epochs or self.epochs):

@@ -252,6 +252,10 @@ def test_save_checkpoint_roundtrip(tmp_path):
     tr = PPOTrainer(env, rollout_len=16, epochs=3, train_pi_iterations=5, seed=4)
     tr.learn(2)
     path = tr.save_checkpoint(str(tmp_path))
+    tr.write_progress_csv(str(tmp_path / "progress.csv"))
+    rows = open(tmp_path / "progress.csv").read().strip().split("\n")
+    assert rows[0].startswith("Epoch,EpRet/Mean,EpLen/Mean,Loss/Pi,Loss/Value") and len(rows) == 3
+    assert rows[2].split(",")[0] == "2" and float(rows[2].split(",")[10]) == 2 * 16 * 512
     sd = torch.load(path, map_location="cpu", weights_only=True)
     assert set(sd) == set(tr.ac.state_dict())
     ac2 = ActorCritic.from_reference_state_dict(sd).to(env.device)
