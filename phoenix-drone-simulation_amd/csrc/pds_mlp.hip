@@ -117,6 +117,25 @@ __device__ __forceinline__ f32x4 gemm_wt(const float *Ws, int it, const f32x4 (&
   return c;
 }
 
+// Two output tiles at once: their accumulation chains alternate, so no MFMA waits for the 40-cycle
+// dependent-accumulator latency of v_mfma_f32_16x16x4_f32 (issue interval 32 cycles).
+template <int NK>
+__device__ __forceinline__ void gemm_wt2(const float *Ws, int it, const f32x4 (&in)[NK], int n, int g, f32x4 &c0,
+                                         f32x4 &c1) {
+  c0 = (f32x4)(0.f);
+  c1 = (f32x4)(0.f);
+  const float *wp = Ws + (it * kTW + n) * kS + 4 * g;
+#pragma unroll
+  for (int kt = 0; kt < NK; ++kt) {
+    const f32x4 a0 = lds4(wp + kt * kTW), a1 = lds4(wp + kTW * kS + kt * kTW);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      c0 = PDS_MFMA(a0[j], in[kt][j], c0);
+      c1 = PDS_MFMA(a1[j], in[kt][j], c1);
+    }
+  }
+}
+
 // NINB: 16-wide tiles of the input dimension beyond the first two (1: d_in <= 48, 2: d_in <= 64) -- 16
 // accumulator registers that decide whether the gradient kernels fit 256 registers (two waves per SIMD)
 // GB: bias gradients as per-lane partial sums (36 registers).  Otherwise they come for free out of
@@ -221,9 +240,12 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
     }
     // ---- forward: activations stay in registers from layer to layer -------------------------------
     f32x4 h1r[kNT], h2r[kNT];
+    f32x4 cc[kNT];
+#pragma unroll
+    for (int it = 0; it < kNT; it += 2) gemm_wt2<NIN>(W1s, it, xin, n, g, cc[it], cc[it + 1]);
 #pragma unroll
     for (int it = 0; it < kNT; ++it) {  // H1^T = act(W1 X^T + b1); rows >= h1: act(0) = 0
-      const f32x4 c = gemm_wt<NIN>(W1s, it, xin, n, g);
+      const f32x4 c = cc[it];
       const f32x4 b = lds4(b1s + it * kTW + 4 * g);
 #pragma unroll
       for (int q = 0; q < 4; ++q) h1r[it][q] = act_fn<ACT>(c[q] + b[q]);
@@ -237,8 +259,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
       }
     }
 #pragma unroll
+    for (int it = 0; it < kNT; it += 2) gemm_wt2<kNT>(W2s, it, h1r, n, g, cc[it], cc[it + 1]);
+#pragma unroll
     for (int it = 0; it < kNT; ++it) {  // H2^T = act(W2 H1^T + b2)
-      const f32x4 c = gemm_wt<kNT>(W2s, it, h1r, n, g);
+      const f32x4 c = cc[it];
       const f32x4 b = lds4(b2s + it * kTW + 4 * g);
 #pragma unroll
       for (int q = 0; q < 4; ++q) h2r[it][q] = act_fn<ACT>(c[q] + b[q]);
@@ -320,12 +344,15 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
     // dZ2^T = (W3^T dY^T) * act'(H2^T); the k-slot (j, h) carries output 4 h + j = register j of dy
     f32x4 dz2[kNT];
 #pragma unroll
+    for (int it = 0; it < kNT; ++it) cc[it] = (f32x4)(0.f);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int it = 0; it < kNT; ++it) cc[it] = PDS_MFMA(W3s[(4 * h + j) * kS + it * kTW + r], dy[j], cc[it]);
+#pragma unroll
     for (int it = 0; it < kNT; ++it) {
-      f32x4 c = (f32x4)(0.f);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) c = PDS_MFMA(W3s[(4 * h + j) * kS + it * kTW + r], dy[j], c);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) dz2[it][q] = c[q] * act_grad<ACT>(h2r[it][q]);
+      for (int q = 0; q < 4; ++q) dz2[it][q] = cc[it][q] * act_grad<ACT>(h2r[it][q]);
       if (GB) gb2[it] += dz2[it];
     }
 #pragma unroll
@@ -348,12 +375,17 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
     // dZ1^T = (W2^T dZ2^T) * act'(H1^T): A = W2^T read column-wise (4 dwords per k-tile)
     f32x4 dz1[kNT];
 #pragma unroll
+    for (int jt = 0; jt < kNT; ++jt) cc[jt] = (f32x4)(0.f);
+#pragma unroll
+    for (int kt = 0; kt < kNT; ++kt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int jt = 0; jt < kNT; ++jt)
+          cc[jt] = PDS_MFMA(W2s[(kt * kTW + 4 * h + j) * kS + jt * kTW + r], dz2[kt][j], cc[jt]);
+#pragma unroll
     for (int jt = 0; jt < kNT; ++jt) {
-      f32x4 c = (f32x4)(0.f);
-#pragma unroll
-      for (int kt = 0; kt < kNT; ++kt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) c = PDS_MFMA(W2s[(kt * kTW + 4 * h + j) * kS + jt * kTW + r], dz2[kt][j], c);
+      const f32x4 c = cc[jt];
       const f32x4 hv = lds4(H1img + n * kS + jt * kTW + 4 * g);  // this lane's own H1 values
 #pragma unroll
       for (int q = 0; q < 4; ++q) dz1[jt][q] = c[q] * act_grad<ACT>(hv[q]);
