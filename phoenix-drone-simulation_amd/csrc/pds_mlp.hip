@@ -104,7 +104,10 @@ __device__ __forceinline__ void sts4(float *p, f32x4 v) { *reinterpret_cast<f32x
 // register tiles in the C/D layout: the k-slot (step j, lane group h) of feature tile kt carries
 // feature 16 kt + 4 h + j, which is register j of that tile in every lane of group h -- no movement.
 // The matching A operands are 4 consecutive floats of a weight row: one ds_read_b128 per (it, kt).
-template <int NK>
+// LASTJ: k-steps of the LAST k-tile that carry data (step j holds features 16 kt + 4 h + j, so with
+// dim = 16 (NK - 1) + d, d <= 4, only j < d do; 4 = all).  A compile-time parameter: the specialised
+// kernels of the reference's default nets (50 hidden units, 34 inputs) skip their all-padding steps.
+template <int NK, int LASTJ>
 __device__ __forceinline__ f32x4 gemm_wt(const float *Ws, int it, const f32x4 (&in)[NK], int n, int g) {
   f32x4 c = (f32x4)(0.f);
   const float *wp = Ws + (it * kTW + n) * kS + 4 * g;
@@ -112,14 +115,15 @@ __device__ __forceinline__ f32x4 gemm_wt(const float *Ws, int it, const f32x4 (&
   for (int kt = 0; kt < NK; ++kt) {
     const f32x4 a = lds4(wp + kt * kTW);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) c = PDS_MFMA(a[j], in[kt][j], c);
+    for (int j = 0; j < 4; ++j)
+      if (kt < NK - 1 || j < LASTJ) c = PDS_MFMA(a[j], in[kt][j], c);
   }
   return c;
 }
 
 // Two output tiles at once: their accumulation chains alternate, so no MFMA waits for the 40-cycle
 // dependent-accumulator latency of v_mfma_f32_16x16x4_f32 (issue interval 32 cycles).
-template <int NK>
+template <int NK, int LASTJ>
 __device__ __forceinline__ void gemm_wt2(const float *Ws, int it, const f32x4 (&in)[NK], int n, int g, f32x4 &c0,
                                          f32x4 &c1) {
   c0 = (f32x4)(0.f);
@@ -130,8 +134,10 @@ __device__ __forceinline__ void gemm_wt2(const float *Ws, int it, const f32x4 (&
     const f32x4 a0 = lds4(wp + kt * kTW), a1 = lds4(wp + kTW * kS + kt * kTW);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      c0 = PDS_MFMA(a0[j], in[kt][j], c0);
-      c1 = PDS_MFMA(a1[j], in[kt][j], c1);
+      if (kt < NK - 1 || j < LASTJ) {
+        c0 = PDS_MFMA(a0[j], in[kt][j], c0);
+        c1 = PDS_MFMA(a1[j], in[kt][j], c1);
+      }
     }
   }
 }
@@ -142,7 +148,8 @@ __device__ __forceinline__ void gemm_wt2(const float *Ws, int it, const f32x4 (&
 // the weight-gradient GEMMs: the first padding column of each [sample][feature] image (column d_in
 // of X, h1 of H1, h2 of H2) is set to 1, so column d_in / h1 / h2 of dW1 / dW2 / dW3 accumulates
 // sum_s dZ[s][i] -- possible whenever the dimension leaves a padding column (not a multiple of 16).
-template <int LOSS, int ACT, int NINB, bool GB>
+// KJI / KJH: data-carrying k-steps of the last input / hidden k-tile (see gemm_wt; 4 = generic)
+template <int LOSS, int ACT, int NINB, bool GB, int KJI = 4, int KJH = 4>
 __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
   constexpr int NIN = 2 + NINB;
   // ---- LDS images ---------------------------------------------------------------------------------
@@ -242,7 +249,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
     f32x4 h1r[kNT], h2r[kNT];
     f32x4 cc[kNT];
 #pragma unroll
-    for (int it = 0; it < kNT; it += 2) gemm_wt2<NIN>(W1s, it, xin, n, g, cc[it], cc[it + 1]);
+    for (int it = 0; it < kNT; it += 2) gemm_wt2<NIN, KJI>(W1s, it, xin, n, g, cc[it], cc[it + 1]);
 #pragma unroll
     for (int it = 0; it < kNT; ++it) {  // H1^T = act(W1 X^T + b1); rows >= h1: act(0) = 0
       const f32x4 c = cc[it];
@@ -259,7 +266,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
       }
     }
 #pragma unroll
-    for (int it = 0; it < kNT; it += 2) gemm_wt2<kNT>(W2s, it, h1r, n, g, cc[it], cc[it + 1]);
+    for (int it = 0; it < kNT; it += 2) gemm_wt2<kNT, KJH>(W2s, it, h1r, n, g, cc[it], cc[it + 1]);
 #pragma unroll
     for (int it = 0; it < kNT; ++it) {  // H2^T = act(W2 H1^T + b2)
       const f32x4 c = cc[it];
@@ -277,7 +284,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
     }
     f32x4 y;  // Y^T = W3 H2^T + b3: lane (n, g) holds outputs 4 g + q of sample n (rows >= d_out: 0)
     {
-      const f32x4 c = gemm_wt<kNT>(W3s, 0, h2r, n, g);
+      const f32x4 c = gemm_wt<kNT, KJH>(W3s, 0, h2r, n, g);
       const f32x4 b = lds4(b3s + 4 * g);
       y = c + b;
     }
@@ -382,7 +389,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int jt = 0; jt < kNT; ++jt)
-          cc[jt] = PDS_MFMA(W2s[(kt * kTW + 4 * h + j) * kS + jt * kTW + r], dz2[kt][j], cc[jt]);
+          if (kt < kNT - 1 || j < KJH) cc[jt] = PDS_MFMA(W2s[(kt * kTW + 4 * h + j) * kS + jt * kTW + r], dz2[kt][j], cc[jt]);
 #pragma unroll
     for (int jt = 0; jt < kNT; ++jt) {
       const f32x4 c = cc[jt];
@@ -608,7 +615,14 @@ static int launch_grad(int loss, Args &a, float *d_grads, float *d_stats, float 
       else hipLaunchKernelGGL((mlp_kernel<L, A, 1, false>), g, b, 0, s, a);              \
     }                                                                                    \
   } while (0)
-  if (loss == LOSS_PPO) {
+  // the reference's default policy (algs/ppo/defaults.py: 50-50 relu) on 34 (Hover, noisy) / 40 / 42 / 48
+  // inputs: hidden k-tile 3 holds features 48, 49 only, input k-tile 2 of the 34-input net 32, 33 only
+  const auto last_steps = [](int dim) { const int d = dim - 16 * ((dim - 1) / 16); return d < 4 ? d : 4; };
+  if (loss == LOSS_PPO && a.m.activation == 0 && !gb && !wide && a.m.h1 == a.m.h2 && last_steps(a.m.h1) == 2 &&
+      a.m.h1 > 48) {
+    if (a.m.d_in > 32 && last_steps(a.m.d_in) == 2) hipLaunchKernelGGL((mlp_kernel<LOSS_PPO, 0, 1, false, 2, 2>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((mlp_kernel<LOSS_PPO, 0, 1, false, 4, 2>), g, b, 0, s, a);
+  } else if (loss == LOSS_PPO) {
     if (a.m.activation == 0) PDS_MLP_LAUNCH(LOSS_PPO, 0); else PDS_MLP_LAUNCH(LOSS_PPO, 1);
   } else {
     if (a.m.activation == 0) PDS_MLP_LAUNCH(LOSS_MSE, 0); else PDS_MLP_LAUNCH(LOSS_MSE, 1);
