@@ -547,6 +547,16 @@ __global__ __launch_bounds__(1024) void reduce_kernel(const float *partials, int
   }
 }
 
+// data-carrying k-steps of a partially filled last k-tile (4: the tile is full enough for the generic code)
+inline int last_steps(int dim) {
+  const int d = dim - 16 * ((dim - 1) / 16);
+  return d < 4 ? d : 4;
+}
+// the shapes of the reference's default nets get the compile-time skipping of all-padding k-steps:
+// 2 data steps in the last hidden k-tile (50 units) and / or in the last input k-tile (34 inputs)
+inline bool two_hidden_steps(const pds_mlp &m) { return m.h1 == m.h2 && m.h1 > 48 && last_steps(m.h1) == 2; }
+inline bool two_input_steps(const pds_mlp &m) { return m.d_in > 32 && m.d_in <= 48 && last_steps(m.d_in) == 2; }
+
 int check(const pds_mlp *m) {
   if (!m || m->d_in < 1 || m->d_in > kMaxDim || m->h1 < 1 || m->h1 > kMaxDim || m->h2 < 1 || m->h2 > kMaxDim ||
       m->d_out < 1 || m->d_out > kMaxOut || (m->activation != 0 && m->activation != 1) || !m->w1 || !m->b1 ||
@@ -584,11 +594,15 @@ extern "C" int pds_mlp_forward(const pds_mlp *m, const float *d_x, const int64_t
   const dim3 g(grid_blocks(B)), b(kWaves * 64);
   hipStream_t s = (hipStream_t)stream;
   const bool wide = m->d_in > 3 * kTW;
+  const bool ki2 = two_input_steps(*m), kh2 = two_hidden_steps(*m);
   if (m->activation == 0) {
     if (wide) hipLaunchKernelGGL((mlp_kernel<LOSS_NONE, 0, 2, false>), g, b, 0, s, a);
+    else if (kh2 && ki2) hipLaunchKernelGGL((mlp_kernel<LOSS_NONE, 0, 1, false, 2, 2>), g, b, 0, s, a);  // default policy, 34 inputs
+    else if (kh2) hipLaunchKernelGGL((mlp_kernel<LOSS_NONE, 0, 1, false, 4, 2>), g, b, 0, s, a);         // default policy
     else hipLaunchKernelGGL((mlp_kernel<LOSS_NONE, 0, 1, false>), g, b, 0, s, a);
   } else {
     if (wide) hipLaunchKernelGGL((mlp_kernel<LOSS_NONE, 1, 2, false>), g, b, 0, s, a);
+    else if (ki2 && !kh2) hipLaunchKernelGGL((mlp_kernel<LOSS_NONE, 1, 1, false, 2, 4>), g, b, 0, s, a);  // default critic, 34 inputs
     else hipLaunchKernelGGL((mlp_kernel<LOSS_NONE, 1, 1, false>), g, b, 0, s, a);
   }
   return hipGetLastError() == hipSuccess ? PDS_OK : PDS_EHIP;
@@ -617,11 +631,11 @@ static int launch_grad(int loss, Args &a, float *d_grads, float *d_stats, float 
   } while (0)
   // the reference's default policy (algs/ppo/defaults.py: 50-50 relu) on 34 (Hover, noisy) / 40 / 42 / 48
   // inputs: hidden k-tile 3 holds features 48, 49 only, input k-tile 2 of the 34-input net 32, 33 only
-  const auto last_steps = [](int dim) { const int d = dim - 16 * ((dim - 1) / 16); return d < 4 ? d : 4; };
-  if (loss == LOSS_PPO && a.m.activation == 0 && !gb && !wide && a.m.h1 == a.m.h2 && last_steps(a.m.h1) == 2 &&
-      a.m.h1 > 48) {
-    if (a.m.d_in > 32 && last_steps(a.m.d_in) == 2) hipLaunchKernelGGL((mlp_kernel<LOSS_PPO, 0, 1, false, 2, 2>), g, b, 0, s, a);
+  if (loss == LOSS_PPO && a.m.activation == 0 && !gb && !wide && two_hidden_steps(a.m)) {
+    if (two_input_steps(a.m)) hipLaunchKernelGGL((mlp_kernel<LOSS_PPO, 0, 1, false, 2, 2>), g, b, 0, s, a);
     else hipLaunchKernelGGL((mlp_kernel<LOSS_PPO, 0, 1, false, 4, 2>), g, b, 0, s, a);
+  } else if (loss == LOSS_MSE && a.m.activation == 1 && gb && !wide && two_input_steps(a.m) && !two_hidden_steps(a.m)) {
+    hipLaunchKernelGGL((mlp_kernel<LOSS_MSE, 1, 1, true, 2, 4>), g, b, 0, s, a);  // default critic, 34 inputs
   } else if (loss == LOSS_PPO) {
     if (a.m.activation == 0) PDS_MLP_LAUNCH(LOSS_PPO, 0); else PDS_MLP_LAUNCH(LOSS_PPO, 1);
   } else {
