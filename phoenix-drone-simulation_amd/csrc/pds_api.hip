@@ -467,7 +467,10 @@ extern "C" int pds_step_with_variates(pds_handle *h, const float *d_actions, con
   // half observation tile (4 resident blocks per CU instead of 3) while the grid is between one and
   // about 2.7 rounds of the full-tile residency; see pds_types.h kHalfTileRows
   LaunchFlags lf = h->flags;
-  lf.half_tile = grid.x > (unsigned)(kFullTileBlocksPerCU * kCUs) && grid.x <= (unsigned)(8 * kCUs);
+  // (variants that reset in registers on the full tile -- pds_step.h MERGED -- gain less from the half
+  // tile: it wins up to 5 blocks per CU there, up to 8 for the others; profiles/r01_tile_rows.txt)
+  const bool merged = !lf.on && !(lf.motor && lf.dr) && h->cfg.task != PDS_TASK_TAKEOFF && h->cfg.auto_reset;
+  lf.half_tile = grid.x > (unsigned)(kFullTileBlocksPerCU * kCUs) && grid.x <= (unsigned)((merged ? 5 : 8) * kCUs);
   if (h->force_tile) lf.half_tile = h->force_tile == 1;
   switch (h->cfg.task) {
     case PDS_TASK_HOVER: launch_step_hover(lf, grid, s, a); break;
