@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Train PPO on a batched Simple env, evaluate it and leave the reference's run artefacts behind.
+
+Counterpart of the reference's examples/train_drone_hover.py / `python -m phoenix_drone_simulation.train
+--alg ppo --env DroneHoverSimpleEnv-v0`: same env ids and kwargs, same PPO hyper-parameters
+(algs/ppo/defaults.py), but the rollout is one lockstep batch on the GPU (the env-step kernel of
+csrc/pds_step.h, network inference and loss gradients on the f32 matrix cores, csrc/pds_mlp.hip).
+
+    python examples/train_ppo.py --env DroneCircleSimpleEnv-v0 --num-envs 8192 --epochs 300 --log-dir /tmp/run
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import phoenix_drone_simulation_amd as pds  # noqa: E402
+from phoenix_drone_simulation_amd.evaluation import evaluate  # noqa: E402
+from phoenix_drone_simulation_amd.ppo import PPOTrainer  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--env", default="DroneHoverSimpleEnv-v0")
+    ap.add_argument("--num-envs", type=int, default=8192)
+    ap.add_argument("--rollout-len", type=int, default=64)
+    ap.add_argument("--epochs", type=int, default=300)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--log-dir", default=None)
+    args = ap.parse_args()
+    env = pds.make(args.env, num_envs=args.num_envs, seed=args.seed)  # the reference's default config
+    trainer = PPOTrainer(env, rollout_len=args.rollout_len, epochs=args.epochs, seed=args.seed)
+    t0 = time.time()
+    for e in range(args.epochs):
+        i = trainer.learn_one_epoch()
+        if e % max(1, args.epochs // 20) == 0 or e == args.epochs - 1:
+            print(f"epoch {i['epoch']:4d}  EpRet {i['ep_ret']:9.2f}  EpLen {i['ep_len']:6.1f}  FPS {i['fps']:.3e}", flush=True)
+    torch.cuda.synchronize()
+    print(f"{args.epochs * args.num_envs * args.rollout_len} env-steps in {time.time() - t0:.1f} s")
+    ret, length, cost = evaluate(env, trainer.ac, log_dir=args.log_dir)
+    print(f"evaluation: mean return {float(ret.mean()):.2f}  mean episode length {float(length.mean()):.1f}  mean cost {float(cost.mean()):.2f}")
+    if args.log_dir:
+        trainer.save_checkpoint(args.log_dir)          # torch_save/model.pt + model.json (firmware format)
+        trainer.write_progress_csv(os.path.join(args.log_dir, "progress.csv"))
+        print("saved to", args.log_dir)
+
+
+if __name__ == "__main__":
+    main()
