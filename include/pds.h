@@ -195,6 +195,11 @@ int pds_get_state(pds_handle *h, int field, void *d_out, void *stream);
 int pds_set_state(pds_handle *h, int field, const void *d_in, void *stream);
 
 /* Number of reset/step ticks issued so far (the Philox counter word). */
+/* Diagnostic (synchronises the stream): number of envs whose position / attitude / velocity / body
+ * rates hold a NaN or an Inf.  The reference has no such guard; its explicit Euler
+ * step can overflow on envs that never terminate (TakeOff with domain randomisation). */
+int pds_count_nonfinite(pds_handle *h, int64_t *count, void *stream);
+
 uint64_t pds_tick(const pds_handle *h);
 /* Restore the tick of a checkpoint: a handle created with the same config whose fields were all set
  * with pds_set_state and whose tick was set to the saved one continues the saved run bit for bit

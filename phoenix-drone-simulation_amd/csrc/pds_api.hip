@@ -503,6 +503,19 @@ extern "C" int pds_field_width(int field) {
   }
 }
 
+// number of envs whose dynamic state holds a NaN or an Inf (diagnostic, see pds_count_nonfinite)
+__global__ __launch_bounds__(256) void nonfinite_kernel(DevState st, long long n, unsigned long long *count) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  bool bad = false;
+  if (i < n) {
+    const float4 a = st.s0[i], b = st.s1[i], c = st.s2[i];
+    const float s = ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w)) + ((c.x + c.y) + (c.z + c.w));
+    bad = !(fabsf(s) <= 3.4e38f);  // NaN or Inf anywhere poisons the sum (Inf - Inf = NaN included)
+  }
+  const unsigned long long m = __ballot(bad);
+  if ((threadIdx.x & 63) == 0 && m != 0ull) atomicAdd(count, (unsigned long long)__popcll(m));
+}
+
 static int do_field(pds_handle *h, int field, void *d_ptr, int set, void *stream) {
   if (!h) return PDS_EINVAL;
   if (!d_ptr || pds_field_width(field) < 0) return fail(h, PDS_EINVAL, "bad field %d or NULL pointer", field);
@@ -516,6 +529,23 @@ static int do_field(pds_handle *h, int field, void *d_ptr, int set, void *stream
   hipLaunchKernelGGL(field_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, a);
   PDS_HIP(h, hipGetLastError());
   if (set) h->was_reset = true;
+  return PDS_OK;
+}
+
+extern "C" int pds_count_nonfinite(pds_handle *h, int64_t *count, void *stream) {
+  if (!h || !count) return PDS_EINVAL;
+  PDS_HIP(h, hipSetDevice(h->cfg.device));
+  hipStream_t s = (hipStream_t)stream;
+  unsigned long long *d = nullptr;
+  PDS_HIP(h, hipMalloc(&d, sizeof(*d)));
+  PDS_HIP(h, hipMemsetAsync(d, 0, sizeof(*d), s));
+  const long long n = h->cfg.num_envs;
+  hipLaunchKernelGGL(nonfinite_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->st, n, d);
+  unsigned long long host = 0;
+  PDS_HIP(h, hipMemcpyAsync(&host, d, sizeof(host), hipMemcpyDeviceToHost, s));
+  PDS_HIP(h, hipStreamSynchronize(s));
+  PDS_HIP(h, hipFree(d));
+  *count = (int64_t)host;
   return PDS_OK;
 }
 

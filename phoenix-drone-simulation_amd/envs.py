@@ -315,6 +315,13 @@ class DroneVecEnv:
         native.check(self._handle, rc, f"pds_set_state({name})")
         torch.cuda.current_stream(self.device).synchronize()  # `v` may be a temporary
 
+    def count_nonfinite(self):
+        """Number of envs whose dynamic state holds a NaN / Inf (diagnostic; synchronises)."""
+        out = C.c_int64(0)
+        rc = self.lib.pds_count_nonfinite(self._handle, C.byref(out), self._stream())
+        native.check(self._handle, rc, "pds_count_nonfinite")
+        return int(out.value)
+
     def state_dict(self):
         """Everything a bit-exact continuation needs: every state field (`pds_get_state`) + the RNG tick.
         Load it into an env created with the same kwargs (`load_state_dict`)."""

@@ -31,7 +31,7 @@ STEP_NOISE_LAYOUT = dict(ou=0, a_bias=4, a_rw=7, a_to=10, obs=13)
 EXPORTS = ["pds_version", "pds_default_config", "pds_create", "pds_destroy", "pds_obs_dim",
            "pds_num_envs", "pds_reset", "pds_reset_from_samples", "pds_step", "pds_step_with_variates",
            "pds_field_width",
-           "pds_get_state", "pds_set_state", "pds_tick", "pds_set_tick", "pds_bytes_per_env_step", "pds_last_error", "pds_gae",
+           "pds_get_state", "pds_set_state", "pds_tick", "pds_set_tick", "pds_count_nonfinite", "pds_bytes_per_env_step", "pds_last_error", "pds_gae",
            "pds_mlp_param_count", "pds_mlp_workspace_floats", "pds_mlp_forward", "pds_ppo_policy_grad",
            "pds_value_grad", "pds_gaussian_sample", "pds_rollout_record", "pds_adam_step"]
 
@@ -95,6 +95,7 @@ def load():
     lib.pds_tick.argtypes = [vp]
     lib.pds_tick.restype = C.c_uint64
     lib.pds_set_tick.argtypes = [vp, C.c_uint64]
+    lib.pds_count_nonfinite.argtypes = [vp, C.POINTER(C.c_int64), vp]
     lib.pds_bytes_per_env_step.argtypes = [vp]
     lib.pds_last_error.argtypes = [vp]
     lib.pds_last_error.restype = C.c_char_p

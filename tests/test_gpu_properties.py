@@ -263,3 +263,23 @@ def test_checkpoint_resume_is_bit_exact(task, kw):
         fin = r1[2] | r1[3]
         assert torch.equal(r1[4]["final_obs"][fin], r2[4]["final_obs"][fin])
     env.close(); env2.close()
+
+
+def test_count_nonfinite_flags_the_takeoff_overflow():
+    """pds_count_nonfinite: 0 on a healthy Hover batch; > 0 once TakeOff + domain randomisation has run
+    into the explicit-Euler overflow the reference's integrator has there."""
+    import phoenix_drone_simulation_amd as pds
+    n = 2048
+    env = pds.make(ENV_ID["hover"], num_envs=n, seed=1)
+    obs, _ = env.reset()
+    for k in range(20):
+        env.step(_actions(n, obs.device, 900 + k))
+    assert env.count_nonfinite() == 0
+    env.close()
+    env = pds.make(ENV_ID["takeoff"], num_envs=n, seed=1)
+    obs, _ = env.reset()
+    g = torch.Generator(device=obs.device); g.manual_seed(0)
+    for k in range(400):
+        env.step(0.5 * torch.randn(n, 4, generator=g, device=obs.device))
+    assert 0 < env.count_nonfinite() <= n
+    env.close()
