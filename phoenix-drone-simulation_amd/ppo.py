@@ -446,6 +446,12 @@ class PPOTrainer:
             self.ac.update(frac=self.epoch / self.epochs)
         stats = self.roll_out()
         info = self.update()
+        if not (math.isfinite(info["loss_pi"]) and math.isfinite(info["loss_v"])):
+            # the reference only guards NPG (algs/npg/npg.py:118,126); a poisoned batch would train NaNs
+            bad = self.env.count_nonfinite() if hasattr(self.env, "count_nonfinite") else "?"
+            raise FloatingPointError(f"non-finite loss in epoch {self.epoch + 1}: {bad} envs hold a NaN/Inf state "
+                                     "(e.g. DroneTakeOffSimpleEnv-v0 with domain randomisation: the reference's "
+                                     "explicit Euler step overflows on an env that never terminates)")
         if self.scheduler is not None:
             self.scheduler.step()
         if dist.is_initialized() and dist.get_world_size() > 1:
