@@ -154,3 +154,47 @@ def test_noise_statistics_full_size():
     dw = env.get_state("gyro_lpf") - env.get_state("omega")
     assert 0.03 < float(dw.std()) < 0.09
     env.close()
+
+
+@pytest.mark.parametrize("task", ["hover", "circle"])
+def test_episode_statistics_match_the_reference_under_its_own_randomness(task):
+    """The stochastic DEFAULT configuration (sensor + thrust noise, 10 % domain randomisation, reset
+    distribution) end to end: episode lengths / returns of the reference envs under numpy's MT19937
+    (tests/golden/episode_stats.json, 1500 episodes each, oracle/refgen/gen_golden_episode_stats.py)
+    against the HIP envs under Philox, same action distribution a = HOVER_ACTION + 0.1 N(0,1)."""
+    import json
+    import os
+    import phoenix_drone_simulation_amd as pds
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "episode_stats.json")))[task]
+    n = 16384
+    env = pds.make({"hover": "DroneHoverSimpleEnv-v0", "circle": "DroneCircleSimpleEnv-v0"}[task], num_envs=n, seed=7)
+    env.reset()
+    g = torch.Generator(device=env.device); g.manual_seed(3)
+    hover = -1.0 + 2.0 / 2.25
+    alive = torch.ones(n, dtype=torch.bool, device=env.device)
+    length = torch.zeros(n, device=env.device); ret = torch.zeros(n, device=env.device); cost = torch.zeros(n, device=env.device)
+    first = None
+    for t in range(500):
+        a = hover + 0.1 * torch.randn(n, 4, generator=g, device=env.device)
+        o, r, te, tr, info = env.step(a)
+        if first is None:
+            first = r.clone()
+        length += alive.float(); ret += torch.where(alive, r, torch.zeros_like(r)); cost += torch.where(alive, info["cost"], torch.zeros_like(r))
+        alive &= ~(te | tr)
+        if not bool(alive.any()):
+            break
+    length, ret, cost, first = length.cpu().numpy(), ret.cpu().numpy(), cost.cpu().numpy(), first.cpu().numpy()
+
+    def close(got_mean, got_std, ref_mean, ref_std, what, k=4.5):
+        se = np.sqrt(ref_std ** 2 / ref["episodes"] + got_std ** 2 / n)
+        assert abs(got_mean - ref_mean) < k * se + 1e-3 * abs(ref_mean), (what, got_mean, ref_mean, se)
+
+    close(length.mean(), length.std(), ref["len_mean"], ref["len_std"], "episode length")
+    close(ret.mean(), ret.std(), ref["ret_mean"], ref["ret_std"], "episode return")
+    close((ret / length).mean(), (ret / length).std(), ref["ret_per_step_mean"], ref["ret_per_step_std"], "return per step")
+    close(first.mean(), first.std(), ref["first_reward_mean"], ref["first_reward_std"], "first-step reward")
+    assert abs((cost / length).mean() - ref["cost_per_step_mean"]) < 2e-3
+    assert abs(length.std() - ref["len_std"]) < 0.08 * ref["len_std"]
+    q = np.quantile(length, [0.1, 0.25, 0.5, 0.75, 0.9])
+    assert np.all(np.abs(q - np.array(ref["len_quantiles"])) <= np.maximum(2.0, 0.06 * np.array(ref["len_quantiles"]))), (q, ref["len_quantiles"])
+    env.close()
