@@ -179,7 +179,8 @@ class DroneVecEnv:
             b["_args"] = tuple(C.c_void_p(b[k].data_ptr()) for k in
                                ("obs", "reward", "terminated", "truncated", "cost", "final_obs"))
             b["_ret"] = (b["obs"], b["reward"], b["terminated"].view(torch.bool), b["truncated"].view(torch.bool),
-                         {"cost": b["cost"], "final_obs": b["final_obs"]})
+                         {"cost": b["cost"], "final_obs": b["final_obs"],
+                          "final_observation": b["final_obs"]})  # gymnasium's VectorEnv key, same tensor
         self._shape = (self.num_envs, 4)
 
     # ------------------------------------------------------------------ gymnasium surface ----
@@ -253,7 +254,8 @@ class DroneVecEnv:
         else:
             self._hist = final_hist
         return (self._hist.reshape(N, -1), reward, term, trunc,
-                {"cost": info["cost"], "final_obs": final_hist.reshape(N, -1)})
+                {"cost": info["cost"], "final_obs": final_hist.reshape(N, -1),
+                 "final_observation": final_hist.reshape(N, -1)})
 
     def step(self, action, noise_variates=None):
         """env.step(action).  `noise_variates` [N, 37] (native.STEP_NOISE_LAYOUT) replaces the in-kernel
