@@ -277,6 +277,9 @@ class OracleBatch:
         return a.ctypes.data_as(C.POINTER(t or self.real))
 
     def reset(self, seed, tick):
+        if not getattr(self, "_ctor_done", False):  # the constructor's compute_observation() (envs/base.py:142)
+            getattr(self.L, "po_ctor_noise_batch" + self.suf)(C.byref(self.cfg), self.envs, C.c_int64(self.n), C.c_uint64(seed))
+            self._ctor_done = True
         getattr(self.L, "po_reset_batch" + self.suf)(
             C.byref(self.cfg), self.envs, C.c_int64(self.n), self._p(self.obs), C.c_uint64(seed),
             C.c_uint64(tick), C.c_int(self.nthreads))

@@ -826,6 +826,26 @@ static void step_streams(const po_config *c, uint64_t seed, uint64_t env_id, uin
   *nz = iz; *nu = iu;
 }
 
+/* DroneBaseEnv.__init__ evaluates compute_observation() once to size the observation space
+ * (envs/base.py:142): with sensor noise that call advances the gyro bias random walk by one draw
+ * (envs/sensors.py:130-131) before the first reset; the bias is never reset afterwards.  In-kernel
+ * counterpart: block PO_BLK_CTOR of tick 0 (csrc/pds_api.hip ctor_noise_kernel). */
+#define PO_BLK_CTOR 16u
+void SUF(po_ctor_noise_batch)(const po_config *c, ENV *envs, int64_t n, uint64_t seed) {
+  if (c->observation_noise <= 0) return;
+  const double gyro_noise_density = 0.000175, corr = 1000.0, dt = (double)c->time_step;
+  const double sigma_g_d = gyro_noise_density / sqrt(dt);
+  const REAL sb = (REAL)sqrt(-(sigma_g_d * sigma_g_d) * (corr / 2) * (exp(-2 * dt / corr) - 1));
+  for (int64_t i = 0; i < n; ++i) {
+    uint32_t w[4];
+    philox_words(seed, (uint64_t)i, 0, PO_BLK_CTOR, 1, w);
+    REAL z[4];
+    box_muller_word(w[0], &z[0], &z[1]);
+    box_muller_word(w[1], &z[2], &z[3]);
+    for (int j = 0; j < 3; ++j) envs[i].gyro_bias[j] = sb * z[j];
+  }
+}
+
 /* Batched drivers (OpenMP over envs) -- the `cpu_baseline` leg of bench.py and the lockstep
  * auto-reset semantics the HIP path is compared with: an env that terminates or truncates in this
  * step hands its last observation to final_obs and is reset in the same call. */

@@ -118,7 +118,8 @@ typedef struct po_rng {
                           REAL *cost, REAL *final_obs, uint64_t seed, uint64_t tick,                \
                           int auto_reset, int nthreads);                                            \
   void po_reset_batch##SUF(const po_config *c, po_env##SUF *envs, int64_t n, REAL *obs,             \
-                           uint64_t seed, uint64_t tick, int nthreads);
+                           uint64_t seed, uint64_t tick, int nthreads);                             \
+  void po_ctor_noise_batch##SUF(const po_config *c, po_env##SUF *envs, int64_t n, uint64_t seed);
 
 PO_DECL(_f64, double)
 PO_DECL(_f32, float)

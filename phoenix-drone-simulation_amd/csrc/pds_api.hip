@@ -275,6 +275,21 @@ static int obs_dim_of(const pds_config &c) {
   return 2 * (o + 4);
 }
 
+// DroneBaseEnv.__init__ evaluates compute_observation() once to size the observation space
+// (envs/base.py:142): with sensor noise that advances the gyro bias random walk by one draw
+// (envs/sensors.py:130-131) before the first reset, and the bias is never reset afterwards.
+constexpr uint32_t kBlkCtor = 16;  // Philox block of tick 0 (oracle: PO_BLK_CTOR)
+__global__ __launch_bounds__(256) void ctor_noise_kernel(DevState st, long long n, unsigned long long id_base, float gyro_sb,
+                                                         uint32_t seed_lo, uint32_t seed_hi) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const U4 r = philox4x32_7((uint32_t)(id_base + (unsigned long long)i), 0u, 0u, kBlkCtor, seed_lo, seed_hi);
+  float z0, z1, z2, z3;
+  box_muller_word(r.x, z0, z1);
+  box_muller_word(r.y, z2, z3);
+  st.nz0[i] = make_float4(gyro_sb * z0, gyro_sb * z1, gyro_sb * z2, 0.f);
+}
+
 extern "C" int pds_create(const pds_config *cfg, pds_handle **out) {
   if (!cfg || !out) return PDS_EINVAL;
   *out = nullptr;
@@ -357,6 +372,11 @@ extern "C" int pds_create(const pds_config *cfg, pds_handle **out) {
     e = hipMemcpy(h->d_circle_ref, ref, sizeof(ref), hipMemcpyHostToDevice);
   }
   h->st.circle_ref = h->d_circle_ref;
+  if (e == hipSuccess && h->flags.on) {
+    hipLaunchKernelGGL(ctor_noise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, h->st, (long long)n,
+                       (unsigned long long)cfg->env_id_base, h->k.gyro_sb, (uint32_t)cfg->seed, (uint32_t)(cfg->seed >> 32));
+    e = hipDeviceSynchronize();
+  }
   if (e != hipSuccess) {
     snprintf(g_create_err, sizeof(g_create_err), "allocation of %zu envs failed: %s", n, hipGetErrorString(e));
     pds_destroy(h);
