@@ -30,18 +30,29 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--log-dir", default=None)
     args = ap.parse_args()
-    env = pds.make(args.env, num_envs=args.num_envs, seed=args.seed)  # the reference's default config
+    # one process per GPU (the reference: mpi_fork over CPU cores, examples/train_with_multi_cores.py):
+    #   python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/train_ppo.py ...
+    # every rank steps its shard of the envs; gradients and running statistics are averaged over RCCL
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        from phoenix_drone_simulation_amd.sharding import make_sharded
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl")
+        env = make_sharded(args.env, args.num_envs * world, seed=args.seed)
+    else:
+        env = pds.make(args.env, num_envs=args.num_envs, seed=args.seed)  # the reference's default config
     trainer = PPOTrainer(env, rollout_len=args.rollout_len, epochs=args.epochs, seed=args.seed)
     t0 = time.time()
     for e in range(args.epochs):
         i = trainer.learn_one_epoch()
-        if e % max(1, args.epochs // 20) == 0 or e == args.epochs - 1:
+        if rank == 0 and (e % max(1, args.epochs // 20) == 0 or e == args.epochs - 1):
             print(f"epoch {i['epoch']:4d}  EpRet {i['ep_ret']:9.2f}  EpLen {i['ep_len']:6.1f}  FPS {i['fps']:.3e}", flush=True)
     torch.cuda.synchronize()
     print(f"{args.epochs * args.num_envs * args.rollout_len} env-steps in {time.time() - t0:.1f} s")
     ret, length, cost = evaluate(env, trainer.ac, log_dir=args.log_dir)
     print(f"evaluation: mean return {float(ret.mean()):.2f}  mean episode length {float(length.mean()):.1f}  mean cost {float(cost.mean()):.2f}")
-    if args.log_dir:
+    if args.log_dir and rank == 0:
         trainer.save_checkpoint(args.log_dir)          # torch_save/model.pt + model.json (firmware format)
         trainer.write_progress_csv(os.path.join(args.log_dir, "progress.csv"))
         print("saved to", args.log_dir)
