@@ -50,7 +50,7 @@ def main():
             print(f"epoch {i['epoch']:4d}  EpRet {i['ep_ret']:9.2f}  EpLen {i['ep_len']:6.1f}  FPS {i['fps']:.3e}", flush=True)
     torch.cuda.synchronize()
     print(f"{args.epochs * args.num_envs * args.rollout_len} env-steps in {time.time() - t0:.1f} s")
-    ret, length, cost = evaluate(env, trainer.ac, log_dir=args.log_dir)
+    ret, length, cost = evaluate(env, trainer.ac, log_dir=args.log_dir if rank == 0 else None)
     print(f"evaluation: mean return {float(ret.mean()):.2f}  mean episode length {float(length.mean()):.1f}  mean cost {float(cost.mean()):.2f}")
     if args.log_dir and rank == 0:
         trainer.save_checkpoint(args.log_dir)          # torch_save/model.pt + model.json (firmware format)
