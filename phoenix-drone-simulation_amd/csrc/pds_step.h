@@ -505,7 +505,8 @@ __global__ __launch_bounds__(kBlock, PDS_MIN_WAVES) void step_kernel(const StepA
       while (m != 0ull) {
         const int src_lane = __builtin_ctzll(m);
         m &= m - 1ull;
-        if (lane < D) a.final_obs[(wave_base + src_lane) * D + lane] = tile[(src_lane % TR) * D + lane];
+        // non-temporal like the other streamed outputs (same box: 57.7 vs 58.4 us on Hover 2^20)
+        if (lane < D) nt_store(a.final_obs + (wave_base + src_lane) * D + lane, tile[(src_lane % TR) * D + lane]);
       }
       if (MERGED && reset_mask != 0ull) {  // wave-uniform: the reset envs' rows become [o0, u0, o0, u0]
         if (need_reset && (TR == kWave || (lane / TR) == pass)) {
