@@ -73,6 +73,10 @@ def main():
     ap.add_argument("--config", type=int, default=0,
                     help="0: north-star headline (Hover 2^20/GPU); 2/3/4: BASELINE.json configs[1..3]; "
                          "6: Hover 2^20 with the reference's default noise + DR")
+    ap.add_argument("--mode", default="eager", choices=["eager", "graph", "stepk"],
+                    help="eager: one pds_step launch per step (the headline); graph: the same launches captured "
+                         "in ONE hipGraph per ring pass and replayed; stepk: open-loop pds_step_k, --k steps per launch")
+    ap.add_argument("--k", type=int, default=8, help="steps per launch for --mode stepk")
     ap.add_argument("--allgather-obs", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-auto-reset", action="store_true", help="diagnostic only: INVALID as a benchmark number")
@@ -130,8 +134,30 @@ def main():
         return out
 
     env.reset()
-    for s in range(args.warmup):
-        one_step(s)
+    if args.mode != "eager":
+        # diagnostic modes (never the headline `value` of the driver's default run): same env-steps, fewer launches
+        if gathered is not None:
+            raise SystemExit("--mode graph/stepk: no --allgather-obs")
+        K = args.k if args.mode == "stepk" else T
+        if args.steps % K or args.warmup % K:
+            raise SystemExit(f"--steps and --warmup must be multiples of {K} in --mode {args.mode}")
+        if args.mode == "graph":
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for s in range(T):
+                    env.step(ring[s])
+            launch = lambda j: graph.replay()
+        else:
+            assert T % K == 0
+            launch = lambda j: env.step_k(ring[(j * K) % T:(j * K) % T + K])
+        for j in range(args.warmup // K):
+            launch(j)
+    else:
+        K = 1
+        launch = one_step
+        for s in range(args.warmup):
+            one_step(s)
 
     def sync():
         if world > 1:
@@ -142,12 +168,12 @@ def main():
     sync()
     t0 = time.perf_counter()
     ev0.record()  # same stream pds_step launches on (torch's current stream)
-    for s in range(args.steps):
-        one_step(args.warmup + s)
+    for j in range(args.steps // K):
+        launch(args.warmup // K + j)
     ev1.record()
     sync()
     wall = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # average launch-to-launch duration on the stream
+    kernel_ms = ev0.elapsed_time(ev1) / (args.steps // K)  # average launch-to-launch duration on the stream
     if world > 1:
         t = torch.tensor([wall], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -155,8 +181,9 @@ def main():
 
     total_envs = n * world
     value = total_envs * args.steps / wall
-    bytes_per = env.bytes_per_env_step
-    achieved = n * bytes_per / (kernel_ms * 1e-3) / 1e9
+    bytes_per = env.bytes_per_env_step if args.mode != "stepk" else env.bytes_per_env_step_k(K)
+    launch_bytes = n * bytes_per * K  # algorithmic bytes of one launch (graph: one replay = K = 64 step launches)
+    achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
     # HBM bytes per launch measured with the PMC counters (separate rocprofv3 passes,
     # profiles/run_profile.sh) for exactly this workload; null for workloads that were not profiled
     traffic = None
@@ -180,8 +207,9 @@ def main():
                        else f"env-shard x{world} + all-gather(obs)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "pds::step_kernel", "avg_launch_ms": kernel_ms,
-                         "algorithmic_bytes_per_launch": n * bytes_per},
+                         "kernel": "pds::step_kernel" if args.mode != "stepk" else "pds::step_k_kernel",
+                         "avg_launch_ms": kernel_ms, "steps_per_launch": K, "mode": args.mode,
+                         "algorithmic_bytes_per_launch": launch_bytes},
         }
         if not args.no_cpu_baseline and world == 1:
             try:

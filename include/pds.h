@@ -23,6 +23,9 @@
  *                                       compute_history/reward/info/done + TimeLimit truncation
  *   pds_get_state / pds_set_state    <- direct attribute access env.drone.{xyz,rpy,xyz_dot,rpy_dot,x,
  *                                       last_action,...} used by simopt/ and debug/ callers
+ *   pds_step_k                       <- the open-loop replay loop `for i in range(T-1): sim_env.step(acs[i])`
+ *                                       of simopt (simopt/pybullet.py:163-176), K steps per launch
+ *   pds_set_latency                  <- CrazyFlieAgent.set_latency (envs/agents.py:388-404)
  *   pds_destroy                      <- env.close()
  *
  * All pointers named `d_*` are DEVICE pointers on the handle's device; tensors are row-major fp32.
@@ -40,7 +43,7 @@
 extern "C" {
 #endif
 
-#define PDS_VERSION 1
+#define PDS_VERSION 2
 
 #define PDS_TASK_HOVER 0   /* DroneHoverSimpleEnv-v0   */
 #define PDS_TASK_CIRCLE 1  /* DroneCircleSimpleEnv-v0  */
@@ -49,6 +52,9 @@ extern "C" {
 #define PDS_CTRL_PWM 0           /* envs/control.py:91-100  */
 #define PDS_CTRL_ATTITUDE_RATE 1 /* envs/control.py:120-191 */
 #define PDS_CTRL_ATTITUDE 2      /* envs/control.py:194-287 */
+
+#define PDS_MAX_LATENCY_STEPS 8 /* rows of the delayed-action ring: int(latency / time_step) <= 8 */
+#define PDS_MAX_REF_POINTS 300  /* Circle: circle_time * observation_frequency <= 300 (envs/circle.py:49) */
 
 #define PDS_OK 0
 #define PDS_EINVAL -1
@@ -80,6 +86,11 @@ typedef struct pds_config {
   double target_pos[3];
   double init_xyz[3], init_rpy[3], init_xyz_dot[3], init_rpy_dot[3];
   int32_t control_mode;              /* PDS_CTRL_*: 'PWM' (default), 'AttitudeRate', 'Attitude' (envs/control.py) */
+  int32_t use_latency;               /* CrazyFlieAgent(use_latency=...), envs/agents.py:125,165; the Simple agent passes
+                                        False (agents.py:492), simopt flips it through set_latency; default 0 */
+  double latency;                    /* [s] envs/base.py:40 (0.015); buf_size = max(1, latency // time_step) */
+  int32_t observation_frequency;     /* envs/base.py:42 (100): obs_rate = sim_freq // observation_frequency
+                                        (base.py:108) and Circle num_ref_points = 3 * observation_frequency */
   int32_t reserved_;
 } pds_config;
 
@@ -106,12 +117,14 @@ enum pds_field {
   PDS_F_GYRO_LPF = 16,   /* 3  gyro_lpf._x */
   PDS_F_NOISY_OBS = 17,  /* 10 observation_history[-1][0:10]: noisy xyz, quaternion, velocity */
   PDS_F_PID = 18,        /* 12 rate integral3, rate last_error3, attitude integral3, attitude last_error3 */
-  PDS_F_COUNT_ = 19
+  PDS_F_ACTION_BUFFER = 19, /* 32 drone.action_buffer, PDS_MAX_LATENCY_STEPS rows x 4 (rows >= buf_size: 0) */
+  PDS_F_ACTION_IDX = 20,    /* 1  int32: drone.action_idx */
+  PDS_F_COUNT_ = 21
 };
 
 /* Layout of one row of `d_samples` for pds_reset_from_samples (the values np.random returned in
  * the reference's draw order; see oracle/phoenix_oracle.h po_reset_sample). */
-#define PDS_SAMPLE_FLOATS 84
+#define PDS_SAMPLE_FLOATS 112
 #define PDS_S_POS_OFFSET 0 /* 3 */
 #define PDS_S_RPY 3        /* 3 */
 #define PDS_S_VEL 6        /* 3 */
@@ -130,6 +143,9 @@ enum pds_field {
  * each call: PDS_N_OBS_* layout below (24 floats).  Only read when observation_noise > 0. */
 #define PDS_S_NOISE_CALL0 36
 #define PDS_S_NOISE_CALL1 60
+/* use_latency with buf_size B > 1: rows 0..B-2 of np.random.normal(HOVER_ACTION, 0.02, size=(B, 4))
+ * (envs/hover.py:226-228) before clipping; row B-1 is PDS_S_ACTION (it becomes drone.last_action). */
+#define PDS_S_ACTION_BUF 84 /* (PDS_MAX_LATENCY_STEPS - 1) x 4 */
 
 /* Layout of one row of `d_variates` for pds_step_with_variates: the STANDARD variates (z ~ N(0,1),
  * u ~ U[0,1)) one env.step() consumes, in the reference's draw order restricted to the draws whose
@@ -190,6 +206,21 @@ int pds_step_with_variates(pds_handle *h, const float *d_actions, const float *d
                            float *d_reward, uint8_t *d_terminated, uint8_t *d_truncated, float *d_cost,
                            float *d_final_obs, void *stream);
 
+/* K lockstep env.step()s in ONE launch for open-loop action sequences (the replay of recorded actions
+ * in simopt, simopt/pybullet.py:127-183: `for i in range(T-1): sim_env.step(acs[i])`): the env state
+ * stays in registers between the K steps, only actions (in) and observations / rewards / flags (out)
+ * stream through HBM.  Bitwise identical to K pds_step calls.
+ *   d_actions [K,N,4]   d_obs [K,N,D]   d_reward, d_cost [K,N]   d_terminated, d_truncated [K,N] u8
+ *   d_final_obs [K,N,D] or NULL */
+int pds_step_k(pds_handle *h, int k_steps, const float *d_actions, float *d_obs, float *d_reward,
+               uint8_t *d_terminated, uint8_t *d_truncated, float *d_cost, float *d_final_obs, void *stream);
+
+/* CrazyFlieAgent.set_latency (envs/agents.py:388-404; called by simopt/pybullet.py:248): latency <
+ * time_step disables the delay, otherwise buf_size = int(latency / time_step) and the action buffer and
+ * its index are zeroed for every env.  Synchronises the device (not a hot path). */
+int pds_set_latency(pds_handle *h, double latency);
+int pds_latency_steps(const pds_handle *h); /* current buf_size, 0 when use_latency is off */
+
 int pds_field_width(int field);
 int pds_get_state(pds_handle *h, int field, void *d_out, void *stream);
 int pds_set_state(pds_handle *h, int field, const void *d_in, void *stream);
@@ -200,7 +231,13 @@ int pds_set_state(pds_handle *h, int field, const void *d_in, void *stream);
  * step can overflow on envs that never terminate (TakeOff with domain randomisation). */
 int pds_count_nonfinite(pds_handle *h, int64_t *count, void *stream);
 
+/* The tick and the parity of the action ring live in DEVICE memory (one word per 64-env tile, advanced
+ * by the kernels themselves), so no kernel argument changes between two pds_step calls with the same
+ * pointers: a sequence of pds_step / pds_reset calls can be captured into a hipGraph and replayed.
+ * pds_tick returns the host's mirror (exact unless a captured graph was replayed);
+ * pds_sync_tick(h, stream) synchronises `stream`, re-reads the device word and returns it. */
 uint64_t pds_tick(const pds_handle *h);
+uint64_t pds_sync_tick(pds_handle *h, void *stream);
 /* Restore the tick of a checkpoint: a handle created with the same config whose fields were all set
  * with pds_set_state and whose tick was set to the saved one continues the saved run bit for bit
  * (there is no other hidden state: the reference offers no checkpointing of its envs; its trainer
@@ -209,6 +246,8 @@ int pds_set_tick(pds_handle *h, uint64_t tick);
 
 /* Algorithmic HBM bytes one pds_step moves per env for this configuration. */
 int pds_bytes_per_env_step(const pds_handle *h);
+/* the same for pds_step_k with k_steps per launch (state traffic amortised over the K steps) */
+int pds_bytes_per_env_step_k(const pds_handle *h, int k_steps);
 
 const char *pds_last_error(const pds_handle *h);
 

@@ -1,7 +1,8 @@
 """Build libpds_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
-Four translation units (the host API + one per task, each instantiating 32 step / 8 reset kernel
-variants) are compiled in parallel and linked into one shared library."""
+The translation units (the host API, one per (task, variant family) -- each instantiating its step /
+K-step / reset kernel variants -- and the trainer kernels) are compiled in parallel and linked into
+one shared library."""
 import concurrent.futures
 import os
 import shutil
@@ -9,8 +10,9 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-_UNITS = ["pds_api.hip", "pds_task_hover.hip", "pds_task_circle.hip", "pds_task_takeoff.hip", "pds_gae.hip",
-          "pds_mlp.hip", "pds_train.hip"]
+_UNITS = ["pds_task_hover.hip", "pds_task_circle.hip", "pds_task_takeoff.hip", "pds_task_hover_lat.hip",
+          "pds_task_circle_lat.hip", "pds_task_hover_pid.hip", "pds_task_circle_pid.hip", "pds_task_takeoff_lat.hip",
+          "pds_mlp.hip", "pds_api.hip", "pds_gae.hip", "pds_train.hip"]  # longest first
 _HEADERS = ["pds_device.h", "pds_types.h", "pds_reset.h", "pds_step.h"]
 _DEPS = [os.path.join(_CSRC, f) for f in _UNITS + _HEADERS] + [os.path.join(_HERE, "..", "include", "pds.h")]
 _LIB = os.path.join(_HERE, "libpds_hip.so")
@@ -55,7 +57,7 @@ def build_library(force=False, verbose=False, extra_flags=(), out=None):
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
 
-    with concurrent.futures.ThreadPoolExecutor(max_workers=7) as ex:
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
         list(ex.map(compile_unit, zip(_UNITS, objs)))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out + ".tmp"] + objs
     if verbose:

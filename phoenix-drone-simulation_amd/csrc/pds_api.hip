@@ -23,7 +23,6 @@ struct FieldArgs {
   void *user;
   long long n;
   int field;
-  int parity;
   int set;
   int has_motor, has_dr, has_tn, has_on, ctrl;
 };
@@ -35,6 +34,7 @@ __global__ __launch_bounds__(kBlock) void field_kernel(const FieldArgs a) {
   int32_t *ui = reinterpret_cast<int32_t *>(a.user);
   float4 q0 = a.st.s0[i], q1 = a.st.s1[i], q2 = a.st.s2[i];
   const uint32_t c = a.st.ctr[i];
+  const int parity = (int)(a.st.clk[0].z & 1u);  // every tile's clock holds the same value between launches
   switch (a.field) {
     case PDS_F_POS:
       if (a.set) { q0.x = uf[3 * i]; q0.y = uf[3 * i + 1]; q0.z = uf[3 * i + 2]; a.st.s0[i] = q0; }
@@ -68,8 +68,8 @@ __global__ __launch_bounds__(kBlock) void field_kernel(const FieldArgs a) {
       float4 *arr = nullptr;
       float4 dflt = make_float4(0.f, 0.f, 0.f, 0.f);
       if (a.field == PDS_F_MOTOR_X) arr = a.has_motor ? a.st.mx : nullptr;
-      else if (a.field == PDS_F_LAST_ACTION) arr = a.st.hist[a.parity];
-      else if (a.field == PDS_F_PREV_ACTION) arr = a.st.hist[a.parity ^ 1];
+      else if (a.field == PDS_F_LAST_ACTION) arr = a.st.hist[parity];
+      else if (a.field == PDS_F_PREV_ACTION) arr = a.st.hist[parity ^ 1];
       else if (a.field == PDS_F_OU) arr = a.has_tn ? a.st.ou : nullptr;
       else if (a.field == PDS_F_MOTOR_A) { arr = (a.has_motor && a.has_dr) ? a.st.mA : nullptr; dflt = make_float4(a.k.A, a.k.A, a.k.A, a.k.A); }
       else { arr = (a.has_motor && a.has_dr) ? a.st.mK : nullptr; dflt = make_float4(a.k.K, a.k.K, a.k.K, a.k.K); }
@@ -78,15 +78,15 @@ __global__ __launch_bounds__(kBlock) void field_kernel(const FieldArgs a) {
       break;
     }
     case PDS_F_STEP_COUNT:
-      if (a.set) a.st.ctr[i] = ctr_pack((uint32_t)ui[i] & 0xFFFFu, ctr_sign(c), ctr_off(c));
+      if (a.set) a.st.ctr[i] = ctr_pack((uint32_t)ui[i] & 0xFFFFu, ctr_sign(c), ctr_off(c), ctr_lat(c));
       else ui[i] = (int32_t)ctr_step(c);
       break;
     case PDS_F_QUAT_SIGN:
-      if (a.set) a.st.ctr[i] = ctr_pack(ctr_step(c), ui[i] ? 1u : 0u, ctr_off(c));
+      if (a.set) a.st.ctr[i] = ctr_pack(ctr_step(c), ui[i] ? 1u : 0u, ctr_off(c), ctr_lat(c));
       else ui[i] = (int32_t)ctr_sign(c);
       break;
     case PDS_F_REF_OFFSET:
-      if (a.set) a.st.ctr[i] = ctr_pack(ctr_step(c), ctr_sign(c), (uint32_t)ui[i] % 300u);
+      if (a.set) a.st.ctr[i] = ctr_pack(ctr_step(c), ctr_sign(c), (uint32_t)ui[i] % (uint32_t)a.k.ref_points, ctr_lat(c));
       else ui[i] = (int32_t)ctr_off(c);
       break;
     case PDS_F_PARAMS:
@@ -145,8 +145,40 @@ __global__ __launch_bounds__(kBlock) void field_kernel(const FieldArgs a) {
       }
       break;
     }
+    case PDS_F_ACTION_BUFFER:  // drone.action_buffer, rows >= buf_size read as 0 / are ignored
+      for (int b = 0; b < kMaxLatSteps; ++b) {
+        const bool live = a.st.lat != nullptr && b < a.k.lat_steps;
+        if (a.set) {
+          if (live) a.st.lat[(long long)b * a.n + i] = make_float4(uf[32 * i + 4 * b], uf[32 * i + 4 * b + 1], uf[32 * i + 4 * b + 2], uf[32 * i + 4 * b + 3]);
+        } else {
+          const float4 v = live ? a.st.lat[(long long)b * a.n + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+          uf[32 * i + 4 * b] = v.x; uf[32 * i + 4 * b + 1] = v.y; uf[32 * i + 4 * b + 2] = v.z; uf[32 * i + 4 * b + 3] = v.w;
+        }
+      }
+      break;
+    case PDS_F_ACTION_IDX:
+      if (a.set) a.st.ctr[i] = ctr_pack(ctr_step(c), ctr_sign(c), ctr_off(c), a.k.lat_steps > 0 ? (uint32_t)ui[i] % (uint32_t)a.k.lat_steps : 0u);
+      else ui[i] = (int32_t)ctr_lat(c);
+      break;
     default: break;
   }
+}
+
+// pds_set_tick / pds_create: every tile's clock word <- (tick, parity kept or 0)
+__global__ __launch_bounds__(256) void clock_fill_kernel(WaveClock *clk, long long ntiles, unsigned long long tick, int keep_parity) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ntiles) return;
+  const uint32_t par = keep_parity ? (clk[t].z & 1u) : 0u;
+  clk[t] = make_uint4((uint32_t)tick, (uint32_t)(tick >> 32), par, 0u);
+}
+
+// pds_set_latency: action buffer and index of every env <- 0 (envs/agents.py:403-404)
+__global__ __launch_bounds__(256) void latency_clear_kernel(DevState st, long long n, int rows) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int b = 0; b < rows; ++b) st.lat[(long long)b * n + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const uint32_t c = st.ctr[i];
+  st.ctr[i] = ctr_pack(ctr_step(c), ctr_sign(c), ctr_off(c), 0u);
 }
 
 }  // namespace pds
@@ -164,11 +196,31 @@ struct pds_handle {
   int force_tile = 0;  // PDS_FORCE_TILE=half|full (tests / A-B runs): 1 half, 2 full, 0 pick per launch
   float2 *d_circle_ref;
   void *slab;  // one allocation holds every state array (staggered, see pds_create)
+  float4 *lat_buf;  // [PDS_MAX_LATENCY_STEPS][N] delayed-action ring, allocated when latency is first enabled
+  unsigned long long *d_count;  // pds_count_nonfinite result word (in the slab)
+  unsigned long long *d_stamps;  // diagnostic builds: pds_debug_stamps
   int obs_dim;
-  int parity;
-  uint64_t tick;
+  int num_cus;    // hipDeviceProp.multiProcessorCount (256 on MI355X): drives the half-tile rule
+  uint64_t tick;  // host mirror of the device clock words (pds_sync_tick refreshes it)
   bool was_reset;
   char err[512];
+};
+
+// Every entry point runs on the handle's device and leaves the caller's current device as it found it.
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int dev) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != dev) {
+      err = hipSetDevice(dev);
+      switched = err == hipSuccess;
+    }
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
 };
 
 static int fail(pds_handle *h, int code, const char *fmt, ...) {
@@ -221,7 +273,31 @@ extern "C" int pds_default_config(int task, pds_config *c) {
   c->target_pos[2] = 1.0;
   c->init_xyz[2] = (task == PDS_TASK_TAKEOFF) ? (double)0.0125f : 1.0;
   c->control_mode = PDS_CTRL_PWM;
+  c->use_latency = 0;          // CrazyFlieSimpleAgent: use_latency=False (envs/agents.py:492)
+  c->latency = 0.015;          // envs/base.py:40
+  c->observation_frequency = 100;  // envs/base.py:42
   return PDS_OK;
+}
+
+// buf_size of the delayed-action ring: ctor form max(1, int(LATENCY // time_step)) (envs/agents.py:180),
+// set_latency form int(latency / TIME_STEP) (envs/agents.py:401); 0 = no delay
+static int latency_steps_ctor(double latency, double time_step) {
+  if (!(latency >= time_step)) return 0;  // use_latency if latency >= time_step else False, agents.py:165
+  const int b = (int)floor(latency / time_step);  // Python's float // float
+  return b < 1 ? 1 : b;
+}
+
+static void set_latency_consts(Consts &k, int lat_steps, int agg) {
+  k.lat_steps = lat_steps;
+  k.lat_own1 = k.lat_own2 = 0;
+  if (lat_steps > 0) {
+    // the row action_buffer[-1] is rewritten by every lat_steps-th apply_action; after env.step s
+    // (agg sub-steps each) it holds the action of step ceil(m / agg), m = floor(s agg / B) B (0: reset row)
+    for (int s = 1; s <= 2; ++s) {
+      const int m = (s * agg / lat_steps) * lat_steps;
+      (s == 1 ? k.lat_own1 : k.lat_own2) = (m + agg - 1) / agg;
+    }
+  }
 }
 
 static void fill_consts(const pds_config &c, Consts &k) {
@@ -266,6 +342,8 @@ static void fill_consts(const pds_config &c, Consts &k) {
   k.gyro_to = (float)(5 * D2R);
   k.agg = c.aggregate_phy_steps; k.max_steps = c.max_episode_steps;
   k.reset_dist = c.enable_reset_distribution ? 1 : 0;
+  k.ref_points = (c.task == PDS_TASK_CIRCLE) ? 3 * c.observation_frequency : kRefPoints;  // envs/circle.py:47-49
+  set_latency_consts(k, c.use_latency ? latency_steps_ctor(c.latency, c.time_step) : 0, c.aggregate_phy_steps);
 }
 
 static int obs_dim_of(const pds_config &c) {
@@ -290,30 +368,62 @@ __global__ __launch_bounds__(256) void ctor_noise_kernel(DevState st, long long 
   st.nz0[i] = make_float4(gyro_sb * z0, gyro_sb * z1, gyro_sb * z2, 0.f);
 }
 
+#define PDS_CREATE_FAIL(code, ...)                                   \
+  do {                                                               \
+    snprintf(g_create_err, sizeof(g_create_err), __VA_ARGS__);       \
+    return code;                                                     \
+  } while (0)
+
+static int ensure_latency_buffer(pds_handle *h) {
+  if (h->lat_buf) return PDS_OK;
+  const size_t bytes = (size_t)kMaxLatSteps * (size_t)h->cfg.num_envs * sizeof(float4);
+  hipError_t e = hipMalloc((void **)&h->lat_buf, bytes);
+  if (e == hipSuccess) e = hipMemset(h->lat_buf, 0, bytes);
+  if (e != hipSuccess) {
+    h->lat_buf = nullptr;
+    return fail(h, e == hipErrorOutOfMemory ? PDS_ENOMEM : PDS_EHIP, "latency buffer (%zu bytes): %s", bytes, hipGetErrorString(e));
+  }
+  h->st.lat = h->lat_buf;
+  return PDS_OK;
+}
+
 extern "C" int pds_create(const pds_config *cfg, pds_handle **out) {
   if (!cfg || !out) return PDS_EINVAL;
   *out = nullptr;
-  if (cfg->struct_size != (int32_t)sizeof(pds_config)) { snprintf(g_create_err, sizeof(g_create_err), "pds_config size mismatch"); return PDS_EINVAL; }
+  if (cfg->struct_size != (int32_t)sizeof(pds_config)) PDS_CREATE_FAIL(PDS_EINVAL, "pds_config size mismatch (built against another pds.h?)");
   if (cfg->task < 0 || cfg->task > 2 || cfg->num_envs < 1 || cfg->aggregate_phy_steps < 1 ||
-      cfg->max_episode_steps < 1 || cfg->max_episode_steps > 65535 || cfg->time_step <= 0 ||
-      cfg->num_envs > (1ll << 30)) {  // the Philox counter carries a 32-bit global env id
-    snprintf(g_create_err, sizeof(g_create_err), "invalid pds_config");
-    return PDS_EINVAL;
+      cfg->max_episode_steps < 1 || cfg->max_episode_steps > 65535 || cfg->time_step <= 0)
+    PDS_CREATE_FAIL(PDS_EINVAL, "invalid pds_config (task, num_envs, aggregate_phy_steps, max_episode_steps or time_step)");
+  if (cfg->num_envs > (1ll << 30)) PDS_CREATE_FAIL(PDS_EINVAL, "num_envs %lld exceeds 2^30 per handle", (long long)cfg->num_envs);
+  // the Philox counter carries a 32-bit global env id
+  if (cfg->env_id_base < 0 || cfg->env_id_base + cfg->num_envs > (1ll << 32))
+    PDS_CREATE_FAIL(PDS_EINVAL, "env_id_base %lld + num_envs %lld leaves the 32-bit global env id range [0, 2^32)",
+                    (long long)cfg->env_id_base, (long long)cfg->num_envs);
+  if (cfg->device < 0) PDS_CREATE_FAIL(PDS_EINVAL, "device %d is negative", cfg->device);
+  if (cfg->control_mode < 0 || cfg->control_mode > 2) PDS_CREATE_FAIL(PDS_EINVAL, "control_mode %d", cfg->control_mode);
+  if (cfg->control_mode != PDS_CTRL_PWM && (cfg->task == PDS_TASK_TAKEOFF || cfg->use_ground_effect))
+    PDS_CREATE_FAIL(PDS_EUNSUPPORTED, "control_mode %d: the PID modes exist for Hover/Circle without the ground-effect extension", cfg->control_mode);
+  if (cfg->observation_frequency < 1) PDS_CREATE_FAIL(PDS_EINVAL, "observation_frequency %d", cfg->observation_frequency);
+  if (cfg->task == PDS_TASK_CIRCLE && 3 * cfg->observation_frequency > PDS_MAX_REF_POINTS)
+    PDS_CREATE_FAIL(PDS_EUNSUPPORTED, "Circle with observation_frequency %d needs %d reference points (limit %d)",
+                    cfg->observation_frequency, 3 * cfg->observation_frequency, PDS_MAX_REF_POINTS);
+  if (cfg->observation_noise > 0) {
+    // obs_rate = sim_freq // observation_frequency (envs/base.py:108)
+    const int sim_freq = (int)llround(1.0 / cfg->time_step);
+    const int obs_rate = sim_freq / cfg->observation_frequency;
+    if (obs_rate < 1) PDS_CREATE_FAIL(PDS_EINVAL, "observation_frequency %d above sim_freq %d: obs_rate 0 (the reference divides by it)", cfg->observation_frequency, sim_freq);
+    if (obs_rate != 1)
+      PDS_CREATE_FAIL(PDS_EUNSUPPORTED, "observation noise with obs_rate %d != 1 (Kalman-hold branch of compute_observation) is not built", obs_rate);
   }
-  if (cfg->control_mode < 0 || cfg->control_mode > 2 ||
-      (cfg->control_mode != PDS_CTRL_PWM && (cfg->task == PDS_TASK_TAKEOFF || cfg->use_ground_effect))) {
-    snprintf(g_create_err, sizeof(g_create_err),
-             "control_mode %d: the PID modes exist for Hover/Circle without the ground-effect extension", cfg->control_mode);
-    return cfg->control_mode < 0 || cfg->control_mode > 2 ? PDS_EINVAL : PDS_EUNSUPPORTED;
-  }
+  const int lat_steps = cfg->use_latency ? latency_steps_ctor(cfg->latency, cfg->time_step) : 0;
+  if (lat_steps > kMaxLatSteps) PDS_CREATE_FAIL(PDS_EUNSUPPORTED, "latency %g s = %d steps (limit %d)", cfg->latency, lat_steps, kMaxLatSteps);
+  if (cfg->use_latency && cfg->use_ground_effect) PDS_CREATE_FAIL(PDS_EUNSUPPORTED, "use_latency with the ground-effect extension is not built");
   int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device >= ndev) {
-    snprintf(g_create_err, sizeof(g_create_err), "no HIP device %d (found %d); there is no CPU fallback", cfg->device, ndev);
-    return PDS_ENODEVICE;
-  }
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device >= ndev)
+    PDS_CREATE_FAIL(PDS_ENODEVICE, "no HIP device %d (found %d); there is no CPU fallback", cfg->device, ndev);
   pds_handle *h = new (std::nothrow) pds_handle();
   if (!h) return PDS_ENOMEM;
-  memset(h, 0, sizeof(*h));
+  memset((void *)h, 0, sizeof(*h));
   h->cfg = *cfg;
   fill_consts(*cfg, h->k);
   h->obs_dim = obs_dim_of(*cfg);
@@ -323,11 +433,19 @@ extern "C" int pds_create(const pds_config *cfg, pds_handle **out) {
   h->flags.tn = cfg->motor_thrust_noise > 0;
   h->flags.on = cfg->observation_noise > 0;
   h->flags.ctrl = cfg->control_mode;
+  h->flags.lat = lat_steps > 0;
   h->flags.half_tile = false;
   if (const char *ft = getenv("PDS_FORCE_TILE")) h->force_tile = (ft[0] == 'h') ? 1 : ((ft[0] == 'f') ? 2 : 0);
   const size_t n = (size_t)cfg->num_envs;
+  const size_t ntiles = (n + kWave - 1) / kWave;
   const LaunchFlags &f = h->flags;
-  hipError_t e = hipSetDevice(cfg->device);
+  DeviceGuard guard(cfg->device);
+  hipError_t e = guard.err;
+  if (e == hipSuccess) {
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, cfg->device);
+    h->num_cus = (e == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
   // All state arrays live in ONE slab (one allocation, one free, contiguous pages); consecutive arrays
   // are staggered by an odd multiple of 256 B so that the 6-21 concurrent streams of the step kernel do
   // not start at the same offset modulo a power of two (measured neutral on MI355X: 62.4-63.7 us for
@@ -337,6 +455,8 @@ extern "C" int pds_create(const pds_config *cfg, pds_handle **out) {
   alloc((void **)&h->st.s0, n * 16); alloc((void **)&h->st.s1, n * 16); alloc((void **)&h->st.s2, n * 16);
   alloc((void **)&h->st.hist[0], n * 16); alloc((void **)&h->st.hist[1], n * 16);
   alloc((void **)&h->st.ctr, n * 4);
+  alloc((void **)&h->st.clk, ntiles * sizeof(WaveClock));
+  alloc((void **)&h->d_count, 256);
   if (f.motor) alloc((void **)&h->st.mx, n * 16);
   if (f.dr) { alloc((void **)&h->st.par0, n * 16); alloc((void **)&h->st.par1, n * 8); }
   if (f.dr && f.motor) { alloc((void **)&h->st.mA, n * 16); alloc((void **)&h->st.mK, n * 16); }
@@ -358,14 +478,15 @@ extern "C" int pds_create(const pds_config *cfg, pds_handle **out) {
       total += req[j].second;
     }
     if (e == hipSuccess) e = hipMalloc(&h->slab, total + 256);
-    if (e == hipSuccess) e = hipMemset(h->slab, 0, total + 256);
+    if (e == hipSuccess) e = hipMemset(h->slab, 0, total + 256);  // tick 0, parity 0, OU / PID / stale-rate state 0
     if (e == hipSuccess)
       for (size_t j = 0; j < req.size(); ++j) *req[j].first = (char *)h->slab + off[j];
   }
   if (e == hipSuccess) {
     float2 ref[kRefPoints];  // envs/circle.py:45-56
+    const int np = h->k.ref_points;
     for (int t = 0; t < kRefPoints; ++t) {
-      const double ts = 2 * M_PI * (double)t / kRefPoints;
+      const double ts = 2 * M_PI * (double)(t % np) / np;
       ref[t].x = (float)(0.25 * (1 - cos(ts)));
       ref[t].y = (float)(0.25 * sin(ts));
     }
@@ -375,12 +496,23 @@ extern "C" int pds_create(const pds_config *cfg, pds_handle **out) {
   if (e == hipSuccess && h->flags.on) {
     hipLaunchKernelGGL(ctor_noise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, h->st, (long long)n,
                        (unsigned long long)cfg->env_id_base, h->k.gyro_sb, (uint32_t)cfg->seed, (uint32_t)(cfg->seed >> 32));
-    e = hipDeviceSynchronize();
+    e = hipGetLastError();
   }
+  // The zero fill and the constructor draw ran on the null stream; the caller's stream may be a
+  // non-blocking one that is not ordered behind it, so the state is made visible here, always.
+  if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e != hipSuccess) {
     snprintf(g_create_err, sizeof(g_create_err), "allocation of %zu envs failed: %s", n, hipGetErrorString(e));
     pds_destroy(h);
     return e == hipErrorOutOfMemory ? PDS_ENOMEM : PDS_EHIP;
+  }
+  if (h->flags.lat) {
+    const int rc = ensure_latency_buffer(h);
+    if (rc != PDS_OK) {
+      snprintf(g_create_err, sizeof(g_create_err), "%s", h->err);
+      pds_destroy(h);
+      return rc;
+    }
   }
   *out = h;
   return PDS_OK;
@@ -388,8 +520,10 @@ extern "C" int pds_create(const pds_config *cfg, pds_handle **out) {
 
 extern "C" int pds_destroy(pds_handle *h) {
   if (!h) return PDS_OK;
-  (void)hipSetDevice(h->cfg.device);
+  DeviceGuard guard(h->cfg.device);
   if (h->slab) (void)hipFree(h->slab);
+  if (h->lat_buf) (void)hipFree(h->lat_buf);
+  if (h->d_stamps) (void)hipFree(h->d_stamps);
   delete h;
   return PDS_OK;
 }
@@ -397,17 +531,66 @@ extern "C" int pds_destroy(pds_handle *h) {
 extern "C" int pds_obs_dim(const pds_handle *h) { return h ? h->obs_dim : PDS_EINVAL; }
 extern "C" int64_t pds_num_envs(const pds_handle *h) { return h ? h->cfg.num_envs : PDS_EINVAL; }
 extern "C" uint64_t pds_tick(const pds_handle *h) { return h ? h->tick : 0; }
+extern "C" int pds_latency_steps(const pds_handle *h) { return h ? h->k.lat_steps : PDS_EINVAL; }
+extern "C" const char *pds_last_error(const pds_handle *h) { return h ? h->err : g_create_err; }
+
+extern "C" uint64_t pds_sync_tick(pds_handle *h, void *stream) {
+  if (!h) return 0;
+  DeviceGuard guard(h->cfg.device);
+  WaveClock c;
+  if (hipStreamSynchronize((hipStream_t)stream) == hipSuccess &&
+      hipMemcpy(&c, h->st.clk, sizeof(c), hipMemcpyDeviceToHost) == hipSuccess)
+    h->tick = ((uint64_t)c.y << 32) | c.x;
+  return h->tick;
+}
+
 extern "C" int pds_set_tick(pds_handle *h, uint64_t tick) {
   if (!h) return PDS_EINVAL;
+  DeviceGuard guard(h->cfg.device);
+  PDS_HIP(h, guard.err);
+  PDS_HIP(h, hipDeviceSynchronize());  // no stream argument: order behind everything in flight
+  const long long ntiles = (h->cfg.num_envs + kWave - 1) / kWave;
+  hipLaunchKernelGGL(clock_fill_kernel, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, 0, h->st.clk, ntiles,
+                     (unsigned long long)tick, 1);
+  PDS_HIP(h, hipGetLastError());
+  PDS_HIP(h, hipDeviceSynchronize());
   h->tick = tick;
   return PDS_OK;
 }
-extern "C" const char *pds_last_error(const pds_handle *h) { return h ? h->err : g_create_err; }
+
+// CrazyFlieAgent.set_latency, envs/agents.py:388-404
+extern "C" int pds_set_latency(pds_handle *h, double latency) {
+  if (!h) return PDS_EINVAL;
+  if (h->flags.ge) return fail(h, PDS_EUNSUPPORTED, "use_latency with the ground-effect extension is not built");
+  int steps = 0;
+  if (!(latency < h->cfg.time_step)) {
+    steps = (int)(latency / h->cfg.time_step);  // int(self.latency / self.TIME_STEP)
+    if (steps < 1) return fail(h, PDS_EINVAL, "latency %g: buf_size 0 (the reference asserts buf_size > 0)", latency);
+    if (steps > kMaxLatSteps) return fail(h, PDS_EUNSUPPORTED, "latency %g s = %d steps (limit %d)", latency, steps, kMaxLatSteps);
+  }
+  DeviceGuard guard(h->cfg.device);
+  PDS_HIP(h, guard.err);
+  PDS_HIP(h, hipDeviceSynchronize());
+  h->cfg.latency = latency;
+  h->cfg.use_latency = steps > 0;
+  h->flags.lat = steps > 0;
+  set_latency_consts(h->k, steps, h->cfg.aggregate_phy_steps);
+  if (steps > 0) {
+    const int rc = ensure_latency_buffer(h);
+    if (rc != PDS_OK) return rc;
+    const long long n = h->cfg.num_envs;
+    hipLaunchKernelGGL(latency_clear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, h->st, n, kMaxLatSteps);
+    PDS_HIP(h, hipGetLastError());
+    PDS_HIP(h, hipDeviceSynchronize());
+  }
+  return PDS_OK;
+}
 
 // read action 16 + dyn state 48 + action history 32 + counter 4; write dyn state 48
 // + newest history slot 16 + counter 4 + reward 4 + cost 4 + terminated 1 + truncated 1; obs 4*D;
 // DR params +24; motor PT1: x R+W 32 (+ A, K 32 when randomised); OU state R+W 32; gyro bias +
-// low-pass R+W 48; kept noisy observation (10 floats) R+W 80.
+// low-pass R+W 48; kept noisy observation (10 floats) R+W 80; latency ring: one row R+W per physics
+// sub-step.  (The per-tile clock word adds 0.5 B per env-step and is not counted.)
 extern "C" int pds_bytes_per_env_step(const pds_handle *h) {
   if (!h) return PDS_EINVAL;
   int b = 100 + 78 + 4 * h->obs_dim;
@@ -419,7 +602,19 @@ extern "C" int pds_bytes_per_env_step(const pds_handle *h) {
   if (f.on) b += 48 + 80;
   if (f.ctrl >= 1) b += 48;  // rate-PID integral + last error, R+W
   if (f.ctrl == 2) b += 48;  // attitude-PID integral + last error, R+W
+  if (f.lat) b += 32 * h->cfg.aggregate_phy_steps;
   return b;
+}
+
+// Algorithmic bytes per env-step of pds_step_k: the env state is read and written once per launch.
+extern "C" int pds_bytes_per_env_step_k(const pds_handle *h, int k_steps) {
+  if (!h || k_steps < 1) return PDS_EINVAL;
+  const LaunchFlags &f = h->flags;
+  const int full = pds_bytes_per_env_step(h);
+  const int stream = 16 + 4 * h->obs_dim + 10 + (f.lat ? 32 * h->cfg.aggregate_phy_steps : 0);
+  // once per launch: the state read + written, both ring slots and the randomised parameters written back
+  const int state = full - stream + 16 + (f.dr ? 24 : 0) + (f.dr && f.motor ? 32 : 0);
+  return stream + (state + k_steps - 1) / k_steps;
 }
 
 static void base_args(pds_handle *h, StepArgs &a) {
@@ -429,24 +624,36 @@ static void base_args(pds_handle *h, StepArgs &a) {
   a.n = h->cfg.num_envs;
   a.env_id_base = (unsigned long long)h->cfg.env_id_base;
   a.seed_lo = (uint32_t)h->cfg.seed; a.seed_hi = (uint32_t)(h->cfg.seed >> 32);
-  a.tick_lo = (uint32_t)h->tick; a.tick_hi = (uint32_t)(h->tick >> 32);
-  a.parity = h->parity;
   a.auto_reset = h->cfg.auto_reset;
+  a.k_steps = 1;
+  a.stamps = h->d_stamps;
+}
+
+static void launch_family(pds_handle *h, int kind, const LaunchFlags &lf, dim3 grid, hipStream_t s, const StepArgs &a) {
+  const int task = h->cfg.task;
+  if (lf.lat) {
+    if (task == PDS_TASK_HOVER) launch_hover_lat(kind, lf, grid, s, a);
+    else if (task == PDS_TASK_CIRCLE) launch_circle_lat(kind, lf, grid, s, a);
+    else launch_takeoff_lat(kind, lf, grid, s, a);
+  } else if (lf.ctrl != 0 && kind != kLaunchReset) {
+    if (task == PDS_TASK_HOVER) launch_hover_pid(kind, lf, grid, s, a);
+    else launch_circle_pid(kind, lf, grid, s, a);
+  } else {
+    if (task == PDS_TASK_HOVER) launch_hover(kind, lf, grid, s, a);
+    else if (task == PDS_TASK_CIRCLE) launch_circle(kind, lf, grid, s, a);
+    else launch_takeoff(kind, lf, grid, s, a);
+  }
 }
 
 static int do_reset(pds_handle *h, const uint8_t *d_mask, const float *d_samples, float *d_obs, void *stream) {
   if (!h) return PDS_EINVAL;
-  PDS_HIP(h, hipSetDevice(h->cfg.device));
+  DeviceGuard guard(h->cfg.device);
+  PDS_HIP(h, guard.err);
   StepArgs a;
   base_args(h, a);
   a.mask = d_mask; a.samples = d_samples; a.obs = d_obs;
   const dim3 grid((unsigned)((a.n + kBlock - 1) / kBlock));
-  hipStream_t s = (hipStream_t)stream;
-  switch (h->cfg.task) {
-    case PDS_TASK_HOVER: launch_reset_hover(h->flags, grid, s, a); break;
-    case PDS_TASK_CIRCLE: launch_reset_circle(h->flags, grid, s, a); break;
-    default: launch_reset_takeoff(h->flags, grid, s, a); break;
-  }
+  launch_family(h, kLaunchReset, h->flags, grid, (hipStream_t)stream, a);
   PDS_HIP(h, hipGetLastError());
   h->tick += 1;
   h->was_reset = true;
@@ -463,18 +670,25 @@ extern "C" int pds_reset_from_samples(pds_handle *h, const uint8_t *d_mask, cons
   return do_reset(h, d_mask, d_samples, d_obs, stream);
 }
 
+static int check_step_pointers(pds_handle *h, const float *d_actions, float *d_obs, float *d_reward, uint8_t *d_terminated,
+                               uint8_t *d_truncated, float *d_cost) {
+  if (!d_actions || !d_obs || !d_reward || !d_terminated || !d_truncated || !d_cost)
+    return fail(h, PDS_EINVAL, "pds_step: NULL tensor pointer");
+  if (((uintptr_t)d_actions) & 15u) return fail(h, PDS_EINVAL, "pds_step: d_actions must be 16-byte aligned");
+  if (((uintptr_t)d_obs) & 3u) return fail(h, PDS_EINVAL, "pds_step: d_obs must be 4-byte aligned (16 for full speed)");
+  if (!h->was_reset) return fail(h, PDS_EINVAL, "pds_step before pds_reset");
+  return PDS_OK;
+}
+
 extern "C" int pds_step_with_variates(pds_handle *h, const float *d_actions, const float *d_variates,
                                       float *d_obs, float *d_reward, uint8_t *d_terminated,
                                       uint8_t *d_truncated, float *d_cost, float *d_final_obs, void *stream) {
   if (!h) return PDS_EINVAL;
-  if (!d_actions || !d_obs || !d_reward || !d_terminated || !d_truncated || !d_cost)
-    return fail(h, PDS_EINVAL, "pds_step: NULL tensor pointer");
-  if ((((uintptr_t)d_actions) | ((uintptr_t)d_obs)) & 15u)
-    return fail(h, PDS_EINVAL, "pds_step: d_actions and d_obs must be 16-byte aligned");
-  if (!h->was_reset) return fail(h, PDS_EINVAL, "pds_step before pds_reset");
+  if (const int rc = check_step_pointers(h, d_actions, d_obs, d_reward, d_terminated, d_truncated, d_cost)) return rc;
   if (d_variates && h->cfg.aggregate_phy_steps != 1)
     return fail(h, PDS_EUNSUPPORTED, "injected noise variates need aggregate_phy_steps == 1");
-  PDS_HIP(h, hipSetDevice(h->cfg.device));
+  DeviceGuard guard(h->cfg.device);  // (no hipSetDevice when the caller is already on the device)
+  PDS_HIP(h, guard.err);
   StepArgs a;
   base_args(h, a);
   a.actions = reinterpret_cast<const float4 *>(d_actions);
@@ -483,22 +697,17 @@ extern "C" int pds_step_with_variates(pds_handle *h, const float *d_actions, con
   a.noise = d_variates;
   // one 256-env block per 4 tiles
   const dim3 grid((unsigned)((a.n + kBlock - 1) / kBlock));
-  hipStream_t s = (hipStream_t)stream;
   // half observation tile (4 resident blocks per CU instead of 3) while the grid is between one and
   // about 2.7 rounds of the full-tile residency; see pds_types.h kHalfTileRows
   LaunchFlags lf = h->flags;
-  // (variants that reset in registers on the full tile -- pds_step.h MERGED -- gain less from the half
-  // tile: it wins up to 5 blocks per CU there, up to 8 for the others; profiles/r01_tile_rows.txt)
-  const bool merged = !lf.on && !(lf.motor && lf.dr) && h->cfg.task != PDS_TASK_TAKEOFF && h->cfg.auto_reset;
-  lf.half_tile = grid.x > (unsigned)(kFullTileBlocksPerCU * kCUs) && grid.x <= (unsigned)((merged ? 5 : 8) * kCUs);
+  // (variants that reset in registers on the full tile -- pds_step.h merged_reset_variant -- gain less
+  // from the half tile: it wins up to 5 blocks per CU there, up to 8 for the others; profiles/r01_tile_rows.txt)
+  const bool merged = !lf.on && !lf.lat && !(lf.motor && lf.dr) && h->cfg.task != PDS_TASK_TAKEOFF && h->cfg.auto_reset;
+  const unsigned cus = (unsigned)h->num_cus;
+  lf.half_tile = grid.x > (unsigned)kFullTileBlocksPerCU * cus && grid.x <= (merged ? 5u : 8u) * cus;
   if (h->force_tile) lf.half_tile = h->force_tile == 1;
-  switch (h->cfg.task) {
-    case PDS_TASK_HOVER: launch_step_hover(lf, grid, s, a); break;
-    case PDS_TASK_CIRCLE: launch_step_circle(lf, grid, s, a); break;
-    default: launch_step_takeoff(lf, grid, s, a); break;
-  }
+  launch_family(h, kLaunchStep, lf, grid, (hipStream_t)stream, a);
   PDS_HIP(h, hipGetLastError());
-  h->parity ^= 1;
   h->tick += 1;
   return PDS_OK;
 }
@@ -510,15 +719,50 @@ extern "C" int pds_step(pds_handle *h, const float *d_actions, float *d_obs, flo
                                 d_final_obs, stream);
 }
 
+extern "C" int pds_step_k(pds_handle *h, int k_steps, const float *d_actions, float *d_obs, float *d_reward,
+                          uint8_t *d_terminated, uint8_t *d_truncated, float *d_cost, float *d_final_obs, void *stream) {
+  if (!h) return PDS_EINVAL;
+  if (k_steps < 1) return fail(h, PDS_EINVAL, "pds_step_k: k_steps %d", k_steps);
+  if (const int rc = check_step_pointers(h, d_actions, d_obs, d_reward, d_terminated, d_truncated, d_cost)) return rc;
+  const long long n = h->cfg.num_envs;
+  const int D = h->obs_dim;
+  if (h->flags.ctrl != 0) {
+    // PID control modes (no K-step kernel): K single-step launches, same results
+    for (int s = 0; s < k_steps; ++s) {
+      const long long o1 = (long long)s * n;
+      const int rc = pds_step(h, d_actions + o1 * 4, d_obs + o1 * D, d_reward + o1, d_terminated + o1, d_truncated + o1,
+                              d_cost + o1, d_final_obs ? d_final_obs + o1 * D : nullptr, stream);
+      if (rc != PDS_OK) return rc;
+    }
+    return PDS_OK;
+  }
+  DeviceGuard guard(h->cfg.device);
+  PDS_HIP(h, guard.err);
+  StepArgs a;
+  base_args(h, a);
+  a.actions = reinterpret_cast<const float4 *>(d_actions);
+  a.obs = d_obs; a.reward = d_reward; a.term = d_terminated; a.trunc = d_truncated; a.cost = d_cost;
+  a.final_obs = d_final_obs;
+  a.k_steps = k_steps;
+  const dim3 grid((unsigned)((a.n + kBlock - 1) / kBlock));
+  LaunchFlags lf = h->flags;
+  lf.half_tile = false;
+  launch_family(h, kLaunchStepK, lf, grid, (hipStream_t)stream, a);
+  PDS_HIP(h, hipGetLastError());
+  h->tick += (uint64_t)k_steps;
+  return PDS_OK;
+}
+
 extern "C" int pds_field_width(int field) {
   switch (field) {
     case PDS_F_POS: case PDS_F_RPY: case PDS_F_VEL: case PDS_F_OMEGA: case PDS_F_GYRO_BIAS: case PDS_F_GYRO_LPF: return 3;
     case PDS_F_QUAT: case PDS_F_MOTOR_X: case PDS_F_LAST_ACTION: case PDS_F_PREV_ACTION: case PDS_F_MOTOR_A:
     case PDS_F_MOTOR_K: case PDS_F_OU: return 4;
-    case PDS_F_STEP_COUNT: case PDS_F_QUAT_SIGN: case PDS_F_REF_OFFSET: return 1;
+    case PDS_F_STEP_COUNT: case PDS_F_QUAT_SIGN: case PDS_F_REF_OFFSET: case PDS_F_ACTION_IDX: return 1;
     case PDS_F_PARAMS: return 6;
     case PDS_F_NOISY_OBS: return 10;
     case PDS_F_PID: return 12;
+    case PDS_F_ACTION_BUFFER: return 4 * kMaxLatSteps;
     default: return PDS_EINVAL;
   }
 }
@@ -540,10 +784,11 @@ static int do_field(pds_handle *h, int field, void *d_ptr, int set, void *stream
   if (!h) return PDS_EINVAL;
   if (!d_ptr || pds_field_width(field) < 0) return fail(h, PDS_EINVAL, "bad field %d or NULL pointer", field);
   if (set && field == PDS_F_QUAT) return fail(h, PDS_EINVAL, "PDS_F_QUAT is derived (set PDS_F_RPY / PDS_F_QUAT_SIGN)");
-  PDS_HIP(h, hipSetDevice(h->cfg.device));
+  DeviceGuard guard(h->cfg.device);
+  PDS_HIP(h, guard.err);
   FieldArgs a;
   memset(&a, 0, sizeof(a));
-  a.st = h->st; a.k = h->k; a.user = d_ptr; a.n = h->cfg.num_envs; a.field = field; a.parity = h->parity; a.set = set;
+  a.st = h->st; a.k = h->k; a.user = d_ptr; a.n = h->cfg.num_envs; a.field = field; a.set = set;
   a.has_motor = h->flags.motor; a.has_dr = h->flags.dr; a.has_tn = h->flags.tn; a.has_on = h->flags.on; a.ctrl = h->flags.ctrl;
   const dim3 grid((unsigned)((a.n + kBlock - 1) / kBlock));
   hipLaunchKernelGGL(field_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, a);
@@ -554,20 +799,42 @@ static int do_field(pds_handle *h, int field, void *d_ptr, int set, void *stream
 
 extern "C" int pds_count_nonfinite(pds_handle *h, int64_t *count, void *stream) {
   if (!h || !count) return PDS_EINVAL;
-  PDS_HIP(h, hipSetDevice(h->cfg.device));
+  DeviceGuard guard(h->cfg.device);
+  PDS_HIP(h, guard.err);
   hipStream_t s = (hipStream_t)stream;
-  unsigned long long *d = nullptr;
-  PDS_HIP(h, hipMalloc(&d, sizeof(*d)));
-  PDS_HIP(h, hipMemsetAsync(d, 0, sizeof(*d), s));
+  PDS_HIP(h, hipMemsetAsync(h->d_count, 0, sizeof(*h->d_count), s));  // handle-owned word: nothing to free
   const long long n = h->cfg.num_envs;
-  hipLaunchKernelGGL(nonfinite_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->st, n, d);
+  hipLaunchKernelGGL(nonfinite_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->st, n, h->d_count);
+  PDS_HIP(h, hipGetLastError());
   unsigned long long host = 0;
-  PDS_HIP(h, hipMemcpyAsync(&host, d, sizeof(host), hipMemcpyDeviceToHost, s));
+  PDS_HIP(h, hipMemcpyAsync(&host, h->d_count, sizeof(host), hipMemcpyDeviceToHost, s));
   PDS_HIP(h, hipStreamSynchronize(s));
-  PDS_HIP(h, hipFree(d));
   *count = (int64_t)host;
   return PDS_OK;
 }
 
 extern "C" int pds_get_state(pds_handle *h, int field, void *d_out, void *stream) { return do_field(h, field, d_out, 0, stream); }
 extern "C" int pds_set_state(pds_handle *h, int field, const void *d_in, void *stream) { return do_field(h, field, const_cast<void *>(d_in), 1, stream); }
+
+// Diagnostic builds (-DPDS_STAMPS): per-wave s_memtime stamps of the step kernel's phases, kStampSlots
+// words per 64-env tile; NULL / 0 in regular builds.  Not part of include/pds.h.
+extern "C" int pds_debug_stamps(pds_handle *h, unsigned long long *host_out, long long max_words) {
+#ifdef PDS_STAMPS
+  if (!h) return PDS_EINVAL;
+  DeviceGuard guard(h->cfg.device);
+  const long long ntiles = (h->cfg.num_envs + kWave - 1) / kWave;
+  const long long words = ntiles * kStampSlots;
+  if (!h->d_stamps) {
+    PDS_HIP(h, hipMalloc((void **)&h->d_stamps, (size_t)words * 8));
+    PDS_HIP(h, hipMemset(h->d_stamps, 0, (size_t)words * 8));
+    return 0;
+  }
+  PDS_HIP(h, hipDeviceSynchronize());
+  const long long w = words < max_words ? words : max_words;
+  if (host_out && w > 0) PDS_HIP(h, hipMemcpy(host_out, h->d_stamps, (size_t)w * 8, hipMemcpyDeviceToHost));
+  return (int)(w / kStampSlots);
+#else
+  (void)h; (void)host_out; (void)max_words;
+  return PDS_EUNSUPPORTED;
+#endif
+}

@@ -10,6 +10,7 @@ namespace pds {
 
 // Philox block ids (counter word 3) -- the RNG contract restated by oracle/phoenix_oracle.c
 constexpr uint32_t kBlkReset = 0;        // 0..8   reset distribution + domain randomisation (10 rounds)
+constexpr uint32_t kBlkLatRows = 9;      // 9..15  rows 0..6 of the latency action buffer (10 rounds); 16 = ctor noise
 constexpr uint32_t kBlkResetNoise = 32;  // 32..37 two add_noise calls inside reset (7 rounds)
 constexpr uint32_t kBlkObsNoise = 64;    // 64..66 the add_noise call that produces o(k+1) (7 rounds)
 constexpr uint32_t kBlkSubNoise = 128;   // 128+2*sub+{0,1}: OU + the discarded add_noise call (7 rounds)
@@ -21,22 +22,33 @@ constexpr uint32_t kBlkSubNoise = 128;   // 128+2*sub+{0,1}: OU + the discarded 
 constexpr int kResetBlocks = 9;        // reset distribution + domain randomisation
 constexpr int kObsCallBlocks = 3;     // one add_noise call that reaches the observation
 constexpr int kResetNoiseBlocks = 2 * kObsCallBlocks;  // two add_noise calls
-constexpr int kScratchBlocks = kResetBlocks + kResetNoiseBlocks;
+constexpr int kLatRowBlocks = kMaxLatSteps - 1;        // one block (4 normals) per extra action-buffer row
+constexpr int kScratchBlocks = kResetBlocks + kResetNoiseBlocks + kLatRowBlocks;
 
 struct DirectWords {
   uint32_t env_id, tick_lo, tick_hi, seed_lo, seed_hi;
+  PDS_DEV DirectWords(uint32_t id, const RngKey &r) : env_id(id), tick_lo(r.tick_lo), tick_hi(r.tick_hi), seed_lo(r.seed_lo), seed_hi(r.seed_hi) {}
   PDS_DEV U4 reset_block(uint32_t b) const { return philox4x32_10(env_id, tick_lo, tick_hi, kBlkReset + b, seed_lo, seed_hi); }
   PDS_DEV U4 noise_block(uint32_t b) const { return philox4x32_7(env_id, tick_lo, tick_hi, kBlkResetNoise + b, seed_lo, seed_hi); }
+  PDS_DEV U4 lat_block(uint32_t r) const { return philox4x32_10(env_id, tick_lo, tick_hi, kBlkLatRows + r, seed_lo, seed_hi); }
+  // scratch slot j of the cooperative fill (LdsWords layout)
+  PDS_DEV U4 scratch_block(int j) const {
+    if (j < kResetBlocks) return reset_block((uint32_t)j);
+    if (j < kResetBlocks + kResetNoiseBlocks) return noise_block((uint32_t)(j - kResetBlocks));
+    return lat_block((uint32_t)(j - kResetBlocks - kResetNoiseBlocks));
+  }
 };
 struct LdsWords {
   const U4 *slot;  // [kScratchBlocks]
   PDS_DEV U4 reset_block(uint32_t b) const { return slot[b]; }
   PDS_DEV U4 noise_block(uint32_t b) const { return slot[kResetBlocks + b]; }
+  PDS_DEV U4 lat_block(uint32_t r) const { return slot[kResetBlocks + kResetNoiseBlocks + r]; }
 };
 
-// which of the 15 blocks a variant consumes (the cooperative fill skips the others)
+// which of the scratch blocks a variant consumes (the cooperative fill skips the others)
 template <class V>
 PDS_DEV constexpr bool block_needed(int j) {
+  if (j >= kResetBlocks + kResetNoiseBlocks) return V::LAT && V::TASK != PDS_TASK_TAKEOFF;
   if (j >= kResetBlocks) return V::ON;
   if (j <= 1) return true;
   if (j <= 4) return V::TASK != PDS_TASK_TAKEOFF;
@@ -87,6 +99,19 @@ PDS_DEV void sample_philox(const Consts &k, const SRC &src, Sample &s) {
       s.mx[i] = k.hover_x + 0.02f * z[i];
       s.act[i] = k.hover_action + 0.02f * z[4 + i];
     }
+    if constexpr (V::LAT) {  // the other rows of np.random.normal(HOVER_ACTION, 0.02, (buf_size, 4)), hover.py:226-228
+#pragma unroll
+      for (int r = 0; r < kMaxLatSteps - 1; ++r) {
+        if (r < k.lat_steps - 1) {
+          const U4 w = src.lat_block((uint32_t)r);
+          float y[4];
+          box_muller(w.x, w.y, y[0], y[1]);
+          box_muller(w.z, w.w, y[2], y[3]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) s.abuf[r][i] = k.hover_action + 0.02f * y[i];
+        }
+      }
+    }
   } else {
     s.vel[2] = 0.f; s.w[0] = s.w[1] = s.w[2] = 0.f;
 #pragma unroll
@@ -104,7 +129,7 @@ PDS_DEV void sample_philox(const Consts &k, const SRC &src, Sample &s) {
     s.J[1] = PDS_DRV(r5.w, k.Jy_nom);
     s.J[2] = PDS_DRV(r6.x, k.Jz_nom);
     s.ftf1 = PDS_DRV(r6.z, k.ftf1_nom);
-    s.ref_offset = (int)__umulhi(r6.w, 300u);
+    s.ref_offset = (int)__umulhi(r6.w, (uint32_t)k.ref_points);  // randint(0, num_ref_points), circle.py:225
     if (V::MOTOR && V::DR) {
       const U4 r7 = src.reset_block(7u);
       const U4 r8 = src.reset_block(8u);
@@ -117,6 +142,7 @@ PDS_DEV void sample_philox(const Consts &k, const SRC &src, Sample &s) {
   }
 }
 
+template <bool LAT>
 PDS_DEV void sample_load(const float *row, Sample &s) {
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -130,6 +156,12 @@ PDS_DEV void sample_load(const float *row, Sample &s) {
   }
   s.dt = row[PDS_S_DR_DT]; s.m = row[PDS_S_DR_M]; s.ftf1 = row[PDS_S_DR_FTF1];
   s.ref_offset = (int)row[PDS_S_REF_OFFSET];
+  if constexpr (LAT) {
+#pragma unroll
+    for (int r = 0; r < kMaxLatSteps - 1; ++r)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s.abuf[r][i] = row[PDS_S_ACTION_BUF + 4 * r + i];
+  }
 }
 
 // ---- sensor noise -------------------------------------------------------------------------------
@@ -149,7 +181,7 @@ PDS_DEV void obs_noise_from_words(const uint32_t w[12], ObsNoise &n) {
   n.th_u[1] = u01_lo16(w[11]);  n.th_u[2] = u01_hi16(w[11]);
 }
 
-PDS_DEV void obs_noise_philox(uint32_t env_id, const StepArgs &a, uint32_t blk0, ObsNoise &n) {
+PDS_DEV void obs_noise_philox(uint32_t env_id, const RngKey &a, uint32_t blk0, ObsNoise &n) {
   uint32_t w[12];
 #pragma unroll
   for (int b = 0; b < kObsCallBlocks; ++b) {
@@ -254,9 +286,13 @@ PDS_DEV void write_noisy_half(float *row, const NoisyObs &o, const float lpf[3],
 // DroneBaseEnv.reset (envs/base.py:382-431) for one env: task_specific_reset, domain
 // randomisation, the Bullet pose/velocity round trip of update_information
 // (envs/agents.py:434-453: rpy = Euler(quat), omega = R^T R^T omega_sampled).
+struct LatRows {  // rows 0..B-2 of drone.action_buffer after a reset (row B-1 == u0 == drone.last_action)
+  float4 r[kMaxLatSteps - 1];
+};
+
 template <class V>
 PDS_DEV void reset_env(const Consts &k, const float2 *ref_lds, const Sample &s, EnvRegs &e, Quat &q,
-                       float4 &u0, float4 &mx, Params &par, uint32_t &ctr) {
+                       float4 &u0, float4 &mx, Params &par, uint32_t &ctr, LatRows &rows) {
   constexpr int TASK = V::TASK;
   float px = k.init_xyz[0], py = k.init_xyz[1], pz = k.init_xyz[2];
   float vx = k.init_vel[0], vy = k.init_vel[1], vz = k.init_vel[2];
@@ -265,6 +301,10 @@ PDS_DEV void reset_env(const Consts &k, const float2 *ref_lds, const Sample &s, 
   int ref_offset = (TASK == PDS_TASK_CIRCLE) ? (int)ctr_off(ctr) : 0;  // kept when no reset distribution
   u0 = make_float4(0.f, 0.f, 0.f, 0.f);  // drone.reset(): envs/agents.py:380-386
   mx = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (V::LAT) {
+#pragma unroll
+    for (int r = 0; r < kMaxLatSteps - 1; ++r) rows.r[r] = make_float4(0.f, 0.f, 0.f, 0.f);  // agents.py:385
+  }
   if (k.reset_dist) {
     if (TASK == PDS_TASK_HOVER) {  // envs/hover.py:201-229
       px += s.pos[0]; py += s.pos[1]; pz += s.pos[2];
@@ -287,11 +327,21 @@ PDS_DEV void reset_env(const Consts &k, const float2 *ref_lds, const Sample &s, 
       mx = make_float4(s.mx[0], s.mx[1], s.mx[2], s.mx[3]);
       u0 = make_float4(clampf(s.act[0], -1.f, 1.f), clampf(s.act[1], -1.f, 1.f),
                        clampf(s.act[2], -1.f, 1.f), clampf(s.act[3], -1.f, 1.f));
+      if constexpr (V::LAT) {  // action_buffer = clip(normal(HOVER_ACTION, .02, (B, 4))), last_action = its last row
+#pragma unroll
+        for (int r = 0; r < kMaxLatSteps - 1; ++r)
+          rows.r[r] = make_float4(clampf(s.abuf[r][0], -1.f, 1.f), clampf(s.abuf[r][1], -1.f, 1.f),
+                                  clampf(s.abuf[r][2], -1.f, 1.f), clampf(s.abuf[r][3], -1.f, 1.f));
+      }
     }
   }
   if (TASK == PDS_TASK_TAKEOFF) {  // envs/takeoff.py:209-212 (unconditional)
     mx = make_float4(0.f, 0.f, 0.f, 0.f);
     u0 = make_float4(-1.f, -1.f, -1.f, -1.f);
+    if constexpr (V::LAT) {
+#pragma unroll
+      for (int r = 0; r < kMaxLatSteps - 1; ++r) rows.r[r] = u0;  // action_buffer[:] = -1
+    }
   }
   default_params(k, par);
   if (V::DR) {  // envs/base.py:259-287
@@ -333,7 +383,7 @@ PDS_DEV void reset_env(const Consts &k, const float2 *ref_lds, const Sample &s, 
     const Quat qw = quat_from_euler(e.roll, e.pitch, e.yaw);
     sign = (qw.x * q.x + qw.y * q.y + qw.z * q.z + qw.w * q.w) < 0.f ? 1u : 0u;
   }
-  ctr = ctr_pack(0u, sign, (uint32_t)ref_offset);
+  ctr = ctr_pack(0u, sign, (uint32_t)ref_offset, 0u);  // iteration = 0, action_idx = 0
 }
 
 // Result of one reset, split in a pure-compute half and a store half so that the deferred
@@ -344,6 +394,7 @@ struct ResetOut {
   float4 u0, mx;
   Params par;
   uint32_t ctr;
+  LatRows lat;       // LAT
   NoiseState ns;     // ON: gyro bias / low-pass after the two observation calls of reset
   NoisyObs oa, ob;   // ON: the two noisy observations (history fill / compute_history)
   float lpf_a[3];    // ON: filtered gyro of the first one
@@ -355,10 +406,10 @@ template <class V, class SRC>
 PDS_DEV void reset_compute(const StepArgs &a, const float2 *ref_lds, const SRC &src, uint32_t ctr_old,
                            const float *sample_row, const float stale_w[3], const float bias[3], ResetOut &r) {
   Sample s;
-  if (sample_row != nullptr) sample_load(sample_row, s);
+  if (sample_row != nullptr) sample_load<V::LAT>(sample_row, s);
   else sample_philox<V>(a.k, src, s);
   r.ctr = ctr_old;
-  reset_env<V>(a.k, ref_lds, s, r.e, r.q, r.u0, r.mx, r.par, r.ctr);
+  reset_env<V>(a.k, ref_lds, s, r.e, r.q, r.u0, r.mx, r.par, r.ctr, r.lat);
   if (V::ON) {
     ObsNoise n0, n1;
     if (sample_row != nullptr) {
@@ -400,6 +451,11 @@ PDS_DEV void reset_store(const StepArgs &a, const float2 *ref_lds, long long i, 
     }
   }
   if (V::MOTOR) a.st.mx[i] = r.mx;
+  if constexpr (V::LAT) {
+#pragma unroll
+    for (int b = 0; b < kMaxLatSteps; ++b)
+      if (b < a.k.lat_steps) a.st.lat[(long long)b * a.n + i] = (b == a.k.lat_steps - 1 || b == kMaxLatSteps - 1) ? r.u0 : r.lat.r[b < kMaxLatSteps - 1 ? b : 0];
+  }
   if (V::DR) {
     a.st.par0[i] = make_float4(r.par.dt, r.par.m, r.par.Jx, r.par.Jy);
     a.st.par1[i] = make_float2(r.par.Jz, r.par.ftf1);
@@ -418,7 +474,7 @@ PDS_DEV void reset_store(const StepArgs &a, const float2 *ref_lds, long long i, 
   if (a.obs != nullptr) {
     float rowbuf[D];
     float tx, ty, tz;
-    target_at<TASK>(a.k, ref_lds, target_index<TASK>(0, a.k.agg, (int)ctr_off(r.ctr)), tx, ty, tz);
+    target_at<TASK>(a.k, ref_lds, target_index<TASK>(0, a.k.agg, (int)ctr_off(r.ctr), a.k.ref_points), tx, ty, tz);
     if (V::ON) {
       write_noisy_half<TASK>(rowbuf, r.oa, r.lpf_a, r.u0, tx, ty, tz, r.u0);
       write_noisy_half<TASK>(rowbuf + V::O + 4, r.ob, r.ns.lpf, r.u0, tx, ty, tz, r.u0);
@@ -444,8 +500,8 @@ constexpr int kLanesPerReset = 8;
 constexpr int kResetsPerPass = kWave / kLanesPerReset;
 
 template <class V>
-PDS_DEV void drain_reset_queue(const StepArgs &a, const float2 *ref_lds, const uint32_t *queue, int qcount,
-                               int lane, long long wave_base, float *tile) {
+PDS_DEV void drain_reset_queue(const StepArgs &a, const RngKey &rk, const float2 *ref_lds, const uint32_t *queue,
+                               int qcount, int lane, long long wave_base, float *tile) {
   static_assert(kResetsPerPass * kScratchBlocks * 16 <= kHalfTileRows * V::D * 4, "scratch must fit in the wave's tile");
   U4 *scratch = reinterpret_cast<U4 *>(tile);
   const int g = lane / kLanesPerReset, b = lane % kLanesPerReset;
@@ -459,14 +515,14 @@ PDS_DEV void drain_reset_queue(const StepArgs &a, const float2 *ref_lds, const u
     const long long i = wave_base + (long long)(ent & 63u);
     const uint32_t env_id = (uint32_t)(a.env_id_base + (unsigned long long)i);
     if (on) {
-      const DirectWords dw{env_id, a.tick_lo, a.tick_hi, a.seed_lo, a.seed_hi};
+      const DirectWords dw(env_id, rk);
 #pragma unroll
       for (int jj = 0; jj < (kScratchBlocks + kLanesPerReset - 1) / kLanesPerReset; ++jj) {
         const int j = jj * kLanesPerReset + b;
         bool need = false;
 #pragma unroll
         for (int c = 0; c < kScratchBlocks; ++c) need = need || (c == j && block_needed<V>(c));
-        if (need) scratch[g * kScratchBlocks + j] = (j < kResetBlocks) ? dw.reset_block((uint32_t)j) : dw.noise_block((uint32_t)(j - kResetBlocks));
+        if (need) scratch[g * kScratchBlocks + j] = dw.scratch_block(j);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -507,6 +563,7 @@ PDS_DEV void drain_reset_queue(const StepArgs &a, const float2 *ref_lds, const u
 struct ShflWords {
   U4 mine, blk8;
   int gbase;
+  PDS_DEV U4 lat_block(uint32_t) const { return U4{0u, 0u, 0u, 0u}; }  // (merged reset: no latency variants)
   PDS_DEV U4 reset_block(uint32_t j) const {
     if (j == 8u) return blk8;
     const int src = gbase + (int)j;
@@ -518,17 +575,17 @@ struct ShflWords {
 // `mine`: this lane's env finished; `pos`: its rank among the wave's `count` finished lanes, whose
 // lane ids are in `lanes[0..count)`.  Must be called in wave-uniform control flow.
 template <class V>
-PDS_DEV void reset_in_registers(const StepArgs &a, const float2 *ref_lds, const uint32_t *lanes, int count,
-                                bool mine, int pos, int lane, long long wave_base, int ref_offset,
+PDS_DEV void reset_in_registers(const StepArgs &a, const RngKey &rk, const float2 *ref_lds, const uint32_t *lanes,
+                                int count, bool mine, int pos, int lane, long long wave_base, int ref_offset,
                                 EnvRegs &e, Quat &q, float4 &u0, float4 &mx, Params &par, uint32_t &ctr) {
-  static_assert(!V::ON, "observation-noise variants use the deferred drain");
+  static_assert(!V::ON && !V::LAT, "observation-noise / latency variants use the deferred drain or the inline reset");
   const int g = lane / kLanesPerReset, b = lane % kLanesPerReset;
   for (int base = 0; base < count; base += kResetsPerPass) {
     const bool on = base + g < count;
     const int src = on ? (int)lanes[base + g] : lane;
     const uint32_t env_id = (uint32_t)(a.env_id_base + (unsigned long long)(wave_base + src));
     const int off_old = __shfl(ref_offset, src);
-    const DirectWords dw{env_id, a.tick_lo, a.tick_hi, a.seed_lo, a.seed_hi};
+    const DirectWords dw(env_id, rk);
     ShflWords sw;
     sw.gbase = lane - b;
     sw.mine = U4{0u, 0u, 0u, 0u};
@@ -545,7 +602,8 @@ PDS_DEV void reset_in_registers(const StepArgs &a, const float2 *ref_lds, const 
     float4 ru0, rmx;
     Params rpar;
     uint32_t rctr = ctr_pack(0u, 0u, (uint32_t)off_old);
-    reset_env<V>(a.k, ref_lds, s, re, rq, ru0, rmx, rpar, rctr);
+    LatRows no_rows;
+    reset_env<V>(a.k, ref_lds, s, re, rq, ru0, rmx, rpar, rctr, no_rows);
     // result of group (pos - base) -> the finished lane it belongs to
     const bool take = mine && pos >= base && pos < base + kResetsPerPass;
     const int from = take ? (pos - base) * kLanesPerReset : lane;
@@ -573,29 +631,49 @@ PDS_DEV void reset_in_registers(const StepArgs &a, const float2 *ref_lds, const 
   }
 }
 
+// tick / parity of the tile this wave owns (see WaveClock in pds_types.h)
+PDS_DEV void read_clock(const WaveClock *clk, long long tile, RngKey &rk, int &parity) {
+  const WaveClock c = clk[tile];
+  rk.tick_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.x);
+  rk.tick_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.y);
+  parity = __builtin_amdgcn_readfirstlane((int)c.z) & 1;
+}
+PDS_DEV void advance_clock(WaveClock *clk, long long tile, const RngKey &rk, int parity, uint32_t ticks, int lane) {
+  if (lane == 0) {
+    const unsigned long long t = (((unsigned long long)rk.tick_hi << 32) | rk.tick_lo) + ticks;
+    clk[tile] = make_uint4((uint32_t)t, (uint32_t)(t >> 32), (uint32_t)parity, 0u);
+  }
+}
+
 // Explicit reset (pds_reset / pds_reset_from_samples): not a hot path.
 template <class V>
 __global__ __launch_bounds__(kBlock) void reset_kernel(const StepArgs a) {
   __shared__ float2 ref_lds[(V::TASK == PDS_TASK_CIRCLE) ? kRefPoints : 1];
   if (V::TASK == PDS_TASK_CIRCLE) {
-    for (int t = threadIdx.x; t < kRefPoints; t += kBlock) ref_lds[t] = a.st.circle_ref[t];
+    for (int t = threadIdx.x; t < a.k.ref_points; t += kBlock) ref_lds[t] = a.st.circle_ref[t];
     __syncthreads();
   }
   const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= a.n) return;
-  if (a.mask != nullptr && a.mask[i] == 0) return;
-  float stale_w[3] = {0.f, 0.f, 0.f}, bias[3] = {0.f, 0.f, 0.f};
-  if (V::ON) {
-    const float4 q2 = a.st.s2[i];
-    const float4 nz = a.st.nz0[i];
-    stale_w[0] = q2.y; stale_w[1] = q2.z; stale_w[2] = q2.w;
-    bias[0] = nz.x; bias[1] = nz.y; bias[2] = nz.z;
+  const long long tile = i / kWave;  // wave-uniform
+  if (tile * kWave >= a.n) return;
+  RngKey rk{a.seed_lo, a.seed_hi, 0u, 0u};
+  int parity;
+  read_clock(a.st.clk, tile, rk, parity);
+  if (i < a.n && !(a.mask != nullptr && a.mask[i] == 0)) {
+    float stale_w[3] = {0.f, 0.f, 0.f}, bias[3] = {0.f, 0.f, 0.f};
+    if (V::ON) {
+      const float4 q2 = a.st.s2[i];
+      const float4 nz = a.st.nz0[i];
+      stale_w[0] = q2.y; stale_w[1] = q2.z; stale_w[2] = q2.w;
+      bias[0] = nz.x; bias[1] = nz.y; bias[2] = nz.z;
+    }
+    ResetOut r;
+    const DirectWords dw((uint32_t)(a.env_id_base + (unsigned long long)i), rk);
+    reset_compute<V>(a, ref_lds, dw, a.st.ctr[i], a.samples != nullptr ? a.samples + i * PDS_SAMPLE_FLOATS : nullptr,
+                     stale_w, bias, r);
+    reset_store<V>(a, ref_lds, i, r);
   }
-  ResetOut r;
-  const DirectWords dw{(uint32_t)(a.env_id_base + (unsigned long long)i), a.tick_lo, a.tick_hi, a.seed_lo, a.seed_hi};
-  reset_compute<V>(a, ref_lds, dw, a.st.ctr[i], a.samples != nullptr ? a.samples + i * PDS_SAMPLE_FLOATS : nullptr,
-                   stale_w, bias, r);
-  reset_store<V>(a, ref_lds, i, r);
+  advance_clock(a.st.clk, tile, rk, parity, 1u, threadIdx.x & (kWave - 1));  // a reset consumes one tick
 }
 
 }  // namespace pds

@@ -19,7 +19,8 @@ namespace pds {
 // Wave-cooperative copy of this wave's [rows, D] LDS tile to global memory (contiguous region).
 template <int D, int TR>
 PDS_DEV void flush_tile(const float *tile, float *gdst, int rows, int lane) {
-  if (rows == TR) {
+  // (an [N, D] slice of a [K, N, D] tensor is only 8-byte aligned when N D is not a multiple of 4)
+  if (rows == TR && (reinterpret_cast<uintptr_t>(gdst) & 15u) == 0) {  // wave-uniform
     constexpr int NV = TR * D / 4;  // float4 count (D is even, 32*D divisible by 4)
     const float4 *src = reinterpret_cast<const float4 *>(tile);
     float4 *dst = reinterpret_cast<float4 *>(gdst);
@@ -36,20 +37,25 @@ PDS_DEV void flush_tile(const float *tile, float *gdst, int rows, int lane) {
 
 // Inputs of one env-step, loaded 16 B/lane.
 struct Loaded {
-  float4 act, q0, q1, q2, h1, h2, mx, p0, mA, mK, ou, nz0, oh0, oh1, pid0, pid2;
+  float4 act, q0, q1, q2, hA, hB, mx, p0, mA, mK, ou, nz0, oh0, oh1, pid0, pid2;
   float2 p1, nz1, oh2, pid1, pid3;
   uint32_t ctr;
+  WaveClock clk;
 };
 
+// Both slots of the action ring are requested by index (hA = slot 0, hB = slot 1): which of them is
+// u(k-1) is decided by the parity bit of the wave's clock word, which arrives with the same batch of
+// loads -- no load address depends on another load.
 template <class V>
-PDS_DEV void load_env(const StepArgs &a, long long ii, Loaded &L) {
-  L.act = nt_load4(a.actions + ii);  // read once per step: keep it out of the caches
+PDS_DEV void load_env(const StepArgs &a, long long ii, long long tile, Loaded &L) {
+  if (a.actions != nullptr) L.act = nt_load4(a.actions + ii);  // read once per step: keep it out of the caches
   L.q0 = st_load4(a.st.s0 + ii);
   L.q1 = st_load4(a.st.s1 + ii);
   L.q2 = st_load4(a.st.s2 + ii);
-  L.h1 = st_load4(a.st.hist[a.parity] + ii);      // u(k-1)
-  L.h2 = st_load4(a.st.hist[a.parity ^ 1] + ii);  // u(k-2)
+  L.hA = st_load4(a.st.hist[0] + ii);
+  L.hB = st_load4(a.st.hist[1] + ii);
   L.ctr = a.st.ctr[ii];
+  L.clk = a.st.clk[tile];
   if (V::MOTOR) L.mx = a.st.mx[ii];
   if (V::DR) {
     L.p0 = a.st.par0[ii];
@@ -62,6 +68,102 @@ PDS_DEV void load_env(const StepArgs &a, long long ii, Loaded &L) {
   if (V::ON) {
     L.nz0 = a.st.nz0[ii]; L.nz1 = a.st.nz1[ii];
     L.oh0 = a.st.oh0[ii]; L.oh1 = a.st.oh1[ii]; L.oh2 = a.st.oh2[ii];
+  }
+}
+
+// Everything one env carries from step to step, in registers (members a variant does not use are
+// never touched and cost nothing).
+struct EnvState {
+  EnvRegs e;
+  float4 h1, h2;  // u(k-1), u(k-2)
+  uint32_t ctr;
+  float xm[4];    // MOTOR
+  Params par;     // DR (otherwise the constants)
+  NoiseState ns;  // TN / ON
+  PidState ps;    // CTRL
+  NoisyObs oh;    // ON: the previous noisy observation
+};
+
+template <class V>
+PDS_DEV void unpack_state(const Consts &k, const Loaded &cur, int parity, EnvState &S) {
+  S.h1 = parity ? cur.hB : cur.hA;
+  S.h2 = parity ? cur.hA : cur.hB;
+  S.ctr = cur.ctr;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) S.xm[j] = 0.f;
+  if (V::MOTOR) { S.xm[0] = cur.mx.x; S.xm[1] = cur.mx.y; S.xm[2] = cur.mx.z; S.xm[3] = cur.mx.w; }
+  default_params(k, S.par);
+  if (V::DR) {
+    S.par.dt = cur.p0.x; S.par.m = cur.p0.y; S.par.Jx = cur.p0.z; S.par.Jy = cur.p0.w; S.par.Jz = cur.p1.x; S.par.ftf1 = cur.p1.y;
+    if (V::MOTOR) {
+      S.par.A[0] = cur.mA.x; S.par.A[1] = cur.mA.y; S.par.A[2] = cur.mA.z; S.par.A[3] = cur.mA.w;
+      S.par.K[0] = cur.mK.x; S.par.K[1] = cur.mK.y; S.par.K[2] = cur.mK.z; S.par.K[3] = cur.mK.w;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) S.ns.ou[j] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { S.ns.bias[j] = 0.f; S.ns.lpf[j] = 0.f; }
+  if (V::TN) { S.ns.ou[0] = cur.ou.x; S.ns.ou[1] = cur.ou.y; S.ns.ou[2] = cur.ou.z; S.ns.ou[3] = cur.ou.w; }
+  if (V::ON) {
+    S.ns.bias[0] = cur.nz0.x; S.ns.bias[1] = cur.nz0.y; S.ns.bias[2] = cur.nz0.z;
+    S.ns.lpf[0] = cur.nz0.w; S.ns.lpf[1] = cur.nz1.x; S.ns.lpf[2] = cur.nz1.y;
+    S.oh = NoisyObs{cur.oh0.x, cur.oh0.y, cur.oh0.z, cur.oh0.w, cur.oh1.x, cur.oh1.y, cur.oh1.z,
+                    cur.oh1.w, cur.oh2.x, cur.oh2.y};
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { S.ps.rate_int[j] = S.ps.rate_err[j] = S.ps.att_int[j] = S.ps.att_err[j] = 0.f; }
+  if (V::CTRL >= 1) {
+    S.ps.rate_int[0] = cur.pid0.x; S.ps.rate_int[1] = cur.pid0.y; S.ps.rate_int[2] = cur.pid0.z;
+    S.ps.rate_err[0] = cur.pid0.w; S.ps.rate_err[1] = cur.pid1.x; S.ps.rate_err[2] = cur.pid1.y;
+  }
+  if (V::CTRL == 2) {
+    S.ps.att_int[0] = cur.pid2.x; S.ps.att_int[1] = cur.pid2.y; S.ps.att_int[2] = cur.pid2.z;
+    S.ps.att_err[0] = cur.pid2.w; S.ps.att_err[1] = cur.pid3.x; S.ps.att_err[2] = cur.pid3.y;
+  }
+  S.e = EnvRegs{cur.q0.x, cur.q0.y, cur.q0.z, cur.q0.w, cur.q1.x, cur.q1.y, cur.q1.z, cur.q1.w,
+                cur.q2.x, cur.q2.y, cur.q2.z, cur.q2.w};
+}
+
+// Coalesced 16 B/lane stores of the env state.  `new_parity` = parity of the action ring AFTER the
+// stored step: slot new_parity holds u(k-1) = S.h1.  The single-step kernel leaves the other slot
+// alone (it already holds S.h2) unless the env was reset in registers (`both`); the K-step kernel
+// rewrites both slots and the randomised parameters.
+template <class V>
+PDS_DEV void store_state(const StepArgs &a, long long i, int new_parity, const EnvState &S, bool both) {
+  const EnvRegs &e = S.e;
+  st_store4(a.st.s0 + i, make_float4(e.px, e.py, e.pz, e.vx));
+  st_store4(a.st.s1 + i, make_float4(e.vy, e.vz, e.roll, e.pitch));
+  st_store4(a.st.s2 + i, make_float4(e.yaw, e.wx, e.wy, e.wz));
+  st_store4(a.st.hist[new_parity] + i, S.h1);
+  a.st.ctr[i] = S.ctr;
+  if (V::MOTOR) a.st.mx[i] = make_float4(S.xm[0], S.xm[1], S.xm[2], S.xm[3]);
+  if (V::TN) a.st.ou[i] = make_float4(S.ns.ou[0], S.ns.ou[1], S.ns.ou[2], S.ns.ou[3]);
+  if (V::CTRL >= 1) {
+    a.st.pid0[i] = make_float4(S.ps.rate_int[0], S.ps.rate_int[1], S.ps.rate_int[2], S.ps.rate_err[0]);
+    a.st.pid1[i] = make_float2(S.ps.rate_err[1], S.ps.rate_err[2]);
+  }
+  if (V::CTRL == 2) {
+    a.st.pid2[i] = make_float4(S.ps.att_int[0], S.ps.att_int[1], S.ps.att_int[2], S.ps.att_err[0]);
+    a.st.pid3[i] = make_float2(S.ps.att_err[1], S.ps.att_err[2]);
+  }
+  if (V::ON) {
+    a.st.nz0[i] = make_float4(S.ns.bias[0], S.ns.bias[1], S.ns.bias[2], S.ns.lpf[0]);
+    a.st.nz1[i] = make_float2(S.ns.lpf[1], S.ns.lpf[2]);
+    a.st.oh0[i] = make_float4(S.oh.x, S.oh.y, S.oh.z, S.oh.qx);
+    a.st.oh1[i] = make_float4(S.oh.qy, S.oh.qz, S.oh.qw, S.oh.vx);
+    a.st.oh2[i] = make_float2(S.oh.vy, S.oh.vz);
+  }
+  if (both) {  // written only by resets (no write-after-write with this step's stores)
+    a.st.hist[new_parity ^ 1][i] = S.h2;
+    if (V::DR) {
+      a.st.par0[i] = make_float4(S.par.dt, S.par.m, S.par.Jx, S.par.Jy);
+      a.st.par1[i] = make_float2(S.par.Jz, S.par.ftf1);
+      if (V::MOTOR) {
+        a.st.mA[i] = make_float4(S.par.A[0], S.par.A[1], S.par.A[2], S.par.A[3]);
+        a.st.mK[i] = make_float4(S.par.K[0], S.par.K[1], S.par.K[2], S.par.K[3]);
+      }
+    }
   }
 }
 
@@ -130,7 +232,7 @@ struct SubNoise {
 };
 
 template <class V>
-PDS_DEV void sub_noise(const StepArgs &a, uint32_t env_id, long long ii, int sub, SubNoise &n) {
+PDS_DEV void sub_noise(const StepArgs &a, const RngKey &rk, uint32_t env_id, long long ii, int sub, SubNoise &n) {
   if (a.noise != nullptr) {  // injected (parity tests; aggregate_phy_steps == 1)
     const float *p = a.noise + ii * PDS_NOISE_FLOATS;
 #pragma unroll
@@ -142,11 +244,11 @@ PDS_DEV void sub_noise(const StepArgs &a, uint32_t env_id, long long ii, int sub
   // words 0,1 -> OU z[0..3]; words 2..6 -> bias, random walk, turn-on z[4..12] (one pair per word)
   const uint32_t b0 = kBlkSubNoise + 2u * (uint32_t)sub;
   float z[14];
-  const U4 r = philox4x32_7(env_id, a.tick_lo, a.tick_hi, b0, a.seed_lo, a.seed_hi);
+  const U4 r = philox4x32_7(env_id, rk.tick_lo, rk.tick_hi, b0, rk.seed_lo, rk.seed_hi);
   box_muller_word(r.x, z[0], z[1]);
   box_muller_word(r.y, z[2], z[3]);
   if (V::ON) {
-    const U4 r1 = philox4x32_7(env_id, a.tick_lo, a.tick_hi, b0 + 1u, a.seed_lo, a.seed_hi);
+    const U4 r1 = philox4x32_7(env_id, rk.tick_lo, rk.tick_hi, b0 + 1u, rk.seed_lo, rk.seed_hi);
     box_muller_word(r.z, z[4], z[5]);
     box_muller_word(r.w, z[6], z[7]);
     box_muller_word(r1.x, z[8], z[9]);
@@ -162,6 +264,362 @@ PDS_DEV void sub_noise(const StepArgs &a, uint32_t env_id, long long ii, int sub
   for (int j = 0; j < 3; ++j) { n.bias_z[j] = z[4 + j]; n.rw_z[j] = z[7 + j]; n.to_z[j] = z[10 + j]; }
 }
 
+// How an env that finished is reset inside the step (all three produce the same bits):
+//  RM_MERGED   before the wave stores, 8 lanes per finished env, results through ds_bpermute
+//              (reset_in_registers): state and observation leave through the ordinary coalesced stores;
+//  RM_DEFERRED after the wave's stores (drain_reset_queue, cooperative Philox through LDS, scattered
+//              stores): the variants whose merged form would cost a wave of occupancy (single step only);
+//  RM_INLINE   by the finished lane itself after the final_obs copy (K-step kernel for the variants
+//              that are not merged: the fresh state has to come back into registers).
+enum { RM_MERGED = 0, RM_DEFERRED = 1, RM_INLINE = 2 };
+
+#ifdef PDS_STAMPS  // diagnostic build: s_memtime stamps of one wave's phases (profiles/tools/stamps.py)
+#define PDS_STAMP(j)                                                  \
+  do {                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                \
+    stamp_[j] = __builtin_amdgcn_s_memtime();                         \
+    __builtin_amdgcn_sched_barrier(0);                                \
+  } while (0)
+#define PDS_STAMP_WAIT(j)                                             \
+  do {                                                                \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       \
+    PDS_STAMP(j);                                                     \
+  } while (0)
+#else
+#define PDS_STAMP(j) do { } while (0)
+#define PDS_STAMP_WAIT(j) do { } while (0)
+#endif
+constexpr int kStampSlots = 10;
+
+// One env.step() of the env in `S` (registers in, registers out) + this step's output streams, which
+// start `o1` envs into the output tensors (0 for the single-step kernel, step * N for the K-step one;
+// the pointers are formed where they are used so that the kernel arguments are not held in SGPRs
+// across the whole step).  Returns true for a lane whose env was reset in registers (RM_MERGED /
+// RM_INLINE).
+template <class V, int TR, int RM, bool STORE>
+PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, int parity, const float2 *ref_lds,
+                       float *tile, uint32_t *queue, int lane, long long wave_base, long long i, long long ii,
+                       bool active, const float4 act, EnvState &S, int &qcount
+#ifdef PDS_STAMPS
+                       , unsigned long long *stamp_
+#endif
+) {
+  constexpr int TASK = V::TASK;
+  constexpr int D = V::D;
+  constexpr int O = V::O;
+  static_assert(RM != RM_MERGED || (!V::ON && !V::LAT), "merged reset: variants without observation noise / latency");
+  static_assert(RM != RM_INLINE || TR == kWave, "inline reset: full tile only");
+  static_assert(RM != RM_DEFERRED || STORE, "deferred drain: the state must be in HBM before it");
+  const Consts &k = a.k;
+  // full tile: the row is built in place in LDS; half tile: in registers, staged pass by pass
+  float rowbuf[(TR == kWave) ? 1 : D];
+  float *row = (TR == kWave) ? tile + lane * D : rowbuf;
+  const uint32_t env_id = (uint32_t)(a.env_id_base + (unsigned long long)ii);
+  const float4 h1 = S.h1, h2 = S.h2;
+  const uint32_t ctr = S.ctr;
+  EnvRegs &e = S.e;
+  Params &par = S.par;
+  NoiseState &ns = S.ns;
+  PidState &ps = S.ps;
+  const int step = (int)ctr_step(ctr);
+  const int ref_offset = (int)ctr_off(ctr);
+
+  // paired actions of the two row halves: u(k-2) and u(k-1).  With the latency model the reference's
+  // action_history still holds VIEWS of action_buffer[-1] for the first two steps after a reset
+  // (agents.py:386, base.py:425-426), so those entries show whatever apply_action has written into
+  // that row meanwhile (k.lat_own1/2 = the step whose action the row holds after step 1 / 2).
+  float4 pa1 = h2, pa2 = h1;
+  if (V::LAT) {
+    if (step == 0) {
+      if (k.lat_own1 == 1) { pa1 = act; pa2 = act; }
+    } else if (step == 1) {
+      if (k.lat_own2 == 2) pa1 = act;
+      else if (k.lat_own2 == 1) pa1 = h1;
+    }
+  }
+
+  // ---- o(k): first half of the row ------------------------------------------------------------
+  // noise-free: rebuilt from the pre-step state instead of being re-read from HBM;
+  // noisy: the stored noisy observation + the filtered gyro (== the low-pass state)
+  Quat q = quat_from_euler(e.roll, e.pitch, e.yaw);
+  {
+    float tx, ty, tz;
+    target_at<TASK>(k, ref_lds, target_index<TASK>(step, k.agg, ref_offset, k.ref_points), tx, ty, tz);
+    if (V::ON) {
+      write_noisy_half<TASK>(row, S.oh, ns.lpf, h1, tx, ty, tz, pa1);
+    } else {
+      Quat qk = q;
+      if (ctr_sign(ctr)) { qk.x = -q.x; qk.y = -q.y; qk.z = -q.z; qk.w = -q.w; }
+      write_obs_half<TASK>(row, e, qk, h1, tx, ty, tz, pa1);
+    }
+  }
+
+  // ---- aggregate_phy_steps x SimplePhysics.step_forward (envs/base.py:457-465) ---------------
+  float *xm = S.xm;
+  uint32_t lat_idx = ctr_lat(ctr);
+  // divisions by the per-env mass / inertia become multiplications by v_rcp_f32 results (1 ulp)
+  const float inv_m = fast_rcp(par.m), inv_Jx = fast_rcp(par.Jx), inv_Jy = fast_rcp(par.Jy), inv_Jz = fast_rcp(par.Jz);
+  for (int sub = 0; sub < k.agg; ++sub) {
+    SubNoise sn;
+    if (V::TN || V::ON) sub_noise<V>(a, rk, env_id, ii, sub, sn);
+    // CrazyFlieAgent.apply_action, envs/agents.py:259-298 (+ PWM.act envs/control.py:94-100)
+    float av[4] = {act.x, act.y, act.z, act.w};
+    if (V::LAT) {  // agents.py:267-276: the controller sees the action of buf_size physics steps ago
+      float4 *slot = a.st.lat + (long long)lat_idx * a.n + ii;
+      const float4 d = *slot;
+      if (active) *slot = act;
+      lat_idx = (lat_idx + 1u == (uint32_t)k.lat_steps) ? 0u : lat_idx + 1u;
+      av[0] = d.x; av[1] = d.y; av[2] = d.z; av[3] = d.w;
+    }
+    float f[4], pwmv[4];
+    if (V::CTRL == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pwmv[j] = 30000.f + clampf(av[j], -1.f, 1.f) * 30000.f;
+    } else {
+      control_pwm<V::CTRL>(k.dt_nom, e, av, ps, pwmv);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float un = pwmv[j] * (1.0f / 60000.f);
+      float noise1 = 1.0f;
+      if (V::TN) {  // OUNoise.noise, envs/utils.py:104-108 (theta .15, mu 0); never reset
+        ns.ou[j] = ns.ou[j] + (0.15f * (0.f - ns.ou[j]) + k.ou_sigma * sn.ou[j]);
+        noise1 = 1.0f + ns.ou[j];
+      }
+      float n;
+      if (V::MOTOR) {
+        xm[j] = par.A[j] * xm[j] + (1.0f - par.A[j]) * fast_sqrt(un);
+        n = noise1 * (xm[j] * xm[j]);
+      } else {
+        n = noise1 * un;
+      }
+      f[j] = par.K[j] * clampf(n, 0.f, 1.f);
+    }
+    // yaw torque: sum of +-(ftf1*f_i + ftf0); ftf0 cancels (envs/agents.py:295-297)
+    const float tz_ = par.ftf1 * (-f[0] + f[1] - f[2] + f[3]);
+    float R[9];
+    matrix_from_quat(q, R);  // envs/physics.py:160 (quaternion of the PREVIOUS step)
+    if (V::GE) {
+      // BasePhysics.calculate_ground_effect, envs/physics.py:27-58, applied as extra per-motor
+      // thrust (envs/physics.py:117-120); branch-free per-env scale
+      const float ok = (fabsf(e.roll) < kHalfPi && fabsf(e.pitch) < kHalfPi) ? 1.f : 0.f;
+      const float ox[4] = {0.028f, -0.028f, -0.028f, 0.028f};
+      const float oy[4] = {-0.028f, -0.028f, 0.028f, 0.028f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float hz = fmaxf(e.pz + (R[6] * ox[j] + R[7] * oy[j]), k.h_clip);
+        const float qq = k.prop_r * fast_rcp(4.f * hz);
+        f[j] = f[j] + ok * (f[j] * k.gec * (qq * qq));
+      }
+    }
+    const float thrust = ((f[0] + f[1]) + f[2]) + f[3];
+    const float Fx = R[2] * thrust, Fy = R[5] * thrust, Fz = R[8] * thrust - k.G * par.m;
+    const float tx_ = (-f[0] - f[1] + f[2] + f[3]) * k.Lq;  // envs/physics.py:167
+    const float ty_ = (-f[0] + f[1] + f[2] - f[3]) * k.Lq;  // envs/physics.py:168
+    const float Jwx = par.Jx * e.wx, Jwy = par.Jy * e.wy, Jwz = par.Jz * e.wz;
+    const float t0 = tx_ - (e.wy * Jwz - e.wz * Jwy);  // tau - w x (J w), envs/physics.py:170-171
+    const float t1 = ty_ - (e.wz * Jwx - e.wx * Jwz);
+    const float t2 = tz_ - (e.wx * Jwy - e.wy * Jwx);
+    const float dt = par.dt;
+    e.vx += dt * (Fx * inv_m); e.vy += dt * (Fy * inv_m); e.vz += dt * (Fz * inv_m);    // :173,175
+    e.wx += dt * (t0 * inv_Jx); e.wy += dt * (t1 * inv_Jy); e.wz += dt * (t2 * inv_Jz);  // :172,176
+    e.px += dt * e.vx; e.py += dt * e.vy; e.pz += dt * e.vz;                             // :177
+    e.roll += dt * e.wx; e.pitch += dt * e.wy; e.yaw += dt * e.wz;                       // :178
+    q = quat_from_euler(e.roll, e.pitch, e.yaw);                                         // :179
+    e.pz = fmaxf(e.pz, 0.f);                                                             // :182
+    // envs/base.py:464: compute_observation() whose result is dropped still advances the gyro
+    // bias random walk and the low-pass filter
+    if (V::ON) gyro_update(k, e, sn.bias_z, sn.rw_z, sn.to_z, ns);
+  }
+  PDS_STAMP(3);
+
+  // ---- task: target, done, reward, cost (all on the TRUE state) -------------------------------
+  float tx, ty, tz;
+  target_at<TASK>(k, ref_lds, target_index<TASK>(step + 1, k.agg, ref_offset, k.ref_points), tx, ty, tz);
+  const float dx = e.px - tx, dy = e.py - ty, dz = e.pz - tz;
+  const float dist = fast_sqrt(dx * dx + dy * dy + dz * dz);
+  bool done = false;
+  if (TASK == PDS_TASK_HOVER) {  // envs/hover.py:89-101
+    constexpr float lim = 60.f * kPi / 180.f;
+    constexpr float r2d = 180.f / kPi;
+    done = (e.pz < 0.2f) || (fabsf(e.roll) > lim) || (fabsf(e.pitch) > lim) ||
+           (fabsf(e.wx) * r2d > 300.f) || (fabsf(e.wy) * r2d > 300.f) || (fabsf(e.wz) * r2d > 300.f);
+  } else if (TASK == PDS_TASK_CIRCLE) {  // envs/circle.py:116-120
+    done = dist > 0.25f;
+  }
+  float reward;
+  {  // envs/hover.py:169-187, envs/circle.py:183-204, envs/takeoff.py:155-174
+    const float n0 = 0.5f * (clampf(act.x, -1.f, 1.f) + 1.f), n1 = 0.5f * (clampf(act.y, -1.f, 1.f) + 1.f);
+    const float n2 = 0.5f * (clampf(act.z, -1.f, 1.f) + 1.f), n3 = 0.5f * (clampf(act.w, -1.f, 1.f) + 1.f);
+    const float pen_act = k.pa * fast_sqrt(n0 * n0 + n1 * n1 + n2 * n2 + n3 * n3);
+    float pen_rate = 0.f;
+    if (TASK == PDS_TASK_CIRCLE) {  // a - env.last_action (previous action, envs/circle.py:186)
+      const float d0 = act.x - h1.x, d1 = act.y - h1.y, d2 = act.z - h1.z, d3 = act.w - h1.w;
+      pen_rate = k.arp * fast_sqrt(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
+    }
+    float pen_rpy = 0.f;
+    if (k.pang != 0.f) pen_rpy = k.pang * fast_sqrt(e.roll * e.roll + e.pitch * e.pitch + e.yaw * e.yaw);
+    const float pen_spin = k.pspin * fast_sqrt(e.wx * e.wx + e.wy * e.wy + e.wz * e.wz);
+    const float pen_term = done ? k.pterm : 0.f;
+    // envs/takeoff.py:165 multiplies the velocity norm by penalty_ACTION
+    const float pv = (TASK == PDS_TASK_TAKEOFF) ? k.pa : k.pvel;
+    float pen_vel = 0.f;
+    if (pv != 0.f) pen_vel = pv * fast_sqrt(e.vx * e.vx + e.vy * e.vy + e.vz * e.vz);
+    const float penalties = ((((pen_rpy + pen_rate) + pen_spin) + pen_vel) + pen_act) + pen_term;
+    reward = -dist - penalties;
+    if (TASK == PDS_TASK_TAKEOFF && e.pz < 0.08f) reward -= 1.f;  // envs/takeoff.py:172-173
+  }
+  float cost = 0.f;
+  if (TASK == PDS_TASK_HOVER) {
+    // envs/hover.py:103-129: state[10:13] is rpy_dot and state[13:16] is last_action[0:3] in the
+    // get_state layout -- reproduced as is
+    constexpr float rp_lim = 10.f * kPi / 180.f, dot_lim = 200.f * kPi / 180.f;
+    const bool c = (fabsf(e.px) > 0.10f) || (fabsf(e.py) > 0.10f) || (e.pz > 1.20f) ||
+                   (fabsf(e.roll) > rp_lim) || (fabsf(e.pitch) > rp_lim) ||
+                   (fabsf(e.wx) > 0.25f) || (fabsf(e.wy) > 0.25f) || (fabsf(e.wz) > 0.25f) ||
+                   (fabsf(act.x) > dot_lim) || (fabsf(act.y) > dot_lim) || (fabsf(act.z) > dot_lim);
+    cost = c ? 1.f : 0.f;
+  }
+  const bool trunc = (step + 1) >= k.max_steps;  // gymnasium TimeLimit, __init__.py:11
+
+  // ---- o(k+1) and u(k-1) -> second half of the row (envs/base.py:303-319) --------------------
+  if (V::ON) {
+    ObsNoise n;
+    if (a.noise != nullptr) obs_noise_load(a.noise + ii * PDS_NOISE_FLOATS + PDS_N_OBS, n);
+    else obs_noise_philox(env_id, rk, kBlkObsNoise, n);
+    sensor_observe(k, e, n, ns, S.oh);
+    write_noisy_half<TASK>(row + O + 4, S.oh, ns.lpf, act, tx, ty, tz, pa2);
+  } else {
+    write_obs_half<TASK>(row + O + 4, e, q, act, tx, ty, tz, pa2);
+  }
+
+  S.ctr = ctr_pack((uint32_t)(step + 1), 0u, (uint32_t)ref_offset, lat_idx);
+  S.h2 = h1;   // u(k-1) becomes u(k-2)
+  S.h1 = act;  // -> the ring slot that held u(k-2)
+  // ---- auto-reset.  ~2 % of the envs finish per step under random actions, i.e. 3 of 4 waves
+  // hold one or two finished envs.  Their last observation goes to final_obs (below, out of the
+  // LDS tile); the reset itself: see RM_* above.
+  const bool need_reset = a.auto_reset && (done || trunc) && active;
+  const unsigned long long reset_mask = __ballot(need_reset);  // wave-uniform
+  const unsigned long long done_mask = (a.final_obs != nullptr) ? reset_mask : 0ull;  // -> final_obs
+  bool was_reset = false;
+  if (reset_mask != 0ull) {  // wave-uniform
+    const int pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(reset_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)reset_mask, 0u));
+    if constexpr (RM == RM_DEFERRED) {
+      qcount = __popcll(reset_mask);
+      if (need_reset) queue[pos] = (uint32_t)lane | ((uint32_t)ref_offset << 6);
+    } else if constexpr (RM == RM_MERGED) {
+      const int count = __popcll(reset_mask);
+      if (need_reset) queue[pos] = (uint32_t)lane;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      float4 u0 = act, mxr = make_float4(xm[0], xm[1], xm[2], xm[3]);
+      reset_in_registers<V>(a, rk, ref_lds, queue, count, need_reset, pos, lane, wave_base, ref_offset, e, q, u0,
+                            mxr, par, S.ctr);
+      if (need_reset) {
+        was_reset = true;
+        S.h1 = u0; S.h2 = u0;
+        xm[0] = mxr.x; xm[1] = mxr.y; xm[2] = mxr.z; xm[3] = mxr.w;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { ps.rate_int[j] = ps.rate_err[j] = ps.att_int[j] = ps.att_err[j] = 0.f; }
+      }
+    }
+  }
+
+  // ---- coalesced stores ----------------------------------------------------------------------
+  if (active) {
+    if constexpr (STORE) store_state<V>(a, i, parity ^ 1, S, was_reset);
+    nt_store(a.reward + o1 + i, reward);
+    nt_store(a.cost + o1 + i, cost);
+    nt_store(a.term + o1 + i, (uint8_t)(done ? 1 : 0));
+    nt_store(a.trunc + o1 + i, (uint8_t)(trunc ? 1 : 0));
+  }
+  PDS_STAMP(4);
+  // LDS rows of this wave were written by its own lanes only: wave-synchronous, no block barrier
+  const long long rem = a.n - wave_base;
+#pragma unroll
+  for (int pass = 0; pass < kWave / TR; ++pass) {
+    if (TR != kWave) {
+      if ((lane / TR) == pass) {
+        float *dst = tile + (lane % TR) * D;
+#pragma unroll
+        for (int j = 0; j < D; ++j) dst[j] = rowbuf[j];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // last observation of each finished env -> final_obs: the whole wave copies one row
+    // (D <= 64 contiguous floats) per finished env straight out of the LDS tile
+    unsigned long long m = done_mask;
+    if (TR != kWave) m &= (pass == 0) ? 0x00000000FFFFFFFFull : 0xFFFFFFFF00000000ull;
+    while (m != 0ull) {
+      const int src_lane = __builtin_ctzll(m);
+      m &= m - 1ull;
+      // non-temporal like the other streamed outputs (same box: 57.7 vs 58.4 us on Hover 2^20)
+      if (lane < D) nt_store(a.final_obs + (o1 + wave_base + src_lane) * D + lane, tile[(src_lane % TR) * D + lane]);
+    }
+    if (RM != RM_DEFERRED && reset_mask != 0ull) {  // wave-uniform: the reset envs' rows become [o0, u0, o0', u0]
+      if constexpr (RM == RM_INLINE) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // every final_obs row has left the tile
+        if (need_reset) {
+          was_reset = true;
+          const float stale_w[3] = {e.wx, e.wy, e.wz};
+          const float bias[3] = {ns.bias[0], ns.bias[1], ns.bias[2]};
+          ResetOut r;
+          const DirectWords dw(env_id, rk);
+          reset_compute<V>(a, ref_lds, dw, ctr_pack(0u, 0u, (uint32_t)ref_offset), nullptr, stale_w, bias, r);
+          e = r.e;
+          S.ctr = r.ctr;
+          S.h1 = r.u0; S.h2 = r.u0;
+          xm[0] = r.mx.x; xm[1] = r.mx.y; xm[2] = r.mx.z; xm[3] = r.mx.w;
+          if (V::DR) par = r.par;
+#pragma unroll
+          for (int j = 0; j < 3; ++j) { ps.rate_int[j] = ps.rate_err[j] = ps.att_int[j] = ps.att_err[j] = 0.f; }
+          float tx0, ty0, tz0;
+          target_at<TASK>(k, ref_lds, target_index<TASK>(0, k.agg, (int)ctr_off(r.ctr), k.ref_points), tx0, ty0, tz0);
+          float *dst = tile + lane * D;
+          if (V::ON) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { ns.bias[j] = r.ns.bias[j]; ns.lpf[j] = r.ns.lpf[j]; }
+            S.oh = r.ob;
+            write_noisy_half<TASK>(dst, r.oa, r.lpf_a, r.u0, tx0, ty0, tz0, r.u0);
+            write_noisy_half<TASK>(dst + O + 4, r.ob, r.ns.lpf, r.u0, tx0, ty0, tz0, r.u0);
+          } else {
+            write_obs_half<TASK>(dst, r.e, r.q, r.u0, tx0, ty0, tz0, r.u0);
+            write_obs_half<TASK>(dst + O + 4, r.e, r.q, r.u0, tx0, ty0, tz0, r.u0);
+          }
+          if constexpr (V::LAT) {
+#pragma unroll
+            for (int b = 0; b < kMaxLatSteps; ++b)
+              if (b < k.lat_steps) a.st.lat[(long long)b * a.n + i] = (b == k.lat_steps - 1 || b == kMaxLatSteps - 1) ? r.u0 : r.lat.r[b < kMaxLatSteps - 1 ? b : 0];
+          }
+        }
+      } else {
+        if (need_reset && (TR == kWave || (lane / TR) == pass)) {
+          float tx0, ty0, tz0;
+          target_at<TASK>(k, ref_lds, target_index<TASK>(0, k.agg, (int)ctr_off(S.ctr), k.ref_points), tx0, ty0, tz0);
+          float *dst = tile + (lane % TR) * D;
+          write_obs_half<TASK>(dst, e, q, S.h1, tx0, ty0, tz0, S.h1);
+          write_obs_half<TASK>(dst + O + 4, e, q, S.h1, tx0, ty0, tz0, S.h1);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    const long long left = rem - pass * TR;
+    if (left > 0)
+      flush_tile<D, TR>(tile, a.obs + (o1 + wave_base + pass * TR) * D, left >= TR ? TR : (int)left, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // the tile is rewritten by the next pass / the reset drain / the next step
+  }
+  PDS_STAMP(5);
+  return was_reset;
+}
+
 // One 64-env tile per wave, one launch covers all tiles (the hardware dispatcher balances blocks
 // whose deferred-reset drains differ in length).  A persistent grid-stride variant (256 x 3 resident
 // blocks, register prefetch of the next tile) measured 66.7 us vs 62.7 us for this shape, doubled the
@@ -169,7 +627,6 @@ PDS_DEV void sub_noise(const StepArgs &a, uint32_t env_id, long long ii, int sub
 // the tile loop -- pushed the kernel over the SGPR budget (137 v_writelane/v_readlane spill
 // instructions in the main path), so there is no tile loop here.
 // __launch_bounds__(256, 3): LDS admits 3 blocks (12 waves) per CU, so cap VGPRs at 168.
-template <class V, int TR>
 // The lean variants are additionally held to 128 VGPRs (min 4 waves/SIMD): measured 2-3 % faster
 // (62.7 vs 64.3 us Hover, 63.5 vs 64.7 us TakeOff+GE on the same box); the observation-noise
 // variants spill badly under that cap (154 vs 106 us) and keep 168.
@@ -179,431 +636,188 @@ template <class V, int TR>
 #ifndef PDS_MIN_WAVES
 #define PDS_MIN_WAVES (V::ON ? 3 : PDS_MIN_WAVES_LEAN)
 #endif
-__global__ __launch_bounds__(kBlock, PDS_MIN_WAVES) void step_kernel(const StepArgs a) {
-  constexpr int TASK = V::TASK;
-  constexpr int D = V::D;
-  constexpr int O = V::O;
-  // Auto-reset in registers before the stores, or deferred drain after them (see below).  Measured
-  // on one MI355X box, merged vs deferred: Hover 2^20 58.45 vs 60.0 us, Hover 2^21 108.5 vs 111.0 us;
-  // but Circle + PT1 + DR at 2^20 82.9 vs 78.6 us (181 VGPRs => 2 waves/SIMD), TakeOff (resets only by
-  // the 500-step truncation) 61.4 vs 60.7 us, and under the half tile's 128-VGPR cap it spills
-  // (Circle 262 144: 39 vs 21 us) -- so those keep the deferred drain.
-  constexpr bool MERGED = PDS_MERGED_RESET && !V::ON && TR == kWave && !(V::MOTOR && V::DR) && TASK != PDS_TASK_TAKEOFF;
-  __shared__ __attribute__((aligned(16))) float tile_all[(kBlock / kWave) * TR * D];
-  __shared__ float2 ref_lds[(TASK == PDS_TASK_CIRCLE) ? kRefPoints : 1];
-  __shared__ uint32_t queue_all[(kBlock / kWave) * kQueueCap];
-  const Consts &k = a.k;
-  const int tid = threadIdx.x;
-  const int lane = tid & (kWave - 1);
-  const int wave = tid >> 6;
-  if (TASK == PDS_TASK_CIRCLE) {
-    for (int t = tid; t < kRefPoints; t += kBlock) ref_lds[t] = a.st.circle_ref[t];
-    __syncthreads();
-  }
-  uint32_t *queue = queue_all + wave * kQueueCap;
-  int qcount = 0;  // wave-uniform
-  float *tile = tile_all + wave * (TR * D);
-  // full tile: the row is built in place in LDS; half tile: in registers, staged pass by pass
-  float rowbuf[(TR == kWave) ? 1 : D];
-  float *row = (TR == kWave) ? tile + lane * D : rowbuf;
-  const long long ntiles = (a.n + kWave - 1) / kWave;
-  const long long t = (long long)blockIdx.x * (kBlock / kWave) + wave;
-  if (t >= ntiles) return;  // wave-uniform
 
+// Auto-reset in registers before the stores, or deferred drain after them.  Measured on one MI355X
+// box, merged vs deferred: Hover 2^20 58.45 vs 60.0 us, Hover 2^21 108.5 vs 111.0 us; but Circle +
+// PT1 + DR at 2^20 82.9 vs 78.6 us (181 VGPRs => 2 waves/SIMD), TakeOff (resets only by the 500-step
+// truncation) 61.4 vs 60.7 us, and under the half tile's 128-VGPR cap it spills (Circle 262 144: 39
+// vs 21 us) -- so those keep the deferred drain.
+template <class V>
+constexpr bool merged_reset_variant() {
+  return PDS_MERGED_RESET && !V::ON && !V::LAT && !(V::MOTOR && V::DR) && V::TASK != PDS_TASK_TAKEOFF;
+}
+
+template <class V, int TR>
+struct WaveSetup {
+  float *tile;
+  uint32_t *queue;
+  int lane, wave;
+  long long t, wave_base, i, ii;
+  bool active, valid;
+};
+
+#define PDS_WAVE_SETUP(V, TR)                                                                          \
+  __shared__ __attribute__((aligned(16))) float tile_all[(kBlock / kWave) * TR * V::D];               \
+  __shared__ float2 ref_lds[(V::TASK == PDS_TASK_CIRCLE) ? kRefPoints : 1];                           \
+  __shared__ uint32_t queue_all[(kBlock / kWave) * kQueueCap];                                        \
+  const int tid = threadIdx.x;                                                                         \
+  const int lane = tid & (kWave - 1);                                                                  \
+  const int wave = tid >> 6;                                                                           \
+  if (V::TASK == PDS_TASK_CIRCLE) {                                                                    \
+    for (int t_ = tid; t_ < a.k.ref_points; t_ += kBlock) ref_lds[t_] = a.st.circle_ref[t_];          \
+    __syncthreads();                                                                                   \
+  }                                                                                                    \
+  uint32_t *queue = queue_all + wave * kQueueCap;                                                      \
+  float *tile = tile_all + wave * (TR * V::D);                                                         \
+  const long long ntiles = (a.n + kWave - 1) / kWave;                                                  \
+  const long long t = (long long)blockIdx.x * (kBlock / kWave) + wave;                                 \
+  if (t >= ntiles) return; /* wave-uniform */                                                          \
+  const long long wave_base = t * kWave;                                                               \
+  const long long i = wave_base + lane;                                                                \
+  const bool active = i < a.n;                                                                         \
+  const long long ii = active ? i : (a.n - 1); /* tail lanes recompute the last env, stores masked */
+
+#ifdef PDS_STAMPS
+#define PDS_STAMP_ARG , stamp_
+#define PDS_STAMP_DECL unsigned long long stamp_[kStampSlots] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; stamp_[0] = __builtin_amdgcn_s_memtime(); stamp_[8] = __builtin_amdgcn_s_memrealtime();
+#define PDS_STAMP_FLUSH                                                                                \
+  do {                                                                                                 \
+    PDS_STAMP_WAIT(7);                                                                                 \
+    stamp_[9] = __builtin_amdgcn_s_memrealtime();                                                      \
+    if (a.stamps != nullptr && lane == 0)                                                              \
+      for (int j_ = 0; j_ < kStampSlots; ++j_) a.stamps[t * kStampSlots + j_] = stamp_[j_];            \
+  } while (0)
+#else
+#define PDS_STAMP_ARG
+#define PDS_STAMP_DECL
+#define PDS_STAMP_FLUSH do { } while (0)
+#endif
+
+template <class V, int TR>
+__global__ __launch_bounds__(kBlock, PDS_MIN_WAVES) void step_kernel(const StepArgs a) {
+  PDS_STAMP_DECL
+  constexpr int RM = (merged_reset_variant<V>() && TR == kWave) ? RM_MERGED : RM_DEFERRED;
+  PDS_WAVE_SETUP(V, TR)
   // The loads are issued before anything else so that the scalar preamble of the kernel
   // (kernel-argument loads, uniform constants) overlaps with their latency.
-  const long long wave_base = t * kWave;
-  const long long i = wave_base + lane;
-  const bool active = i < a.n;
-  const long long ii = active ? i : (a.n - 1);  // tail lanes recompute the last env, stores masked
   Loaded cur;
-  load_env<V>(a, ii, cur);
+  load_env<V>(a, ii, t, cur);
   __builtin_amdgcn_sched_barrier(0);
-  {
-    const uint32_t env_id = (uint32_t)(a.env_id_base + (unsigned long long)ii);
-
-    const float4 act = cur.act, h1 = cur.h1, h2 = cur.h2;
-    const uint32_t ctr = cur.ctr;
-    float4 mx = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (V::MOTOR) mx = cur.mx;
-    Params par;
-    default_params(k, par);
-    if (V::DR) {
-      par.dt = cur.p0.x; par.m = cur.p0.y; par.Jx = cur.p0.z; par.Jy = cur.p0.w; par.Jz = cur.p1.x; par.ftf1 = cur.p1.y;
-      if (V::MOTOR) {
-        par.A[0] = cur.mA.x; par.A[1] = cur.mA.y; par.A[2] = cur.mA.z; par.A[3] = cur.mA.w;
-        par.K[0] = cur.mK.x; par.K[1] = cur.mK.y; par.K[2] = cur.mK.z; par.K[3] = cur.mK.w;
-      }
-    }
-    NoiseState ns;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) ns.ou[j] = 0.f;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) { ns.bias[j] = 0.f; ns.lpf[j] = 0.f; }
-    if (V::TN) { ns.ou[0] = cur.ou.x; ns.ou[1] = cur.ou.y; ns.ou[2] = cur.ou.z; ns.ou[3] = cur.ou.w; }
-    if (V::ON) {
-      ns.bias[0] = cur.nz0.x; ns.bias[1] = cur.nz0.y; ns.bias[2] = cur.nz0.z;
-      ns.lpf[0] = cur.nz0.w; ns.lpf[1] = cur.nz1.x; ns.lpf[2] = cur.nz1.y;
-    }
-    PidState ps;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) { ps.rate_int[j] = ps.rate_err[j] = ps.att_int[j] = ps.att_err[j] = 0.f; }
-    if (V::CTRL >= 1) {
-      ps.rate_int[0] = cur.pid0.x; ps.rate_int[1] = cur.pid0.y; ps.rate_int[2] = cur.pid0.z;
-      ps.rate_err[0] = cur.pid0.w; ps.rate_err[1] = cur.pid1.x; ps.rate_err[2] = cur.pid1.y;
-    }
-    if (V::CTRL == 2) {
-      ps.att_int[0] = cur.pid2.x; ps.att_int[1] = cur.pid2.y; ps.att_int[2] = cur.pid2.z;
-      ps.att_err[0] = cur.pid2.w; ps.att_err[1] = cur.pid3.x; ps.att_err[2] = cur.pid3.y;
-    }
-    EnvRegs e{cur.q0.x, cur.q0.y, cur.q0.z, cur.q0.w, cur.q1.x, cur.q1.y, cur.q1.z, cur.q1.w,
-              cur.q2.x, cur.q2.y, cur.q2.z, cur.q2.w};
-    const int step = (int)ctr_step(ctr);
-    const int ref_offset = (int)ctr_off(ctr);
-
-    // ---- o(k): first half of the row ------------------------------------------------------------
-    // noise-free: rebuilt from the pre-step state instead of being re-read from HBM;
-    // noisy: the stored noisy observation + the filtered gyro (== the low-pass state)
-    Quat q = quat_from_euler(e.roll, e.pitch, e.yaw);
-    {
-      float tx, ty, tz;
-      target_at<TASK>(k, ref_lds, target_index<TASK>(step, k.agg, ref_offset), tx, ty, tz);
-      if (V::ON) {
-        const NoisyObs ok{cur.oh0.x, cur.oh0.y, cur.oh0.z, cur.oh0.w, cur.oh1.x, cur.oh1.y, cur.oh1.z,
-                          cur.oh1.w, cur.oh2.x, cur.oh2.y};
-        write_noisy_half<TASK>(row, ok, ns.lpf, h1, tx, ty, tz, h2);
-      } else {
-        Quat qk = q;
-        if (ctr_sign(ctr)) { qk.x = -q.x; qk.y = -q.y; qk.z = -q.z; qk.w = -q.w; }
-        write_obs_half<TASK>(row, e, qk, h1, tx, ty, tz, h2);
-      }
-    }
-
-    // ---- aggregate_phy_steps x SimplePhysics.step_forward (envs/base.py:457-465) ---------------
-    float xm[4] = {mx.x, mx.y, mx.z, mx.w};
-    const float av[4] = {act.x, act.y, act.z, act.w};
-    // divisions by the per-env mass / inertia become multiplications by v_rcp_f32 results (1 ulp)
-    const float inv_m = fast_rcp(par.m), inv_Jx = fast_rcp(par.Jx), inv_Jy = fast_rcp(par.Jy), inv_Jz = fast_rcp(par.Jz);
-    for (int sub = 0; sub < k.agg; ++sub) {
-      SubNoise sn;
-      if (V::TN || V::ON) sub_noise<V>(a, env_id, ii, sub, sn);
-      // CrazyFlieAgent.apply_action, envs/agents.py:259-298 (+ PWM.act envs/control.py:94-100)
-      float f[4], pwmv[4];
-      if (V::CTRL == 0) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) pwmv[j] = 30000.f + clampf(av[j], -1.f, 1.f) * 30000.f;
-      } else {
-        control_pwm<V::CTRL>(k.dt_nom, e, av, ps, pwmv);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float un = pwmv[j] * (1.0f / 60000.f);
-        float noise1 = 1.0f;
-        if (V::TN) {  // OUNoise.noise, envs/utils.py:104-108 (theta .15, mu 0); never reset
-          ns.ou[j] = ns.ou[j] + (0.15f * (0.f - ns.ou[j]) + k.ou_sigma * sn.ou[j]);
-          noise1 = 1.0f + ns.ou[j];
-        }
-        float n;
-        if (V::MOTOR) {
-          xm[j] = par.A[j] * xm[j] + (1.0f - par.A[j]) * fast_sqrt(un);
-          n = noise1 * (xm[j] * xm[j]);
-        } else {
-          n = noise1 * un;
-        }
-        f[j] = par.K[j] * clampf(n, 0.f, 1.f);
-      }
-      // yaw torque: sum of +-(ftf1*f_i + ftf0); ftf0 cancels (envs/agents.py:295-297)
-      const float tz_ = par.ftf1 * (-f[0] + f[1] - f[2] + f[3]);
-      float R[9];
-      matrix_from_quat(q, R);  // envs/physics.py:160 (quaternion of the PREVIOUS step)
-      if (V::GE) {
-        // BasePhysics.calculate_ground_effect, envs/physics.py:27-58, applied as extra per-motor
-        // thrust (envs/physics.py:117-120); branch-free per-env scale
-        const float ok = (fabsf(e.roll) < kHalfPi && fabsf(e.pitch) < kHalfPi) ? 1.f : 0.f;
-        const float ox[4] = {0.028f, -0.028f, -0.028f, 0.028f};
-        const float oy[4] = {-0.028f, -0.028f, 0.028f, 0.028f};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float hz = fmaxf(e.pz + (R[6] * ox[j] + R[7] * oy[j]), k.h_clip);
-          const float qq = k.prop_r * fast_rcp(4.f * hz);
-          f[j] = f[j] + ok * (f[j] * k.gec * (qq * qq));
-        }
-      }
-      const float thrust = ((f[0] + f[1]) + f[2]) + f[3];
-      const float Fx = R[2] * thrust, Fy = R[5] * thrust, Fz = R[8] * thrust - k.G * par.m;
-      const float tx_ = (-f[0] - f[1] + f[2] + f[3]) * k.Lq;  // envs/physics.py:167
-      const float ty_ = (-f[0] + f[1] + f[2] - f[3]) * k.Lq;  // envs/physics.py:168
-      const float Jwx = par.Jx * e.wx, Jwy = par.Jy * e.wy, Jwz = par.Jz * e.wz;
-      const float t0 = tx_ - (e.wy * Jwz - e.wz * Jwy);  // tau - w x (J w), envs/physics.py:170-171
-      const float t1 = ty_ - (e.wz * Jwx - e.wx * Jwz);
-      const float t2 = tz_ - (e.wx * Jwy - e.wy * Jwx);
-      const float dt = par.dt;
-      e.vx += dt * (Fx * inv_m); e.vy += dt * (Fy * inv_m); e.vz += dt * (Fz * inv_m);    // :173,175
-      e.wx += dt * (t0 * inv_Jx); e.wy += dt * (t1 * inv_Jy); e.wz += dt * (t2 * inv_Jz);  // :172,176
-      e.px += dt * e.vx; e.py += dt * e.vy; e.pz += dt * e.vz;                             // :177
-      e.roll += dt * e.wx; e.pitch += dt * e.wy; e.yaw += dt * e.wz;                       // :178
-      q = quat_from_euler(e.roll, e.pitch, e.yaw);                                         // :179
-      e.pz = fmaxf(e.pz, 0.f);                                                             // :182
-      // envs/base.py:464: compute_observation() whose result is dropped still advances the gyro
-      // bias random walk and the low-pass filter
-      if (V::ON) gyro_update(k, e, sn.bias_z, sn.rw_z, sn.to_z, ns);
-    }
-
-    // ---- task: target, done, reward, cost (all on the TRUE state) -------------------------------
-    float tx, ty, tz;
-    target_at<TASK>(k, ref_lds, target_index<TASK>(step + 1, k.agg, ref_offset), tx, ty, tz);
-    const float dx = e.px - tx, dy = e.py - ty, dz = e.pz - tz;
-    const float dist = fast_sqrt(dx * dx + dy * dy + dz * dz);
-    bool done = false;
-    if (TASK == PDS_TASK_HOVER) {  // envs/hover.py:89-101
-      constexpr float lim = 60.f * kPi / 180.f;
-      constexpr float r2d = 180.f / kPi;
-      done = (e.pz < 0.2f) || (fabsf(e.roll) > lim) || (fabsf(e.pitch) > lim) ||
-             (fabsf(e.wx) * r2d > 300.f) || (fabsf(e.wy) * r2d > 300.f) || (fabsf(e.wz) * r2d > 300.f);
-    } else if (TASK == PDS_TASK_CIRCLE) {  // envs/circle.py:116-120
-      done = dist > 0.25f;
-    }
-    float reward;
-    {  // envs/hover.py:169-187, envs/circle.py:183-204, envs/takeoff.py:155-174
-      const float n0 = 0.5f * (clampf(act.x, -1.f, 1.f) + 1.f), n1 = 0.5f * (clampf(act.y, -1.f, 1.f) + 1.f);
-      const float n2 = 0.5f * (clampf(act.z, -1.f, 1.f) + 1.f), n3 = 0.5f * (clampf(act.w, -1.f, 1.f) + 1.f);
-      const float pen_act = k.pa * fast_sqrt(n0 * n0 + n1 * n1 + n2 * n2 + n3 * n3);
-      float pen_rate = 0.f;
-      if (TASK == PDS_TASK_CIRCLE) {  // a - env.last_action (previous action, envs/circle.py:186)
-        const float d0 = act.x - h1.x, d1 = act.y - h1.y, d2 = act.z - h1.z, d3 = act.w - h1.w;
-        pen_rate = k.arp * fast_sqrt(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
-      }
-      float pen_rpy = 0.f;
-      if (k.pang != 0.f) pen_rpy = k.pang * fast_sqrt(e.roll * e.roll + e.pitch * e.pitch + e.yaw * e.yaw);
-      const float pen_spin = k.pspin * fast_sqrt(e.wx * e.wx + e.wy * e.wy + e.wz * e.wz);
-      const float pen_term = done ? k.pterm : 0.f;
-      // envs/takeoff.py:165 multiplies the velocity norm by penalty_ACTION
-      const float pv = (TASK == PDS_TASK_TAKEOFF) ? k.pa : k.pvel;
-      float pen_vel = 0.f;
-      if (pv != 0.f) pen_vel = pv * fast_sqrt(e.vx * e.vx + e.vy * e.vy + e.vz * e.vz);
-      const float penalties = ((((pen_rpy + pen_rate) + pen_spin) + pen_vel) + pen_act) + pen_term;
-      reward = -dist - penalties;
-      if (TASK == PDS_TASK_TAKEOFF && e.pz < 0.08f) reward -= 1.f;  // envs/takeoff.py:172-173
-    }
-    float cost = 0.f;
-    if (TASK == PDS_TASK_HOVER) {
-      // envs/hover.py:103-129: state[10:13] is rpy_dot and state[13:16] is last_action[0:3] in the
-      // get_state layout -- reproduced as is
-      constexpr float rp_lim = 10.f * kPi / 180.f, dot_lim = 200.f * kPi / 180.f;
-      const bool c = (fabsf(e.px) > 0.10f) || (fabsf(e.py) > 0.10f) || (e.pz > 1.20f) ||
-                     (fabsf(e.roll) > rp_lim) || (fabsf(e.pitch) > rp_lim) ||
-                     (fabsf(e.wx) > 0.25f) || (fabsf(e.wy) > 0.25f) || (fabsf(e.wz) > 0.25f) ||
-                     (fabsf(act.x) > dot_lim) || (fabsf(act.y) > dot_lim) || (fabsf(act.z) > dot_lim);
-      cost = c ? 1.f : 0.f;
-    }
-    const bool trunc = (step + 1) >= k.max_steps;  // gymnasium TimeLimit, __init__.py:11
-
-    // ---- o(k+1) and u(k-1) -> second half of the row (envs/base.py:303-319) --------------------
-    NoisyObs on_new;
-    if (V::ON) {
-      ObsNoise n;
-      if (a.noise != nullptr) obs_noise_load(a.noise + ii * PDS_NOISE_FLOATS + PDS_N_OBS, n);
-      else obs_noise_philox(env_id, a, kBlkObsNoise, n);
-      sensor_observe(k, e, n, ns, on_new);
-      write_noisy_half<TASK>(row + O + 4, on_new, ns.lpf, act, tx, ty, tz, h1);
-    } else {
-      write_obs_half<TASK>(row + O + 4, e, q, act, tx, ty, tz, h1);
-    }
-
-    uint32_t ctr_new = ctr_pack((uint32_t)(step + 1), 0u, (uint32_t)ref_offset);
-    float4 hist_new = act;  // -> hist[parity ^ 1]: overwrites u(k-2); next step's parity makes it u(k-1)
-    // ---- auto-reset.  ~2 % of the envs finish per step under random actions, i.e. 3 of 4 waves
-    // hold one or two finished envs.  Their last observation goes to final_obs (below, out of the
-    // LDS tile); the reset itself is done densely, 8 lanes per finished env:
-    //  * without observation noise: now, in registers (reset_in_registers), so the fresh state and
-    //    observation leave through the wave's ordinary coalesced stores;
-    //  * with observation noise (the reset needs much more state): deferred to a drain after the
-    //    stores (drain_reset_queue).
-    const bool need_reset = a.auto_reset && (done || trunc) && active;
-    const unsigned long long reset_mask = __ballot(need_reset);  // wave-uniform
-    const unsigned long long done_mask = (a.final_obs != nullptr) ? reset_mask : 0ull;  // -> final_obs
-    if (reset_mask != 0ull) {  // wave-uniform
-      const int pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(reset_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)reset_mask, 0u));
-      qcount = __popcll(reset_mask);
-      if (!MERGED) {
-        if (need_reset) queue[pos] = (uint32_t)lane | ((uint32_t)ref_offset << 6);
-      } else {
-        if (need_reset) queue[pos] = (uint32_t)lane;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        float4 u0 = act, mxr = make_float4(xm[0], xm[1], xm[2], xm[3]);
-        if constexpr (MERGED)
-          reset_in_registers<V>(a, ref_lds, queue, qcount, need_reset, pos, lane, wave_base, ref_offset, e, q, u0,
-                                mxr, par, ctr_new);
-        if (need_reset) {
-          hist_new = u0;
-          xm[0] = mxr.x; xm[1] = mxr.y; xm[2] = mxr.z; xm[3] = mxr.w;
-#pragma unroll
-          for (int j = 0; j < 3; ++j) { ps.rate_int[j] = ps.rate_err[j] = ps.att_int[j] = ps.att_err[j] = 0.f; }
-          // written only by resets (no write-after-write with this step's stores)
-          a.st.hist[a.parity][i] = u0;
-          if (V::DR) {
-            a.st.par0[i] = make_float4(par.dt, par.m, par.Jx, par.Jy);
-            a.st.par1[i] = make_float2(par.Jz, par.ftf1);
-            if (V::MOTOR) {
-              a.st.mA[i] = make_float4(par.A[0], par.A[1], par.A[2], par.A[3]);
-              a.st.mK[i] = make_float4(par.K[0], par.K[1], par.K[2], par.K[3]);
-            }
-          }
-        }
-      }
-    }
-
-    // ---- coalesced stores ----------------------------------------------------------------------
-    if (active) {
-      st_store4(a.st.s0 + i, make_float4(e.px, e.py, e.pz, e.vx));
-      st_store4(a.st.s1 + i, make_float4(e.vy, e.vz, e.roll, e.pitch));
-      st_store4(a.st.s2 + i, make_float4(e.yaw, e.wx, e.wy, e.wz));
-      st_store4(a.st.hist[a.parity ^ 1] + i, hist_new);
-      a.st.ctr[i] = ctr_new;
-      if (V::MOTOR) a.st.mx[i] = make_float4(xm[0], xm[1], xm[2], xm[3]);
-      if (V::TN) a.st.ou[i] = make_float4(ns.ou[0], ns.ou[1], ns.ou[2], ns.ou[3]);
-      if (V::CTRL >= 1) {
-        a.st.pid0[i] = make_float4(ps.rate_int[0], ps.rate_int[1], ps.rate_int[2], ps.rate_err[0]);
-        a.st.pid1[i] = make_float2(ps.rate_err[1], ps.rate_err[2]);
-      }
-      if (V::CTRL == 2) {
-        a.st.pid2[i] = make_float4(ps.att_int[0], ps.att_int[1], ps.att_int[2], ps.att_err[0]);
-        a.st.pid3[i] = make_float2(ps.att_err[1], ps.att_err[2]);
-      }
-      if (V::ON) {
-        a.st.nz0[i] = make_float4(ns.bias[0], ns.bias[1], ns.bias[2], ns.lpf[0]);
-        a.st.nz1[i] = make_float2(ns.lpf[1], ns.lpf[2]);
-        a.st.oh0[i] = make_float4(on_new.x, on_new.y, on_new.z, on_new.qx);
-        a.st.oh1[i] = make_float4(on_new.qy, on_new.qz, on_new.qw, on_new.vx);
-        a.st.oh2[i] = make_float2(on_new.vy, on_new.vz);
-      }
-      nt_store(a.reward + i, reward);
-      nt_store(a.cost + i, cost);
-      nt_store(a.term + i, (uint8_t)(done ? 1 : 0));
-      nt_store(a.trunc + i, (uint8_t)(trunc ? 1 : 0));
-    }
-    // LDS rows of this wave were written by its own lanes only: wave-synchronous, no block barrier
-    const long long rem = a.n - wave_base;
-#pragma unroll
-    for (int pass = 0; pass < kWave / TR; ++pass) {
-      if (TR != kWave) {
-        if ((lane / TR) == pass) {
-          float *dst = tile + (lane % TR) * D;
-#pragma unroll
-          for (int j = 0; j < D; ++j) dst[j] = rowbuf[j];
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      // last observation of each finished env -> final_obs: the whole wave copies one row
-      // (D <= 64 contiguous floats) per finished env straight out of the LDS tile
-      unsigned long long m = done_mask;
-      if (TR != kWave) m &= (pass == 0) ? 0x00000000FFFFFFFFull : 0xFFFFFFFF00000000ull;
-      while (m != 0ull) {
-        const int src_lane = __builtin_ctzll(m);
-        m &= m - 1ull;
-        // non-temporal like the other streamed outputs (same box: 57.7 vs 58.4 us on Hover 2^20)
-        if (lane < D) nt_store(a.final_obs + (wave_base + src_lane) * D + lane, tile[(src_lane % TR) * D + lane]);
-      }
-      if (MERGED && reset_mask != 0ull) {  // wave-uniform: the reset envs' rows become [o0, u0, o0, u0]
-        if (need_reset && (TR == kWave || (lane / TR) == pass)) {
-          float tx0, ty0, tz0;
-          target_at<TASK>(k, ref_lds, target_index<TASK>(0, k.agg, (int)ctr_off(ctr_new)), tx0, ty0, tz0);
-          float *dst = tile + (lane % TR) * D;
-          write_obs_half<TASK>(dst, e, q, hist_new, tx0, ty0, tz0, hist_new);
-          write_obs_half<TASK>(dst + O + 4, e, q, hist_new, tx0, ty0, tz0, hist_new);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      }
-      const long long left = rem - pass * TR;
-      if (left > 0)
-        flush_tile<D, TR>(tile, a.obs + (wave_base + pass * TR) * D, left >= TR ? TR : (int)left, lane);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();  // the tile is rewritten by the next pass / the reset drain
-    }
-  }
-  if (!MERGED && qcount > 0) drain_reset_queue<V>(a, ref_lds, queue, qcount, lane, wave_base, tile);
+  PDS_STAMP(1);
+  PDS_STAMP_WAIT(2);
+  RngKey rk{a.seed_lo, a.seed_hi, 0u, 0u};
+  int parity;
+  rk.tick_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.clk.x);
+  rk.tick_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.clk.y);
+  parity = __builtin_amdgcn_readfirstlane((int)cur.clk.z) & 1;
+  EnvState S;
+  unpack_state<V>(a.k, cur, parity, S);
+  int qcount = 0;  // wave-uniform
+  step_once<V, TR, RM, true>(a, 0ll, rk, parity, ref_lds, tile, queue, lane, wave_base, i, ii, active, cur.act, S, qcount PDS_STAMP_ARG);
+  if (RM == RM_DEFERRED && qcount > 0) drain_reset_queue<V>(a, rk, ref_lds, queue, qcount, lane, wave_base, tile);
+  PDS_STAMP(6);
+  advance_clock(a.st.clk, t, rk, parity ^ 1, 1u, lane);
+  PDS_STAMP_FLUSH;
 }
 
-// ---- per-task instantiation (one translation unit per task keeps the build parallel) -----------
-#define PDS_DISPATCH5(FN, TASK, f, ...)                                                              \
-  do {                                                                                                \
-    const int key_ = (f.motor ? 16 : 0) | (f.dr ? 8 : 0) | (f.ge ? 4 : 0) | (f.tn ? 2 : 0) | (f.on ? 1 : 0); \
-    switch (key_) {                                                                                   \
-      PDS_CASES16(FN, TASK, 0, false, __VA_ARGS__)                                                    \
-      PDS_CASES16(FN, TASK, 16, true, __VA_ARGS__)                                                    \
-    }                                                                                                 \
-  } while (0)
-#define PDS_CASES16(FN, TASK, base, M, ...)                                                          \
-  PDS_CASES8(FN, TASK, base, M, false, __VA_ARGS__) PDS_CASES8(FN, TASK, base + 8, M, true, __VA_ARGS__)
-#define PDS_CASES8(FN, TASK, base, M, R, ...)                                                        \
-  PDS_CASES4(FN, TASK, base, M, R, false, __VA_ARGS__) PDS_CASES4(FN, TASK, base + 4, M, R, true, __VA_ARGS__)
-#define PDS_CASES4(FN, TASK, base, M, R, G, ...)                                                     \
-  case base + 0: FN((Variant<TASK, M, R, G, false, false>), __VA_ARGS__); break;                     \
-  case base + 1: FN((Variant<TASK, M, R, G, false, true>), __VA_ARGS__); break;                      \
-  case base + 2: FN((Variant<TASK, M, R, G, true, false>), __VA_ARGS__); break;                      \
-  case base + 3: FN((Variant<TASK, M, R, G, true, true>), __VA_ARGS__); break;
-
-#define PDS_UNPAREN(...) __VA_ARGS__
+// K env.step()s per launch for open-loop action sequences (pds_step_k): the env state stays in
+// registers, per step only the action (16 B) comes in and the observation row, reward, cost and flags
+// go out -- 4 D + 26 B per env-step instead of 4 D + 178 B, and one launch instead of K.
 template <class V>
-inline void launch_step_variant(bool half_tile, dim3 grid, hipStream_t s, const StepArgs &a) {
-  if constexpr (!V::ON) {
-    if (half_tile) {
-      hipLaunchKernelGGL((step_kernel<V, kHalfTileRows>), grid, dim3(kBlock), 0, s, a);
-      return;
-    }
+__global__ __launch_bounds__(kBlock, 3) void step_k_kernel(const StepArgs a) {
+  constexpr int TR = kWave;
+  constexpr int RM = merged_reset_variant<V>() ? RM_MERGED : RM_INLINE;
+#ifdef PDS_STAMPS
+  unsigned long long stamp_[kStampSlots];
+#endif
+  PDS_WAVE_SETUP(V, TR)
+  Loaded cur;
+  load_env<V>(a, ii, t, cur);
+  RngKey rk{a.seed_lo, a.seed_hi, 0u, 0u};
+  int parity;
+  rk.tick_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.clk.x);
+  rk.tick_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.clk.y);
+  parity = __builtin_amdgcn_readfirstlane((int)cur.clk.z) & 1;
+  const RngKey rk0 = rk;
+  EnvState S;
+  unpack_state<V>(a.k, cur, parity, S);
+  const int K = a.k_steps;
+  float4 act = cur.act;  // actions[0]
+  int qcount = 0;
+  for (int s = 0; s < K; ++s) {
+    float4 act_next = act;
+    if (s + 1 < K) act_next = nt_load4(a.actions + (long long)(s + 1) * a.n + ii);  // in flight during step s
+    step_once<V, TR, RM, false>(a, (long long)s * a.n, rk, parity, ref_lds, tile, queue, lane, wave_base, i, ii, active, act, S, qcount PDS_STAMP_ARG);
+    act = act_next;
+    parity ^= 1;
+    rk.tick_lo += 1u;
+    if (rk.tick_lo == 0u) rk.tick_hi += 1u;
   }
-  hipLaunchKernelGGL((step_kernel<V, kWave>), grid, dim3(kBlock), 0, s, a);
+  if (active) store_state<V>(a, i, parity, S, true);
+  advance_clock(a.st.clk, t, rk0, parity, (uint32_t)K, lane);
 }
-#define PDS_LAUNCH_STEP(V, grid, s, a) launch_step_variant<PDS_UNPAREN V>(f.half_tile, grid, s, a)
-#define PDS_LAUNCH_RESET(V, grid, s, a) hipLaunchKernelGGL((reset_kernel<PDS_UNPAREN V>), grid, dim3(kBlock), 0, s, a)
 
-// PID control modes: 16 variants each (motor x DR x thrust noise x observation noise), no ground effect
-#define PDS_PID_CASES(TASK, C, grid, s, a)                                                            \
-  switch ((f.motor ? 8 : 0) | (f.dr ? 4 : 0) | (f.tn ? 2 : 0) | (f.on ? 1 : 0)) {                    \
-    case 0: PDS_LAUNCH_STEP((Variant<TASK, false, false, false, false, false, C>), grid, s, a); break; \
-    case 1: PDS_LAUNCH_STEP((Variant<TASK, false, false, false, false, true, C>), grid, s, a); break;  \
-    case 2: PDS_LAUNCH_STEP((Variant<TASK, false, false, false, true, false, C>), grid, s, a); break;  \
-    case 3: PDS_LAUNCH_STEP((Variant<TASK, false, false, false, true, true, C>), grid, s, a); break;   \
-    case 4: PDS_LAUNCH_STEP((Variant<TASK, false, true, false, false, false, C>), grid, s, a); break;  \
-    case 5: PDS_LAUNCH_STEP((Variant<TASK, false, true, false, false, true, C>), grid, s, a); break;   \
-    case 6: PDS_LAUNCH_STEP((Variant<TASK, false, true, false, true, false, C>), grid, s, a); break;   \
-    case 7: PDS_LAUNCH_STEP((Variant<TASK, false, true, false, true, true, C>), grid, s, a); break;    \
-    case 8: PDS_LAUNCH_STEP((Variant<TASK, true, false, false, false, false, C>), grid, s, a); break;  \
-    case 9: PDS_LAUNCH_STEP((Variant<TASK, true, false, false, false, true, C>), grid, s, a); break;   \
-    case 10: PDS_LAUNCH_STEP((Variant<TASK, true, false, false, true, false, C>), grid, s, a); break;  \
-    case 11: PDS_LAUNCH_STEP((Variant<TASK, true, false, false, true, true, C>), grid, s, a); break;   \
-    case 12: PDS_LAUNCH_STEP((Variant<TASK, true, true, false, false, false, C>), grid, s, a); break;  \
-    case 13: PDS_LAUNCH_STEP((Variant<TASK, true, true, false, false, true, C>), grid, s, a); break;   \
-    case 14: PDS_LAUNCH_STEP((Variant<TASK, true, true, false, true, false, C>), grid, s, a); break;   \
-    default: PDS_LAUNCH_STEP((Variant<TASK, true, true, false, true, true, C>), grid, s, a); break;    \
+// ---- host-side dispatch: runtime flags -> template instantiation ----------------------------------
+template <class V>
+inline void launch_variant(int kind, bool half_tile, dim3 grid, hipStream_t s, const StepArgs &a) {
+  if (kind == kLaunchReset) {
+    hipLaunchKernelGGL((reset_kernel<V>), grid, dim3(kBlock), 0, s, a);
+  } else if (kind == kLaunchStepK) {
+    // (the PID control modes have no K-step kernel: pds_step_k loops over pds_step for them)
+    if constexpr (V::CTRL == 0) hipLaunchKernelGGL((step_k_kernel<V>), grid, dim3(kBlock), 0, s, a);
+  } else {
+    if constexpr (!V::ON && !V::LAT) {
+      if (half_tile) {
+        hipLaunchKernelGGL((step_kernel<V, kHalfTileRows>), grid, dim3(kBlock), 0, s, a);
+        return;
+      }
+    }
+    hipLaunchKernelGGL((step_kernel<V, kWave>), grid, dim3(kBlock), 0, s, a);
   }
+}
 
-#define PDS_DEFINE_TASK_LAUNCHERS(NAME, TASK)                                                        \
-  void launch_step_##NAME(const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a) {       \
-    if (f.ctrl == 0) {                                                                                \
-      PDS_DISPATCH5(PDS_LAUNCH_STEP, TASK, f, grid, s, a);                                           \
-    } else if (TASK != PDS_TASK_TAKEOFF) { /* TakeOff fixes control_mode='PWM', envs/takeoff.py:225 */ \
-      if (f.ctrl == 1) { PDS_PID_CASES(TASK, 1, grid, s, a) } else { PDS_PID_CASES(TASK, 2, grid, s, a) } \
-    }                                                                                                 \
-  }                                                                                                   \
-  void launch_reset_##NAME(const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a) {      \
-    /* the reset code does not depend on the GE / TN flags: 8 variants */                            \
-    switch ((f.motor ? 4 : 0) | (f.dr ? 2 : 0) | (f.on ? 1 : 0)) {                                    \
-      case 0: PDS_LAUNCH_RESET((Variant<TASK, false, false, false, false, false>), grid, s, a); break; \
-      case 1: PDS_LAUNCH_RESET((Variant<TASK, false, false, false, false, true>), grid, s, a); break;  \
-      case 2: PDS_LAUNCH_RESET((Variant<TASK, false, true, false, false, false>), grid, s, a); break;  \
-      case 3: PDS_LAUNCH_RESET((Variant<TASK, false, true, false, false, true>), grid, s, a); break;   \
-      case 4: PDS_LAUNCH_RESET((Variant<TASK, true, false, false, false, false>), grid, s, a); break;  \
-      case 5: PDS_LAUNCH_RESET((Variant<TASK, true, false, false, false, true>), grid, s, a); break;   \
-      case 6: PDS_LAUNCH_RESET((Variant<TASK, true, true, false, false, false>), grid, s, a); break;   \
-      default: PDS_LAUNCH_RESET((Variant<TASK, true, true, false, false, true>), grid, s, a); break;   \
-    }                                                                                                 \
+template <int TASK, int CTRL, bool LAT, bool MOTOR, bool DR, bool GE, bool TN, bool ON>
+struct MakeVariant {
+  using type = Variant<TASK, MOTOR, DR, GE, TN, ON, CTRL, LAT>;
+};
+
+// binds the boolean flags one by one: Bs... = MOTOR, DR, GE, TN, ON
+template <int TASK, int CTRL, bool LAT, bool... Bs>
+struct VariantDispatch {
+  template <typename... Rest>
+  static void run(int kind, bool half, dim3 grid, hipStream_t s, const StepArgs &a, bool first, Rest... rest) {
+    if (first) VariantDispatch<TASK, CTRL, LAT, Bs..., true>::run(kind, half, grid, s, a, rest...);
+    else VariantDispatch<TASK, CTRL, LAT, Bs..., false>::run(kind, half, grid, s, a, rest...);
   }
+  static void run(int kind, bool half, dim3 grid, hipStream_t s, const StepArgs &a) {
+    static_assert(sizeof...(Bs) == 5, "MOTOR, DR, GE, TN, ON");
+    launch_variant<typename MakeVariant<TASK, CTRL, LAT, Bs...>::type>(kind, half, grid, s, a);
+  }
+};
+
+// Families (one translation unit each, see pds_task_*.hip):
+//  base: control_mode PWM, no latency: motor x DR x GE x TN x ON  (32 step variants, half + full tile)
+//  pid:  AttitudeRate / Attitude, no ground effect, no latency     (2 x 16)
+//  lat:  use_latency, any control mode, no ground effect            (3 x 16; TakeOff: PWM only)
+// The reset kernel does not depend on GE / TN / CTRL: those flags are folded to false / 0 for it.
+template <int TASK>
+inline void launch_base(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a) {
+  if (kind == kLaunchReset) VariantDispatch<TASK, 0, false>::run(kind, false, grid, s, a, f.motor, f.dr, false, false, f.on);
+  else VariantDispatch<TASK, 0, false>::run(kind, f.half_tile, grid, s, a, f.motor, f.dr, f.ge, f.tn, f.on);
+}
+template <int TASK>
+inline void launch_pid(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a) {
+  if (f.ctrl == 1) VariantDispatch<TASK, 1, false>::run(kind, f.half_tile, grid, s, a, f.motor, f.dr, false, f.tn, f.on);
+  else VariantDispatch<TASK, 2, false>::run(kind, f.half_tile, grid, s, a, f.motor, f.dr, false, f.tn, f.on);
+}
+template <int TASK>
+inline void launch_lat(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a) {
+  if (kind == kLaunchReset) { VariantDispatch<TASK, 0, true>::run(kind, false, grid, s, a, f.motor, f.dr, false, false, f.on); return; }
+  if (TASK == PDS_TASK_TAKEOFF || f.ctrl == 0) VariantDispatch<TASK, 0, true>::run(kind, false, grid, s, a, f.motor, f.dr, false, f.tn, f.on);
+  else if constexpr (TASK != PDS_TASK_TAKEOFF) {  // TakeOff fixes control_mode='PWM', envs/takeoff.py:225
+    if (f.ctrl == 1) VariantDispatch<TASK, 1, true>::run(kind, false, grid, s, a, f.motor, f.dr, false, f.tn, f.on);
+    else VariantDispatch<TASK, 2, true>::run(kind, false, grid, s, a, f.motor, f.dr, false, f.tn, f.on);
+  }
+}
 
 }  // namespace pds

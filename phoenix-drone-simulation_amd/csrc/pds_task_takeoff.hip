@@ -1,8 +1,8 @@
-// pds_task_takeoff.hip -- instantiates the fused step / reset kernels of pds_step.h for one task
-// (32 step variants: motor dynamics x domain randomisation x ground effect x thrust noise x
-// observation noise; 8 reset variants).
+// pds_task_takeoff.hip -- instantiates the fused step / K-step / reset kernels of pds_step.h for one task,
+// control_mode PWM, no latency (32 variants: motor dynamics x domain randomisation x ground effect x
+// thrust noise x observation noise; the variants without observation noise twice: full and half tile).
 #include "pds_step.h"
 
 namespace pds {
-PDS_DEFINE_TASK_LAUNCHERS(takeoff, PDS_TASK_TAKEOFF)
+void launch_takeoff(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a) { launch_base<PDS_TASK_TAKEOFF>(kind, f, grid, s, a); }
 }  // namespace pds

@@ -24,18 +24,31 @@ constexpr int kWave = 64;
 // 2.7 rounds of the 3-blocks-per-CU residency (Circle 262 144 + PT1 + DR: 20.8 vs 24.9 us); the full
 // tile wins by 1-2 % from 2^20 envs up (fewer registers, one flush).  pds_step picks per launch.
 constexpr int kHalfTileRows = 32;
-constexpr int kCUs = 256;            // MI355X
-constexpr int kFullTileBlocksPerCU = 3;
+constexpr int kFullTileBlocksPerCU = 3;  // x hipDeviceProp.multiProcessorCount (256 on MI355X), queried in pds_create
 constexpr int kQueueCap = 64;    // deferred-reset queue entries per wave (LDS): one tile
 constexpr int kRefPoints = 300;  // envs/circle.py:48, envs/takeoff.py:43
 constexpr int kStaggerBytes = 4352;  // 17 x 256 B between consecutive state arrays in the slab
 
+constexpr int kMaxLatSteps = PDS_MAX_LATENCY_STEPS;  // rows of the latency action ring (envs/agents.py:180-182)
+
 // ---- packing of the per-env counter word --------------------------------------------------------
 // bits 0..15 env.step calls since reset | bit 16 quaternion == -Q(rpy) | bits 17..25 Circle ref_offset
-PDS_DEV uint32_t ctr_pack(uint32_t step, uint32_t sign, uint32_t off) { return step | (sign << 16) | (off << 17); }
+// | bits 26..28 action_idx of the latency ring (envs/agents.py:183,273)
+PDS_DEV uint32_t ctr_pack(uint32_t step, uint32_t sign, uint32_t off, uint32_t lat_idx = 0u) {
+  return step | (sign << 16) | (off << 17) | (lat_idx << 26);
+}
 PDS_DEV uint32_t ctr_step(uint32_t c) { return c & 0xFFFFu; }
 PDS_DEV uint32_t ctr_sign(uint32_t c) { return (c >> 16) & 1u; }
 PDS_DEV uint32_t ctr_off(uint32_t c) { return (c >> 17) & 0x1FFu; }
+PDS_DEV uint32_t ctr_lat(uint32_t c) { return (c >> 26) & 0x7u; }
+
+// ---- per-wave clock word (device memory) ----------------------------------------------------------
+// x, y: tick (counts pds_reset* / pds_step calls; words 1 and 2 of the Philox counter), z: parity of
+// the action ring.  One word per 64-env tile, read by the wave that owns the tile when it starts
+// and advanced by its lane 0 when it ends: no kernel argument changes from one step to the next, so
+// a stream of pds_step calls can be captured in a hipGraph and replayed (a wave reads its word
+// before it writes it; no other wave touches it; the next launch on the stream sees the update).
+typedef uint4 WaveClock;
 
 // ---- SoA state in HBM (one float4 "quad" per env and array => 16 B/lane coalesced streams) ------
 struct DevState {
@@ -59,6 +72,8 @@ struct DevState {
   float2 *pid1;     // rate-PID last_error y z
   float4 *pid2;     // attitude-PID integral xyz, last_error x (control_mode == Attitude)
   float2 *pid3;     // attitude-PID last_error y z
+  float4 *lat;      // [lat_steps][N] delayed-action ring (use_latency; envs/agents.py:267-273)
+  WaveClock *clk;   // [ceil(N / 64)] tick + parity of each tile
   const float2 *circle_ref;  // [300] (x, y) of the reference circle, z = 1
 };
 
@@ -75,6 +90,9 @@ struct Consts {
   // constants of sensors.py:124-128 evaluated on the host in double for dt = 1/sim_freq)
   float ou_sigma, pos_std, pos_unif, vel_std, q_std, q_unif, gyro_pi, gyro_sb, gyro_rw, gyro_to;
   int agg, max_steps, reset_dist;
+  int lat_steps;   // buf_size of the latency ring (0: use_latency False)
+  int lat_own1, lat_own2;  // step whose action action_buffer[-1] holds after env.step 1 / 2 (0: still the reset row)
+  int ref_points;  // Circle: circle_time * observation_frequency (envs/circle.py:49), <= kRefPoints
 };
 
 struct StepArgs {
@@ -92,15 +110,22 @@ struct StepArgs {
   const float *noise;    // step kernel: injected standard variates [N, PDS_NOISE_FLOATS] or nullptr
   long long n;
   unsigned long long env_id_base;
-  uint32_t seed_lo, seed_hi, tick_lo, tick_hi;
-  int parity;
+  uint32_t seed_lo, seed_hi;
   int auto_reset;
+  int k_steps;                // step_k_kernel: number of env.step()s per launch
+  unsigned long long *stamps;  // diagnostic builds (-DPDS_STAMPS): s_memtime stamps per wave
+};
+
+// tick + seed of the current call: words of the Philox counter / key
+struct RngKey {
+  uint32_t seed_lo, seed_hi, tick_lo, tick_hi;
 };
 
 // Compile-time variant of the fused step: task and feature flags.
-template <int TASK_, bool MOTOR_, bool DR_, bool GE_, bool TN_, bool ON_, int CTRL_ = 0>
+template <int TASK_, bool MOTOR_, bool DR_, bool GE_, bool TN_, bool ON_, int CTRL_ = 0, bool LAT_ = false>
 struct Variant {
   static constexpr int CTRL = CTRL_;     // 0 PWM, 1 AttitudeRate PID, 2 cascaded Attitude PID (envs/control.py)
+  static constexpr bool LAT = LAT_;      // delayed actions through the latency ring (envs/agents.py:267-276)
   static constexpr int TASK = TASK_;
   static constexpr bool MOTOR = MOTOR_;  // first-order motor model (envs/agents.py:284-288)
   static constexpr bool DR = DR_;        // per-env dt, m, J, ftf1 (, A, K)
@@ -147,6 +172,7 @@ struct Sample {  // one reset() worth of draws, reference order (see include/pds
   float pos[3], rpy[3], vel[3], w[3], mx[4], act[4];
   float dt, m, J[3], ftf1, T[4], t2w[4];
   int ref_offset;
+  float abuf[kMaxLatSteps - 1][4];  // LAT: rows 0..B-2 of action_buffer (row B-1 is `act`), hover.py:226-229
 };
 
 PDS_DEV void default_params(const Consts &k, Params &p) {
@@ -170,8 +196,8 @@ PDS_DEV void target_at(const Consts &k, const float2 *ref_lds, int t, float &tx,
 }
 
 template <int TASK>
-PDS_DEV int target_index(int step, int agg, int ref_offset) {
-  if (TASK == PDS_TASK_CIRCLE) return (step + ref_offset) % kRefPoints;  // envs/circle.py:130
+PDS_DEV int target_index(int step, int agg, int ref_offset, int ref_points) {
+  if (TASK == PDS_TASK_CIRCLE) return (step + ref_offset) % ref_points;  // envs/circle.py:130
   if (TASK == PDS_TASK_TAKEOFF) return min(step * agg, kRefPoints - 1);  // envs/takeoff.py:108
   return 0;
 }
@@ -180,13 +206,18 @@ PDS_DEV int target_index(int step, int agg, int ref_offset) {
 struct LaunchFlags {
   bool motor, dr, ge, tn, on;
   int ctrl;
+  bool lat;
   bool half_tile;  // per launch: use the 32-row observation tile (variants without observation noise)
 };
-void launch_step_hover(const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
-void launch_step_circle(const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
-void launch_step_takeoff(const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
-void launch_reset_hover(const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
-void launch_reset_circle(const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
-void launch_reset_takeoff(const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
+enum LaunchKind { kLaunchStep = 0, kLaunchStepK = 1, kLaunchReset = 2 };
+// one translation unit per (task, family) keeps the build parallel: pds_task_*.hip
+void launch_hover(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
+void launch_circle(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
+void launch_takeoff(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
+void launch_hover_pid(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
+void launch_circle_pid(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
+void launch_hover_lat(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
+void launch_circle_lat(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
+void launch_takeoff_lat(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
 
 }  // namespace pds

@@ -71,7 +71,7 @@ class DroneVecEnv:
     task = None
 
     def __init__(self, num_envs=1, device=None, seed=0, env_id_base=0, auto_reset=True,
-                 use_motor_dynamics=False, use_ground_effect=False,
+                 use_motor_dynamics=False, use_ground_effect=False, use_latency=False,
                  init_xyz=None, init_rpy=None, init_xyz_dot=None, init_rpy_dot=None,
                  # --- reference kwargs ---
                  aggregate_phy_steps=1, control_mode='PWM', observation_noise=1,
@@ -82,14 +82,13 @@ class DroneVecEnv:
                  render_mode=None, debug=False, max_episode_steps=500):
         if control_mode not in native.CONTROL_MODES:
             raise AssertionError(f'Control={control_mode} not found.')  # envs/agents.py:70-71
-        if observation_noise > 0 and int(100 // observation_frequency) != 1:
-            # obs_rate = sim_freq // observation_frequency (envs/base.py:108) with sim_freq = 100 on the
-            # Simple envs (envs/hover.py:262): the Kalman-hold branch of compute_observation
-            # (envs/hover.py:150-156) is never taken at the reference's defaults and is not built
-            raise NotImplementedError("observation_frequency != 100 with observation noise is not on the accelerated path")
         if int(observation_history_size) < 1:
             raise AssertionError("observation_history_size >= 1")  # envs/base.py:135
         self.observation_history_size = int(observation_history_size)
+        if use_latency and self.observation_history_size != 2:
+            # the history entries that alias drone.action_buffer (envs/agents.py:386) are resolved inside
+            # the kernel for the default history of 2 only
+            raise NotImplementedError("use_latency with observation_history_size != 2")
         if render_mode not in (None, 'rgb_array'):
             raise NotImplementedError("rendering is out of scope (no Bullet world on this path)")
         if int(aggregate_phy_steps) < 1:
@@ -110,6 +109,13 @@ class DroneVecEnv:
         cfg.use_motor_dynamics = int(bool(use_motor_dynamics))
         cfg.use_ground_effect = int(bool(use_ground_effect))
         cfg.control_mode = native.CONTROL_MODES[control_mode]
+        # CrazyFlieAgent(use_latency=..., latency=...), envs/agents.py:125,165,179-183.  The Simple agent of the
+        # reference passes use_latency=False (agents.py:492); sim-opt callers switch it on with set_latency().
+        cfg.use_latency = int(bool(use_latency))
+        cfg.latency = float(latency)
+        # obs_rate = sim_freq // observation_frequency (envs/base.py:108); Circle: 3 * observation_frequency
+        # reference points (envs/circle.py:49).  Unsupported combinations are refused by pds_create.
+        cfg.observation_frequency = int(observation_frequency)
         cfg.observation_noise = 1 if observation_noise > 0 else 0
         cfg.aggregate_phy_steps = int(aggregate_phy_steps)
         cfg.enable_reset_distribution = int(bool(enable_reset_distribution))
@@ -182,6 +188,7 @@ class DroneVecEnv:
                          {"cost": b["cost"], "final_obs": b["final_obs"],
                           "final_observation": b["final_obs"]})  # gymnasium's VectorEnv key, same tensor
         self._shape = (self.num_envs, 4)
+        self._kbufs = {}
 
     # ------------------------------------------------------------------ gymnasium surface ----
     @property
@@ -211,7 +218,7 @@ class DroneVecEnv:
         return b["obs"], {}
 
     def reset_from_samples(self, samples, mask=None):
-        """Reset with caller-supplied draws: `samples` [N, 36] (layout native.SAMPLE_LAYOUT)."""
+        """Reset with caller-supplied draws: `samples` [N, native.SAMPLE_FLOATS] (layout native.SAMPLE_LAYOUT)."""
         s = torch.as_tensor(samples, dtype=torch.float32, device=self.device).contiguous()
         assert s.shape == (self.num_envs, native.SAMPLE_FLOATS)
         b = self._next_buf()
@@ -282,6 +289,52 @@ class DroneVecEnv:
             return self._advance_history(b["_ret"])
         return b["_ret"]
 
+    def step_k(self, actions, out=None):
+        """K open-loop env.step()s in ONE launch (`pds_step_k`): `actions` [K, N, 4] -> (obs [K, N, D],
+        reward [K, N], terminated [K, N], truncated [K, N], info with cost [K, N] and final_obs [K, N, D]).
+        Counterpart of the recorded-action replay loop of the reference's sim-opt
+        (simopt/pybullet.py:163-176); bitwise identical to K calls of step().  The returned tensors are
+        owned by the env and reused by the next step_k call with the same K (pass `out`, a dict of
+        preallocated tensors with the same keys, to keep them)."""
+        a = actions
+        if not (isinstance(a, torch.Tensor) and a.dtype == torch.float32 and a.device == self.device and a.is_contiguous()):
+            a = torch.as_tensor(np.asarray(actions) if not isinstance(actions, torch.Tensor) else actions,
+                                dtype=torch.float32).to(self.device).contiguous()
+        if a.dim() != 3 or tuple(a.shape[1:]) != self._shape:
+            raise ValueError(f"actions must have shape (K, {self.num_envs}, 4), got {tuple(a.shape)}")
+        if self._hist is not None:
+            raise NotImplementedError("step_k with observation_history_size != 2")
+        K, N, D = int(a.shape[0]), self.num_envs, 2 * self._half
+        b = out if out is not None else self._kbufs.get(K)
+        if b is None:
+            f32 = dict(dtype=torch.float32, device=self.device)
+            u8 = dict(dtype=torch.uint8, device=self.device)
+            b = dict(obs=torch.empty(K, N, D, **f32), reward=torch.empty(K, N, **f32), cost=torch.empty(K, N, **f32),
+                     terminated=torch.empty(K, N, **u8), truncated=torch.empty(K, N, **u8),
+                     final_obs=torch.zeros(K, N, D, **f32))
+            self._kbufs = {K: b}  # one cached set
+        rc = self.lib.pds_step_k(self._handle, K, a.data_ptr(), b["obs"].data_ptr(), b["reward"].data_ptr(),
+                                 b["terminated"].data_ptr(), b["truncated"].data_ptr(), b["cost"].data_ptr(),
+                                 b["final_obs"].data_ptr(), torch.cuda.current_stream(self.device).cuda_stream)
+        if rc != 0:
+            native.check(self._handle, rc, "pds_step_k")
+        return (b["obs"], b["reward"], b["terminated"].view(torch.bool), b["truncated"].view(torch.bool),
+                {"cost": b["cost"], "final_obs": b["final_obs"], "final_observation": b["final_obs"]})
+
+    def set_latency(self, new_latency):
+        """CrazyFlieAgent.set_latency (envs/agents.py:388-404): below one time step the delay is switched
+        off, otherwise buf_size = int(latency / time_step); the action buffer of every env is zeroed."""
+        rc = self.lib.pds_set_latency(self._handle, float(new_latency))
+        native.check(self._handle, rc, "pds_set_latency")
+
+    @property
+    def latency_steps(self):
+        return int(self.lib.pds_latency_steps(self._handle))
+
+    def sync_tick(self):
+        """Re-read the device-side tick after replaying a captured hipGraph of steps (synchronises)."""
+        return int(self.lib.pds_sync_tick(self._handle, self._stream()))
+
     def close(self):
         if getattr(self, "_handle", None) is not None and self._handle:
             self.lib.pds_destroy(self._handle)
@@ -345,6 +398,9 @@ class DroneVecEnv:
     @property
     def bytes_per_env_step(self):
         return self.lib.pds_bytes_per_env_step(self._handle)
+
+    def bytes_per_env_step_k(self, k_steps):
+        return self.lib.pds_bytes_per_env_step_k(self._handle, int(k_steps))
 
     @property
     def tick(self):

@@ -10,19 +10,20 @@ from .build import library_path
 
 TASK_HOVER, TASK_CIRCLE, TASK_TAKEOFF = 0, 1, 2
 OK, EINVAL, ENODEVICE, EHIP, ENOMEM, EUNSUPPORTED = 0, -1, -2, -3, -4, -5
-SAMPLE_FLOATS = 84
+SAMPLE_FLOATS = 112
+MAX_LATENCY_STEPS = 8
 NOISE_FLOATS = 37
 # field ids (enum pds_field)
 FIELDS = dict(pos=0, rpy=1, vel=2, omega=3, quat=4, motor_x=5, last_action=6, prev_action=7,
               step_count=8, quat_sign=9, ref_offset=10, params=11, motor_A=12, motor_K=13, ou=14,
-              gyro_bias=15, gyro_lpf=16, noisy_obs=17, pid=18)
+              gyro_bias=15, gyro_lpf=16, noisy_obs=17, pid=18, action_buffer=19, action_idx=20)
 CONTROL_MODES = {'PWM': 0, 'AttitudeRate': 1, 'Attitude': 2}
-INT_FIELDS = ("step_count", "quat_sign", "ref_offset")
+INT_FIELDS = ("step_count", "quat_sign", "ref_offset", "action_idx")
 # sample row offsets (PDS_S_*)
 SAMPLE_LAYOUT = dict(pos_offset=(0, 3), rpy=(3, 3), vel=(6, 3), omega=(9, 3), motor_x=(12, 4),
                      action=(16, 4), dr_dt=(20, 1), dr_m=(21, 1), dr_J=(22, 3), dr_ftf0=(25, 1),
                      dr_ftf1=(26, 1), dr_T=(27, 4), dr_t2w=(31, 4), ref_offset=(35, 1),
-                     noise_call0=(36, 24), noise_call1=(60, 24))
+                     noise_call0=(36, 24), noise_call1=(60, 24), action_buf=(84, 28))
 # one add_noise call (PDS_N_OBS_*): offsets inside its 24 floats
 OBS_NOISE_LAYOUT = dict(pos_z=0, pos_u=3, vel_z=6, bias_z=9, rw_z=12, to_z=15, th_z=18, th_u=21)
 # step noise row (PDS_N_*)
@@ -31,7 +32,9 @@ STEP_NOISE_LAYOUT = dict(ou=0, a_bias=4, a_rw=7, a_to=10, obs=13)
 EXPORTS = ["pds_version", "pds_default_config", "pds_create", "pds_destroy", "pds_obs_dim",
            "pds_num_envs", "pds_reset", "pds_reset_from_samples", "pds_step", "pds_step_with_variates",
            "pds_field_width",
-           "pds_get_state", "pds_set_state", "pds_tick", "pds_set_tick", "pds_count_nonfinite", "pds_bytes_per_env_step", "pds_last_error", "pds_gae",
+           "pds_get_state", "pds_set_state", "pds_tick", "pds_set_tick", "pds_sync_tick", "pds_count_nonfinite",
+           "pds_bytes_per_env_step", "pds_bytes_per_env_step_k", "pds_last_error", "pds_step_k", "pds_set_latency",
+           "pds_latency_steps", "pds_gae",
            "pds_mlp_param_count", "pds_mlp_workspace_floats", "pds_mlp_forward", "pds_ppo_policy_grad",
            "pds_value_grad", "pds_gaussian_sample", "pds_rollout_record", "pds_adam_step"]
 
@@ -59,7 +62,8 @@ class Config(C.Structure):
         ("penalty_terminal", C.c_double), ("penalty_velocity", C.c_double), ("ARP", C.c_double),
         ("target_pos", C.c_double * 3), ("init_xyz", C.c_double * 3), ("init_rpy", C.c_double * 3),
         ("init_xyz_dot", C.c_double * 3), ("init_rpy_dot", C.c_double * 3),
-        ("control_mode", C.c_int32), ("reserved_", C.c_int32),
+        ("control_mode", C.c_int32), ("use_latency", C.c_int32), ("latency", C.c_double),
+        ("observation_frequency", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 
@@ -79,6 +83,8 @@ def load():
     lib = C.CDLL(path)
     vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
     lib.pds_version.restype = i32
+    if lib.pds_version() != 2:
+        raise RuntimeError(f"{path} is version {lib.pds_version()}, this binding needs 2: rebuild it")
     lib.pds_default_config.argtypes = [i32, C.POINTER(Config)]
     lib.pds_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
     lib.pds_destroy.argtypes = [vp]
@@ -95,6 +101,12 @@ def load():
     lib.pds_tick.argtypes = [vp]
     lib.pds_tick.restype = C.c_uint64
     lib.pds_set_tick.argtypes = [vp, C.c_uint64]
+    lib.pds_sync_tick.argtypes = [vp, vp]
+    lib.pds_sync_tick.restype = C.c_uint64
+    lib.pds_step_k.argtypes = [vp, i32] + [vp] * 8
+    lib.pds_set_latency.argtypes = [vp, C.c_double]
+    lib.pds_latency_steps.argtypes = [vp]
+    lib.pds_bytes_per_env_step_k.argtypes = [vp, i32]
     lib.pds_count_nonfinite.argtypes = [vp, C.POINTER(C.c_int64), vp]
     lib.pds_bytes_per_env_step.argtypes = [vp]
     lib.pds_last_error.argtypes = [vp]

@@ -13,6 +13,7 @@ for r in csv.DictReader(open(f)):
         acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 m = {k: sum(v)/len(v) for k, v in acc.items()}
 for k, v in sorted(m.items()): print(f"{k:24s} {v:14.1f}")
-w = 16384.0
-print(f"VALU instr per 64-env tile: {m['SQ_INSTS_VALU']/w:.0f}   SALU: {m['SQ_INSTS_SALU']/w:.0f}   LDS: {m['SQ_INSTS_LDS']/w:.1f}")
+w = m["SQ_WAVES"]
+print(f"per 64-env tile (wave): VALU {m['SQ_INSTS_VALU']/w:.0f}   SALU {m['SQ_INSTS_SALU']/w:.0f}   LDS instr {m['SQ_INSTS_LDS']/w:.1f}   "
+      f"LDS bank-conflict cycles {m['SQ_LDS_BANK_CONFLICT']/w:.0f}   wave cycles (quad) {m['SQ_WAVE_CYCLES']/w:.0f}   wait-any {m['SQ_WAIT_ANY']/w:.0f}")
 PY

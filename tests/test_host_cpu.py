@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"libpds_hip.so does not export {s}"
     assert set(pds.native.EXPORTS) == set(syms)
-    assert lib.pds_version() == 1
+    assert lib.pds_version() == 2
 
 
 def test_config_struct_mirror_and_defaults():
