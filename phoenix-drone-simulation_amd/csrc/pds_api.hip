@@ -23,6 +23,7 @@ struct FieldArgs {
   void *user;
   long long n;
   int field;
+  int task;
   int set;
   int has_motor, has_dr, has_tn, has_on, ctrl;
 };
@@ -78,7 +79,13 @@ __global__ __launch_bounds__(kBlock) void field_kernel(const FieldArgs a) {
       break;
     }
     case PDS_F_STEP_COUNT:
-      if (a.set) a.st.ctr[i] = ctr_pack((uint32_t)ui[i] & 0xFFFFu, ctr_sign(c), ctr_off(c), ctr_lat(c));
+      if (a.set) {
+        uint32_t off = ctr_off(c);
+        const uint32_t s_new = (uint32_t)ui[i] & 0xFFFFu;
+        if (a.task == PDS_TASK_CIRCLE)  // keep ref_offset: the stored phase is (steps + ref_offset) mod num_ref_points
+          off = (circle_ref_offset(c, a.k.ref_points) + s_new % (uint32_t)a.k.ref_points) % (uint32_t)a.k.ref_points;
+        a.st.ctr[i] = ctr_pack(s_new, ctr_sign(c), off, ctr_lat(c));
+      }
       else ui[i] = (int32_t)ctr_step(c);
       break;
     case PDS_F_QUAT_SIGN:
@@ -86,8 +93,13 @@ __global__ __launch_bounds__(kBlock) void field_kernel(const FieldArgs a) {
       else ui[i] = (int32_t)ctr_sign(c);
       break;
     case PDS_F_REF_OFFSET:
-      if (a.set) a.st.ctr[i] = ctr_pack(ctr_step(c), ctr_sign(c), (uint32_t)ui[i] % (uint32_t)a.k.ref_points, ctr_lat(c));
-      else ui[i] = (int32_t)ctr_off(c);
+      if (a.task == PDS_TASK_CIRCLE) {
+        const uint32_t P = (uint32_t)a.k.ref_points;
+        if (a.set) a.st.ctr[i] = ctr_pack(ctr_step(c), ctr_sign(c), ((uint32_t)ui[i] % P + ctr_step(c) % P) % P, ctr_lat(c));
+        else ui[i] = (int32_t)circle_ref_offset(c, a.k.ref_points);
+      } else if (!a.set) {
+        ui[i] = 0;
+      }
       break;
     case PDS_F_PARAMS:
       if (a.has_dr) {
@@ -706,6 +718,7 @@ extern "C" int pds_step_with_variates(pds_handle *h, const float *d_actions, con
   const unsigned cus = (unsigned)h->num_cus;
   lf.half_tile = grid.x > (unsigned)kFullTileBlocksPerCU * cus && grid.x <= (merged ? 5u : 8u) * cus;
   if (h->force_tile) lf.half_tile = h->force_tile == 1;
+  if (lf.on || lf.lat) lf.half_tile = false;  // (no half-tile instantiation)
   launch_family(h, kLaunchStep, lf, grid, (hipStream_t)stream, a);
   PDS_HIP(h, hipGetLastError());
   h->tick += 1;
@@ -788,7 +801,7 @@ static int do_field(pds_handle *h, int field, void *d_ptr, int set, void *stream
   PDS_HIP(h, guard.err);
   FieldArgs a;
   memset(&a, 0, sizeof(a));
-  a.st = h->st; a.k = h->k; a.user = d_ptr; a.n = h->cfg.num_envs; a.field = field; a.set = set;
+  a.st = h->st; a.k = h->k; a.user = d_ptr; a.n = h->cfg.num_envs; a.field = field; a.task = h->cfg.task; a.set = set;
   a.has_motor = h->flags.motor; a.has_dr = h->flags.dr; a.has_tn = h->flags.tn; a.has_on = h->flags.on; a.ctrl = h->flags.ctrl;
   const dim3 grid((unsigned)((a.n + kBlock - 1) / kBlock));
   hipLaunchKernelGGL(field_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, a);

@@ -45,6 +45,12 @@ struct LdsWords {
   PDS_DEV U4 lat_block(uint32_t r) const { return slot[kResetBlocks + kResetNoiseBlocks + r]; }
 };
 
+// number of leading scratch slots a variant can touch (bounds the cooperative fill loop)
+template <class V>
+PDS_DEV constexpr int scratch_blocks_used() {
+  return V::LAT ? kScratchBlocks : (V::ON ? kResetBlocks + kResetNoiseBlocks : kResetBlocks);
+}
+
 // which of the scratch blocks a variant consumes (the cooperative fill skips the others)
 template <class V>
 PDS_DEV constexpr bool block_needed(int j) {
@@ -474,7 +480,7 @@ PDS_DEV void reset_store(const StepArgs &a, const float2 *ref_lds, long long i, 
   if (a.obs != nullptr) {
     float rowbuf[D];
     float tx, ty, tz;
-    target_at<TASK>(a.k, ref_lds, target_index<TASK>(0, a.k.agg, (int)ctr_off(r.ctr), a.k.ref_points), tx, ty, tz);
+    target_at<TASK>(a.k, ref_lds, target_index<TASK>(0, a.k.agg, (int)ctr_off(r.ctr)), tx, ty, tz);
     if (V::ON) {
       write_noisy_half<TASK>(rowbuf, r.oa, r.lpf_a, r.u0, tx, ty, tz, r.u0);
       write_noisy_half<TASK>(rowbuf + V::O + 4, r.ob, r.ns.lpf, r.u0, tx, ty, tz, r.u0);
@@ -517,11 +523,11 @@ PDS_DEV void drain_reset_queue(const StepArgs &a, const RngKey &rk, const float2
     if (on) {
       const DirectWords dw(env_id, rk);
 #pragma unroll
-      for (int jj = 0; jj < (kScratchBlocks + kLanesPerReset - 1) / kLanesPerReset; ++jj) {
+      for (int jj = 0; jj < (scratch_blocks_used<V>() + kLanesPerReset - 1) / kLanesPerReset; ++jj) {
         const int j = jj * kLanesPerReset + b;
         bool need = false;
 #pragma unroll
-        for (int c = 0; c < kScratchBlocks; ++c) need = need || (c == j && block_needed<V>(c));
+        for (int c = 0; c < scratch_blocks_used<V>(); ++c) need = need || (c == j && block_needed<V>(c));
         if (need) scratch[g * kScratchBlocks + j] = dw.scratch_block(j);
       }
     }
@@ -556,78 +562,49 @@ PDS_DEV void drain_reset_queue(const StepArgs &a, const RngKey &rk, const float2
 // coalesced stores and the same observation-tile flush as every other env -- no scattered partial-line
 // writes over lines the wave has just written, no wait for those stores.  (Measured on Hover 2^20:
 // the scattered observation-row rewrite of the deferred drain alone cost 1.0 us of 60.)
-// Groups of 8 lanes serve one finished env: lane b of the group computes Philox block b, the words
-// travel through ds_bpermute (no LDS memory: the observation tile is still occupied), every lane of
-// the group evaluates the reset of the group's env, and the finished lane fetches the result from
-// its group's first lane.
-struct ShflWords {
-  U4 mine, blk8;
-  int gbase;
-  PDS_DEV U4 lat_block(uint32_t) const { return U4{0u, 0u, 0u, 0u}; }  // (merged reset: no latency variants)
-  PDS_DEV U4 reset_block(uint32_t j) const {
-    if (j == 8u) return blk8;
-    const int src = gbase + (int)j;
-    return U4{(uint32_t)__shfl((int)mine.x, src), (uint32_t)__shfl((int)mine.y, src),
-              (uint32_t)__shfl((int)mine.z, src), (uint32_t)__shfl((int)mine.w, src)};
-  }
-};
+// Groups of 8 lanes serve one finished env: lane b of the group computes Philox block b into a small
+// per-wave LDS scratch (8 envs x 9 blocks x 16 B next to the observation tile, which is still
+// occupied); then each finished lane reads ITS env's words back (ds_read_b128) and evaluates the
+// reset under its own exec mask.  Round 1 moved the words and the results through ~57 dependent
+// ds_bpermute per pass with the reset evaluated redundantly by all 8 lanes of a group; the s_memtime
+// stamps (profiles/r02_stamps_*.txt) showed ~3000 cycles per wave with a finished env for that,
+// on the critical path of every launch that fits the chip in one round.
+constexpr int kMergedScratchBlocks = kResetBlocks;                                   // per env
+constexpr int kMergedScratchU4 = kResetsPerPass * kMergedScratchBlocks;              // per wave
 
 // `mine`: this lane's env finished; `pos`: its rank among the wave's `count` finished lanes, whose
 // lane ids are in `lanes[0..count)`.  Must be called in wave-uniform control flow.
 template <class V>
 PDS_DEV void reset_in_registers(const StepArgs &a, const RngKey &rk, const float2 *ref_lds, const uint32_t *lanes,
                                 int count, bool mine, int pos, int lane, long long wave_base, int ref_offset,
-                                EnvRegs &e, Quat &q, float4 &u0, float4 &mx, Params &par, uint32_t &ctr) {
+                                U4 *scratch, EnvRegs &e, Quat &q, float4 &u0, float4 &mx, Params &par, uint32_t &ctr) {
   static_assert(!V::ON && !V::LAT, "observation-noise / latency variants use the deferred drain or the inline reset");
   const int g = lane / kLanesPerReset, b = lane % kLanesPerReset;
   for (int base = 0; base < count; base += kResetsPerPass) {
     const bool on = base + g < count;
     const int src = on ? (int)lanes[base + g] : lane;
     const uint32_t env_id = (uint32_t)(a.env_id_base + (unsigned long long)(wave_base + src));
-    const int off_old = __shfl(ref_offset, src);
     const DirectWords dw(env_id, rk);
-    ShflWords sw;
-    sw.gbase = lane - b;
-    sw.mine = U4{0u, 0u, 0u, 0u};
-    sw.blk8 = U4{0u, 0u, 0u, 0u};
     bool need = false;
 #pragma unroll
     for (int c = 0; c < kLanesPerReset; ++c) need = need || (c == b && block_needed<V>(c));
-    if (need) sw.mine = dw.reset_block((uint32_t)b);
-    if (V::MOTOR && V::DR) sw.blk8 = dw.reset_block(8u);
-    Sample s;
-    sample_philox<V>(a.k, sw, s);
-    EnvRegs re;
-    Quat rq;
-    float4 ru0, rmx;
-    Params rpar;
-    uint32_t rctr = ctr_pack(0u, 0u, (uint32_t)off_old);
-    LatRows no_rows;
-    reset_env<V>(a.k, ref_lds, s, re, rq, ru0, rmx, rpar, rctr, no_rows);
-    // result of group (pos - base) -> the finished lane it belongs to
-    const bool take = mine && pos >= base && pos < base + kResetsPerPass;
-    const int from = take ? (pos - base) * kLanesPerReset : lane;
-#define PDS_TAKE(dst, val) { const float t_ = __shfl((val), from); if (take) (dst) = t_; }
-    PDS_TAKE(e.px, re.px) PDS_TAKE(e.py, re.py) PDS_TAKE(e.pz, re.pz)
-    PDS_TAKE(e.vx, re.vx) PDS_TAKE(e.vy, re.vy) PDS_TAKE(e.vz, re.vz)
-    PDS_TAKE(e.roll, re.roll) PDS_TAKE(e.pitch, re.pitch) PDS_TAKE(e.yaw, re.yaw)
-    PDS_TAKE(e.wx, re.wx) PDS_TAKE(e.wy, re.wy) PDS_TAKE(e.wz, re.wz)
-    PDS_TAKE(q.x, rq.x) PDS_TAKE(q.y, rq.y) PDS_TAKE(q.z, rq.z) PDS_TAKE(q.w, rq.w)
-    PDS_TAKE(u0.x, ru0.x) PDS_TAKE(u0.y, ru0.y) PDS_TAKE(u0.z, ru0.z) PDS_TAKE(u0.w, ru0.w)
-    if (V::MOTOR) { PDS_TAKE(mx.x, rmx.x) PDS_TAKE(mx.y, rmx.y) PDS_TAKE(mx.z, rmx.z) PDS_TAKE(mx.w, rmx.w) }
-    if (V::DR) {
-      PDS_TAKE(par.dt, rpar.dt) PDS_TAKE(par.m, rpar.m) PDS_TAKE(par.Jx, rpar.Jx)
-      PDS_TAKE(par.Jy, rpar.Jy) PDS_TAKE(par.Jz, rpar.Jz) PDS_TAKE(par.ftf1, rpar.ftf1)
-      if (V::MOTOR) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { PDS_TAKE(par.A[j], rpar.A[j]) PDS_TAKE(par.K[j], rpar.K[j]) }
-      }
+    if (on && need) scratch[g * kMergedScratchBlocks + b] = dw.reset_block((uint32_t)b);
+    if (V::MOTOR && V::DR) {  // ninth block: the group's first lane
+      if (on && b == 0) scratch[g * kMergedScratchBlocks + 8] = dw.reset_block(8u);
     }
-#undef PDS_TAKE
-    {
-      const uint32_t t_ = (uint32_t)__shfl((int)rctr, from);
-      if (take) ctr = t_;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (mine && pos >= base && pos < base + kResetsPerPass) {
+      const LdsWords lw{scratch + (pos - base) * kMergedScratchBlocks};
+      Sample s;
+      sample_philox<V>(a.k, lw, s);
+      ctr = ctr_pack(0u, 0u, (uint32_t)ref_offset);
+      LatRows no_rows;
+      reset_env<V>(a.k, ref_lds, s, e, q, u0, mx, par, ctr, no_rows);
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // the scratch is refilled by the next pass
   }
 }
 
@@ -669,7 +646,8 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const StepArgs a) {
     }
     ResetOut r;
     const DirectWords dw((uint32_t)(a.env_id_base + (unsigned long long)i), rk);
-    reset_compute<V>(a, ref_lds, dw, a.st.ctr[i], a.samples != nullptr ? a.samples + i * PDS_SAMPLE_FLOATS : nullptr,
+    const uint32_t ctr_old = ctr_pack(0u, 0u, circle_ref_offset(a.st.ctr[i], a.k.ref_points));  // reset_env keeps ref_offset
+    reset_compute<V>(a, ref_lds, dw, ctr_old, a.samples != nullptr ? a.samples + i * PDS_SAMPLE_FLOATS : nullptr,
                      stale_w, bias, r);
     reset_store<V>(a, ref_lds, i, r);
   }

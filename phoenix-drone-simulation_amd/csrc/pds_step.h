@@ -35,6 +35,17 @@ PDS_DEV void flush_tile(const float *tile, float *gdst, int rows, int lane) {
   }
 }
 
+// Order of the action load among the step's loads (same-box A/B, profiles/r02_load_order.txt):
+//  1  action LAST, no wait: loads return in order and the action slice is the one stream that is cold
+//     every step (fresh 16 B x N region), so nothing queues behind it; best for the lean variants
+//     (Hover 65 536: 7.2 vs 7.4 us, Hover 2^20: 57.9 vs 58.3 us);
+//  2  action FIRST and waited for before the other loads are issued: paces the 12-20 streams of the
+//     heavy variants when the whole grid starts at once (Circle 262 144 + PT1 + DR: 20.7 vs 22.8 us;
+//     Hover 2^20 with noise + DR: 89.4 vs 90.0 us).
+// 0 = action first without the wait (A/B only).  Default: by variant.
+#ifndef PDS_ACT_LOAD_ORDER
+#define PDS_ACT_LOAD_ORDER ((V::MOTOR || V::DR || V::TN || V::ON || V::CTRL != 0 || V::LAT) ? 2 : 1)
+#endif
 // Inputs of one env-step, loaded 16 B/lane.
 struct Loaded {
   float4 act, q0, q1, q2, hA, hB, mx, p0, mA, mK, ou, nz0, oh0, oh1, pid0, pid2;
@@ -48,7 +59,9 @@ struct Loaded {
 // loads -- no load address depends on another load.
 template <class V>
 PDS_DEV void load_env(const StepArgs &a, long long ii, long long tile, Loaded &L) {
-  if (a.actions != nullptr) L.act = nt_load4(a.actions + ii);  // read once per step: keep it out of the caches
+  constexpr int kOrder = PDS_ACT_LOAD_ORDER;
+  if (kOrder == 0 || kOrder == 2) L.act = nt_load4(a.actions + ii);  // read once per step: keep it out of the caches
+  if (kOrder == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   L.q0 = st_load4(a.st.s0 + ii);
   L.q1 = st_load4(a.st.s1 + ii);
   L.q2 = st_load4(a.st.s2 + ii);
@@ -69,6 +82,7 @@ PDS_DEV void load_env(const StepArgs &a, long long ii, long long tile, Loaded &L
     L.nz0 = a.st.nz0[ii]; L.nz1 = a.st.nz1[ii];
     L.oh0 = a.st.oh0[ii]; L.oh1 = a.st.oh1[ii]; L.oh2 = a.st.oh2[ii];
   }
+  if (kOrder == 1) L.act = nt_load4(a.actions + ii);
 }
 
 // Everything one env carries from step to step, in registers (members a variant does not use are
@@ -289,7 +303,6 @@ enum { RM_MERGED = 0, RM_DEFERRED = 1, RM_INLINE = 2 };
 #define PDS_STAMP(j) do { } while (0)
 #define PDS_STAMP_WAIT(j) do { } while (0)
 #endif
-constexpr int kStampSlots = 10;
 
 // One env.step() of the env in `S` (registers in, registers out) + this step's output streams, which
 // start `o1` envs into the output tensors (0 for the single-step kernel, step * N for the K-step one;
@@ -298,7 +311,7 @@ constexpr int kStampSlots = 10;
 // RM_INLINE).
 template <class V, int TR, int RM, bool STORE>
 PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, int parity, const float2 *ref_lds,
-                       float *tile, uint32_t *queue, int lane, long long wave_base, long long i, long long ii,
+                       float *tile, uint32_t *queue, U4 *scratch, int lane, long long wave_base, long long i, long long ii,
                        bool active, const float4 act, EnvState &S, int &qcount
 #ifdef PDS_STAMPS
                        , unsigned long long *stamp_
@@ -322,7 +335,11 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
   NoiseState &ns = S.ns;
   PidState &ps = S.ps;
   const int step = (int)ctr_step(ctr);
-  const int ref_offset = (int)ctr_off(ctr);
+  const int phase = (int)ctr_off(ctr);  // Circle: index of the current reference point
+  const int phase1 = (TASK == PDS_TASK_CIRCLE) ? ((phase + 1 == k.ref_points) ? 0 : phase + 1) : 0;
+  // ref_offset survives a reset only without the reset distribution (envs/circle.py:222-226)
+  int ref_offset = 0;
+  if (TASK == PDS_TASK_CIRCLE && !k.reset_dist) ref_offset = (int)circle_ref_offset(ctr, k.ref_points);
 
   // paired actions of the two row halves: u(k-2) and u(k-1).  With the latency model the reference's
   // action_history still holds VIEWS of action_buffer[-1] for the first two steps after a reset
@@ -344,7 +361,7 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
   Quat q = quat_from_euler(e.roll, e.pitch, e.yaw);
   {
     float tx, ty, tz;
-    target_at<TASK>(k, ref_lds, target_index<TASK>(step, k.agg, ref_offset, k.ref_points), tx, ty, tz);
+    target_at<TASK>(k, ref_lds, target_index<TASK>(step, k.agg, phase), tx, ty, tz);
     if (V::ON) {
       write_noisy_half<TASK>(row, S.oh, ns.lpf, h1, tx, ty, tz, pa1);
     } else {
@@ -435,7 +452,7 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
 
   // ---- task: target, done, reward, cost (all on the TRUE state) -------------------------------
   float tx, ty, tz;
-  target_at<TASK>(k, ref_lds, target_index<TASK>(step + 1, k.agg, ref_offset, k.ref_points), tx, ty, tz);
+  target_at<TASK>(k, ref_lds, target_index<TASK>(step + 1, k.agg, phase1), tx, ty, tz);
   const float dx = e.px - tx, dy = e.py - ty, dz = e.pz - tz;
   const float dist = fast_sqrt(dx * dx + dy * dy + dz * dz);
   bool done = false;
@@ -493,7 +510,7 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
     write_obs_half<TASK>(row + O + 4, e, q, act, tx, ty, tz, pa2);
   }
 
-  S.ctr = ctr_pack((uint32_t)(step + 1), 0u, (uint32_t)ref_offset, lat_idx);
+  S.ctr = ctr_pack((uint32_t)(step + 1), 0u, (uint32_t)phase1, lat_idx);
   S.h2 = h1;   // u(k-1) becomes u(k-2)
   S.h1 = act;  // -> the ring slot that held u(k-2)
   // ---- auto-reset.  ~2 % of the envs finish per step under random actions, i.e. 3 of 4 waves
@@ -515,8 +532,8 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       float4 u0 = act, mxr = make_float4(xm[0], xm[1], xm[2], xm[3]);
-      reset_in_registers<V>(a, rk, ref_lds, queue, count, need_reset, pos, lane, wave_base, ref_offset, e, q, u0,
-                            mxr, par, S.ctr);
+      reset_in_registers<V>(a, rk, ref_lds, queue, count, need_reset, pos, lane, wave_base, ref_offset, scratch, e, q,
+                            u0, mxr, par, S.ctr);
       if (need_reset) {
         was_reset = true;
         S.h1 = u0; S.h2 = u0;
@@ -579,7 +596,7 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
 #pragma unroll
           for (int j = 0; j < 3; ++j) { ps.rate_int[j] = ps.rate_err[j] = ps.att_int[j] = ps.att_err[j] = 0.f; }
           float tx0, ty0, tz0;
-          target_at<TASK>(k, ref_lds, target_index<TASK>(0, k.agg, (int)ctr_off(r.ctr), k.ref_points), tx0, ty0, tz0);
+          target_at<TASK>(k, ref_lds, target_index<TASK>(0, k.agg, (int)ctr_off(r.ctr)), tx0, ty0, tz0);
           float *dst = tile + lane * D;
           if (V::ON) {
 #pragma unroll
@@ -600,7 +617,7 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
       } else {
         if (need_reset && (TR == kWave || (lane / TR) == pass)) {
           float tx0, ty0, tz0;
-          target_at<TASK>(k, ref_lds, target_index<TASK>(0, k.agg, (int)ctr_off(S.ctr), k.ref_points), tx0, ty0, tz0);
+          target_at<TASK>(k, ref_lds, target_index<TASK>(0, k.agg, (int)ctr_off(S.ctr)), tx0, ty0, tz0);
           float *dst = tile + (lane % TR) * D;
           write_obs_half<TASK>(dst, e, q, S.h1, tx0, ty0, tz0, S.h1);
           write_obs_half<TASK>(dst + O + 4, e, q, S.h1, tx0, ty0, tz0, S.h1);
@@ -642,24 +659,44 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
 // PT1 + DR at 2^20 82.9 vs 78.6 us (181 VGPRs => 2 waves/SIMD), TakeOff (resets only by the 500-step
 // truncation) 61.4 vs 60.7 us, and under the half tile's 128-VGPR cap it spills (Circle 262 144: 39
 // vs 21 us) -- so those keep the deferred drain.
-template <class V>
+template <class V, int TR = kWave>
 constexpr bool merged_reset_variant() {
-  return PDS_MERGED_RESET && !V::ON && !V::LAT && !(V::MOTOR && V::DR) && V::TASK != PDS_TASK_TAKEOFF;
+  // (the half tile keeps the whole observation row in registers: PT1 + DR would spill 61 VGPRs there)
+  return PDS_MERGED_RESET && !V::ON && !V::LAT && V::TASK != PDS_TASK_TAKEOFF && (TR == kWave || !(V::MOTOR && V::DR));
 }
 
-template <class V, int TR>
-struct WaveSetup {
-  float *tile;
-  uint32_t *queue;
-  int lane, wave;
-  long long t, wave_base, i, ii;
-  bool active, valid;
-};
+// The kernel arguments (StepArgs, ~10 cache lines) are read with scalar loads that the compiler
+// places next to their uses -- about 30 of them along the step, each a scalar-cache miss (the
+// kernarg segment is rewritten by the host for every launch) whose latency the wave waits out on
+// the spot: measured with the s_memtime stamps, ~250 cycles each, a third of a wave's lifetime when
+// one wave runs per SIMD (65 536 envs).  Touching every line once at kernel entry (all misses in
+// flight together, one wait) turns the later loads into scalar-cache hits.
+#ifndef PDS_KERNARG_PREFETCH
+#define PDS_KERNARG_PREFETCH 1
+#endif
+PDS_DEV void prefetch_kernargs() {
+#if PDS_KERNARG_PREFETCH
+  // one dword from every 64-byte line that starts inside the kernarg segment
+  static_assert(sizeof(StepArgs) > 8 * 64 && sizeof(StepArgs) <= 9 * 64, "prefetch_kernargs touches lines 0..8: adjust");
+  const auto p = __builtin_amdgcn_kernarg_segment_ptr();
+  uint32_t t0, t1, t2, t3, t4, t5, t6, t7, t8;
+  asm volatile(
+      "s_load_dword %0, %9, 0x0\n\ts_load_dword %1, %9, 0x40\n\ts_load_dword %2, %9, 0x80\n\t"
+      "s_load_dword %3, %9, 0xc0\n\ts_load_dword %4, %9, 0x100\n\ts_load_dword %5, %9, 0x140\n\t"
+      "s_load_dword %6, %9, 0x180\n\ts_load_dword %7, %9, 0x1c0\n\ts_load_dword %8, %9, 0x200\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7), "=&s"(t8)
+      : "s"(p)
+      : "memory");
+#endif
+}
 
-#define PDS_WAVE_SETUP(V, TR)                                                                          \
+#define PDS_WAVE_SETUP(V, TR, RM)                                                                      \
   __shared__ __attribute__((aligned(16))) float tile_all[(kBlock / kWave) * TR * V::D];               \
   __shared__ float2 ref_lds[(V::TASK == PDS_TASK_CIRCLE) ? kRefPoints : 1];                           \
   __shared__ uint32_t queue_all[(kBlock / kWave) * kQueueCap];                                        \
+  __shared__ U4 scratch_all[(RM == RM_MERGED) ? (kBlock / kWave) * kMergedScratchU4 : 1];             \
+  U4 *scratch = scratch_all + ((RM == RM_MERGED) ? (threadIdx.x >> 6) * kMergedScratchU4 : 0);        \
   const int tid = threadIdx.x;                                                                         \
   const int lane = tid & (kWave - 1);                                                                  \
   const int wave = tid >> 6;                                                                           \
@@ -696,8 +733,9 @@ struct WaveSetup {
 template <class V, int TR>
 __global__ __launch_bounds__(kBlock, PDS_MIN_WAVES) void step_kernel(const StepArgs a) {
   PDS_STAMP_DECL
-  constexpr int RM = (merged_reset_variant<V>() && TR == kWave) ? RM_MERGED : RM_DEFERRED;
-  PDS_WAVE_SETUP(V, TR)
+  prefetch_kernargs();
+  constexpr int RM = merged_reset_variant<V, TR>() ? RM_MERGED : RM_DEFERRED;
+  PDS_WAVE_SETUP(V, TR, RM)
   // The loads are issued before anything else so that the scalar preamble of the kernel
   // (kernel-argument loads, uniform constants) overlaps with their latency.
   Loaded cur;
@@ -713,7 +751,7 @@ __global__ __launch_bounds__(kBlock, PDS_MIN_WAVES) void step_kernel(const StepA
   EnvState S;
   unpack_state<V>(a.k, cur, parity, S);
   int qcount = 0;  // wave-uniform
-  step_once<V, TR, RM, true>(a, 0ll, rk, parity, ref_lds, tile, queue, lane, wave_base, i, ii, active, cur.act, S, qcount PDS_STAMP_ARG);
+  step_once<V, TR, RM, true>(a, 0ll, rk, parity, ref_lds, tile, queue, scratch, lane, wave_base, i, ii, active, cur.act, S, qcount PDS_STAMP_ARG);
   if (RM == RM_DEFERRED && qcount > 0) drain_reset_queue<V>(a, rk, ref_lds, queue, qcount, lane, wave_base, tile);
   PDS_STAMP(6);
   advance_clock(a.st.clk, t, rk, parity ^ 1, 1u, lane);
@@ -730,7 +768,8 @@ __global__ __launch_bounds__(kBlock, 3) void step_k_kernel(const StepArgs a) {
 #ifdef PDS_STAMPS
   unsigned long long stamp_[kStampSlots];
 #endif
-  PDS_WAVE_SETUP(V, TR)
+  prefetch_kernargs();
+  PDS_WAVE_SETUP(V, TR, RM)
   Loaded cur;
   load_env<V>(a, ii, t, cur);
   RngKey rk{a.seed_lo, a.seed_hi, 0u, 0u};
@@ -747,7 +786,7 @@ __global__ __launch_bounds__(kBlock, 3) void step_k_kernel(const StepArgs a) {
   for (int s = 0; s < K; ++s) {
     float4 act_next = act;
     if (s + 1 < K) act_next = nt_load4(a.actions + (long long)(s + 1) * a.n + ii);  // in flight during step s
-    step_once<V, TR, RM, false>(a, (long long)s * a.n, rk, parity, ref_lds, tile, queue, lane, wave_base, i, ii, active, act, S, qcount PDS_STAMP_ARG);
+    step_once<V, TR, RM, false>(a, (long long)s * a.n, rk, parity, ref_lds, tile, queue, scratch, lane, wave_base, i, ii, active, act, S, qcount PDS_STAMP_ARG);
     act = act_next;
     parity ^= 1;
     rk.tick_lo += 1u;

@@ -29,11 +29,15 @@ constexpr int kQueueCap = 64;    // deferred-reset queue entries per wave (LDS):
 constexpr int kRefPoints = 300;  // envs/circle.py:48, envs/takeoff.py:43
 constexpr int kStaggerBytes = 4352;  // 17 x 256 B between consecutive state arrays in the slab
 
+constexpr int kStampSlots = 10;  // diagnostic builds (-DPDS_STAMPS): s_memtime stamps per wave
 constexpr int kMaxLatSteps = PDS_MAX_LATENCY_STEPS;  // rows of the latency action ring (envs/agents.py:180-182)
 
 // ---- packing of the per-env counter word --------------------------------------------------------
 // bits 0..15 env.step calls since reset | bit 16 quaternion == -Q(rpy) | bits 17..25 Circle ref_offset
-// | bits 26..28 action_idx of the latency ring (envs/agents.py:183,273)
+// | bits 26..28 action_idx of the latency ring (envs/agents.py:183,273).
+// Circle keeps the PHASE (env.step calls + ref_offset) mod num_ref_points in bits 17..25, i.e. the index
+// of the current reference point (envs/circle.py:130): it advances by one per step with a wrap, so the
+// step needs no modulo; ref_offset itself is recovered where it is asked for (circle_ref_offset).
 PDS_DEV uint32_t ctr_pack(uint32_t step, uint32_t sign, uint32_t off, uint32_t lat_idx = 0u) {
   return step | (sign << 16) | (off << 17) | (lat_idx << 26);
 }
@@ -41,6 +45,10 @@ PDS_DEV uint32_t ctr_step(uint32_t c) { return c & 0xFFFFu; }
 PDS_DEV uint32_t ctr_sign(uint32_t c) { return (c >> 16) & 1u; }
 PDS_DEV uint32_t ctr_off(uint32_t c) { return (c >> 17) & 0x1FFu; }
 PDS_DEV uint32_t ctr_lat(uint32_t c) { return (c >> 26) & 0x7u; }
+PDS_DEV uint32_t circle_ref_offset(uint32_t c, int ref_points) {  // not on the hot path
+  const int d = (int)ctr_off(c) - (int)(ctr_step(c) % (uint32_t)ref_points);
+  return (uint32_t)(d < 0 ? d + ref_points : d);
+}
 
 // ---- per-wave clock word (device memory) ----------------------------------------------------------
 // x, y: tick (counts pds_reset* / pds_step calls; words 1 and 2 of the Philox counter), z: parity of
@@ -196,8 +204,8 @@ PDS_DEV void target_at(const Consts &k, const float2 *ref_lds, int t, float &tx,
 }
 
 template <int TASK>
-PDS_DEV int target_index(int step, int agg, int ref_offset, int ref_points) {
-  if (TASK == PDS_TASK_CIRCLE) return (step + ref_offset) % ref_points;  // envs/circle.py:130
+PDS_DEV int target_index(int step, int agg, int phase) {
+  if (TASK == PDS_TASK_CIRCLE) return phase;  // (iteration // aggregate_phy_steps + ref_offset) % num_ref_points, envs/circle.py:130
   if (TASK == PDS_TASK_TAKEOFF) return min(step * agg, kRefPoints - 1);  // envs/takeoff.py:108
   return 0;
 }
