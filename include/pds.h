@@ -251,6 +251,12 @@ int pds_bytes_per_env_step_k(const pds_handle *h, int k_steps);
 
 const char *pds_last_error(const pds_handle *h);
 
+/* The generator of the RNG contract, exposed for verification: d_out[i] =
+ * Philox4x32-<rounds>(counter d_ctr[i][0..3], key d_key[i][0..1]) for i < n, computed by the same device
+ * function the step / reset kernels use (rounds 10: reset sampling, 7: per-step noise).  tests/ check it
+ * against the Random123 known-answer vectors.  Runs on the current device. */
+int pds_philox4x32(const uint32_t *d_ctr, const uint32_t *d_key, int rounds, int64_t n, uint32_t *d_out, void *stream);
+
 /* ---- caller-side helper: GAE over a lockstep rollout ----------------------
  * Replaces core.Buffer.finish_path / calculate_adv_and_value_targets (algs/core.py:461-533, one
  * scipy lfilter per finished path) for a [T, N] rollout: d_rew, d_val [T,N] f32; d_terminated,

@@ -829,6 +829,23 @@ extern "C" int pds_count_nonfinite(pds_handle *h, int64_t *count, void *stream) 
 extern "C" int pds_get_state(pds_handle *h, int field, void *d_out, void *stream) { return do_field(h, field, d_out, 0, stream); }
 extern "C" int pds_set_state(pds_handle *h, int field, const void *d_in, void *stream) { return do_field(h, field, const_cast<void *>(d_in), 1, stream); }
 
+template <int ROUNDS>
+__global__ __launch_bounds__(256) void philox_kernel(const uint32_t *ctr, const uint32_t *key, long long n, uint32_t *out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const U4 r = philox4x32<ROUNDS>(ctr[4 * i], ctr[4 * i + 1], ctr[4 * i + 2], ctr[4 * i + 3], key[2 * i], key[2 * i + 1]);
+  out[4 * i] = r.x; out[4 * i + 1] = r.y; out[4 * i + 2] = r.z; out[4 * i + 3] = r.w;
+}
+
+extern "C" int pds_philox4x32(const uint32_t *d_ctr, const uint32_t *d_key, int rounds, int64_t n, uint32_t *d_out, void *stream) {
+  if (!d_ctr || !d_key || !d_out || n < 0 || (rounds != 7 && rounds != 10)) return PDS_EINVAL;
+  if (n == 0) return PDS_OK;
+  const dim3 grid((unsigned)((n + 255) / 256));
+  if (rounds == 10) hipLaunchKernelGGL(philox_kernel<10>, grid, dim3(256), 0, (hipStream_t)stream, d_ctr, d_key, (long long)n, d_out);
+  else hipLaunchKernelGGL(philox_kernel<7>, grid, dim3(256), 0, (hipStream_t)stream, d_ctr, d_key, (long long)n, d_out);
+  return hipGetLastError() == hipSuccess ? PDS_OK : PDS_EHIP;
+}
+
 // Diagnostic builds (-DPDS_STAMPS): per-wave s_memtime stamps of the step kernel's phases, kStampSlots
 // words per 64-env tile; NULL / 0 in regular builds.  Not part of include/pds.h.
 extern "C" int pds_debug_stamps(pds_handle *h, unsigned long long *host_out, long long max_words) {

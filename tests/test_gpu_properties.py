@@ -283,3 +283,35 @@ def test_count_nonfinite_flags_the_takeoff_overflow():
         env.step(0.5 * torch.randn(n, 4, generator=g, device=obs.device))
     assert 0 < env.count_nonfinite() <= n
     env.close()
+
+
+def test_device_philox_known_answers():
+    """The device function behind every in-kernel draw == Random123's Philox4x32-10 / -7 known answers
+    (and == the oracle's restatement on random counters)."""
+    import ctypes as C
+    from test_oracle_golden import PHILOX_KAT
+    from oracle import oracle as po
+    import phoenix_drone_simulation_amd as pds
+    lib = pds.native.load()
+    dev = torch.device("cuda", 0)
+    for rounds in (10, 7):
+        kat = [k for k in PHILOX_KAT if k[0] == rounds]
+        rs = np.random.RandomState(rounds)
+        extra_c = rs.randint(0, 2 ** 32, size=(500, 4), dtype=np.uint64).astype(np.uint32)
+        extra_k = rs.randint(0, 2 ** 32, size=(500, 2), dtype=np.uint64).astype(np.uint32)
+        ctr = np.concatenate([np.array([k[1] for k in kat], np.uint32), extra_c])
+        key = np.concatenate([np.array([k[2] for k in kat], np.uint32), extra_k])
+        d_ctr = torch.from_numpy(ctr.view(np.int32)).to(dev)
+        d_key = torch.from_numpy(key.view(np.int32)).to(dev)
+        d_out = torch.zeros(ctr.shape[0], 4, dtype=torch.int32, device=dev)
+        rc = lib.pds_philox4x32(d_ctr.data_ptr(), d_key.data_ptr(), rounds, ctr.shape[0], d_out.data_ptr(),
+                                torch.cuda.current_stream(dev).cuda_stream)
+        assert rc == 0
+        out = d_out.cpu().numpy().view(np.uint32)
+        for j, k in enumerate(kat):
+            assert [int(v) for v in out[j]] == k[3], (rounds, j)
+        L = po.lib()
+        for j in range(len(kat), ctr.shape[0], 37):
+            o = (C.c_uint32 * 4)()
+            L.po_philox4x32((C.c_uint32 * 4)(*[int(v) for v in ctr[j]]), (C.c_uint32 * 2)(*[int(v) for v in key[j]]), rounds, o)
+            assert [int(v) for v in o] == [int(v) for v in out[j]]

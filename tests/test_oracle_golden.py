@@ -128,3 +128,30 @@ def test_oracle_f32_single_step(name):
     equal thrusts integrate into rpy_dot with 1/J ~ 6e4 gain)."""
     rtol, atol = gu.tolerances(name)
     _replay(name, "f32", rtol=rtol, atol=atol, resync=True)
+
+
+# Random123 known-answer vectors (kat_vectors of the Random123 distribution, D. E. Shaw Research):
+# philox4x32 <rounds> <counter x4> <key x2> -> <output x4>
+PHILOX_KAT = [
+    (10, [0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+    (10, [0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+    (10, [0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+     [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]),
+    (7, [0, 0, 0, 0], [0, 0], [0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48]),
+    (7, [0xffffffff] * 4, [0xffffffff] * 2, [0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662]),
+    (7, [0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+     [0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a]),
+]
+
+
+def test_oracle_philox_known_answers():
+    """The counter-based generator of the RNG contract (reset sampling: 10 rounds, per-step noise: 7) is
+    the published Philox4x32: the oracle's restatement reproduces the Random123 known-answer vectors."""
+    import ctypes as C
+    L = po.lib()
+    for rounds, ctr, key, want in PHILOX_KAT:
+        out = (C.c_uint32 * 4)()
+        L.po_philox4x32((C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), rounds, out)
+        assert [int(v) for v in out] == want, (rounds, ctr)
+        if rounds == 10:
+            assert po.philox4x32_10(ctr, key) == want
