@@ -15,7 +15,7 @@ _LIB_PATH = os.path.join(_HERE, "libphoenix_oracle.so")
 
 TASK_HOVER, TASK_CIRCLE, TASK_TAKEOFF = 0, 1, 2
 TASK_IDS = {"hover": 0, "circle": 1, "takeoff": 2}
-MAX_OBS, HIST = 24, 2
+MAX_OBS, HIST, MAX_LAT = 24, 2, 8
 
 
 def build(force=False):
@@ -37,7 +37,7 @@ class Config(C.Structure):
         ("penalty_terminal", C.c_double), ("penalty_velocity", C.c_double), ("ARP", C.c_double),
         ("target_pos", C.c_double * 3), ("init_xyz", C.c_double * 3),
         ("init_rpy", C.c_double * 3), ("init_xyz_dot", C.c_double * 3), ("init_rpy_dot", C.c_double * 3),
-        ("control_mode", C.c_int32), ("pad2_", C.c_int32),
+        ("control_mode", C.c_int32), ("use_latency", C.c_int32), ("latency", C.c_double),
     ]
 
 
@@ -48,6 +48,7 @@ class ResetSample(C.Structure):
         ("dr_dt", C.c_double), ("dr_m", C.c_double), ("dr_J", C.c_double * 3),
         ("dr_ftf0", C.c_double), ("dr_ftf1", C.c_double), ("dr_T", C.c_double * 4),
         ("dr_t2w", C.c_double * 4), ("ref_offset", C.c_int32), ("pad_", C.c_int32),
+        ("action_buf", (C.c_double * 4) * (MAX_LAT - 1)),
     ]
 
 
@@ -77,8 +78,11 @@ def _env_struct(real):
             ("T_s", real),
             ("ou", real * 4), ("gyro_bias", real * 3), ("lpf", real * 3), ("kf_state", real * 17),
             ("rate_int", real * 3), ("rate_err", real * 3), ("att_int", real * 3), ("att_err", real * 3),
+            ("action_buffer", (real * 4) * MAX_LAT),
             ("iteration", C.c_int32), ("ref_offset", C.c_int32), ("elapsed_steps", C.c_int32),
             ("obs_len", C.c_int32),
+            ("use_latency", C.c_int32), ("buf_size", C.c_int32), ("action_idx", C.c_int32),
+            ("hist_alias", C.c_int32 * HIST), ("last_action_alias", C.c_int32),
         ]
     return Env
 
@@ -120,6 +124,8 @@ def default_config(task, **overrides):
                 getattr(c, k)[i] = float(v[i])
         elif k == "observation_noise":
             c.observation_noise = 1 if v > 0 else 0
+        elif k == "use_latency":
+            c.use_latency = int(bool(v))
         elif k == "control_mode":
             c.control_mode = {"PWM": 0, "AttitudeRate": 1, "Attitude": 2}[v] if isinstance(v, str) else int(v)
         else:
@@ -200,6 +206,9 @@ class OracleEnv:
         self._f("po_step_forward")(C.byref(self.cfg), C.byref(self.env), _arr(action, self.real),
                                    self._rng_ref())
 
+    def set_latency(self, new_latency):
+        self._f("po_set_latency")(C.byref(self.cfg), C.byref(self.env), C.c_double(new_latency))
+
     def philox_reset_sample(self, seed, env_id, tick):
         s = ResetSample()
         self._f("po_philox_reset_sample")(C.byref(self.cfg), C.c_uint64(seed), C.c_uint64(env_id),
@@ -212,8 +221,9 @@ def make_reset_sample(**kw):
     for k, v in kw.items():
         cur = getattr(s, k)
         if hasattr(cur, "__len__"):
-            for i, x in enumerate(np.asarray(v, dtype=np.float64).reshape(-1)):
-                cur[i] = float(x)
+            flat = np.asarray(v, dtype=np.float64).reshape(-1)
+            dst = np.ctypeslib.as_array(cur).reshape(-1)  # (1-D and 2-D members alike)
+            dst[:flat.size] = flat
         else:
             setattr(s, k, int(v) if k == "ref_offset" else float(v))
     return s

@@ -103,6 +103,8 @@ void po_default_config(int task, po_config *c) {
   c->target_pos[0] = 0; c->target_pos[1] = 0; c->target_pos[2] = 1.0;
   c->init_xyz[0] = 0; c->init_xyz[1] = 0;
   c->init_xyz[2] = (task == PO_TASK_TAKEOFF) ? (double)0.0125f : 1.0; /* float32 literal, takeoff.py:51 */
+  c->use_latency = 0;  /* CrazyFlieSimpleAgent passes use_latency=False, agents.py:492 */
+  c->latency = 0.015;  /* envs/base.py:40 */
 }
 
 /* Philox4x32-10 (Salmon et al., SC'11).  This is the in-kernel RNG of the NEW framework (the
@@ -224,6 +226,30 @@ void SUF(po_env_init)(const po_config *c, ENV *e) {
   e->target_pos[0] = (REAL)c->target_pos[0];
   e->target_pos[1] = (REAL)c->target_pos[1];
   e->target_pos[2] = (REAL)c->target_pos[2];
+  /* agents.py:165,179-183 */
+  e->use_latency = (c->use_latency && c->latency >= c->time_step) ? 1 : 0;
+  {
+    int b = (int)floor(c->latency / c->time_step); /* Python float // float */
+    e->buf_size = b < 1 ? 1 : b;
+    if (e->buf_size > PO_MAX_LAT) e->buf_size = PO_MAX_LAT;
+  }
+  e->action_idx = 0;
+}
+
+/* envs/agents.py:388-404 CrazyFlieAgent.set_latency (called by simopt/pybullet.py:248) */
+void SUF(po_set_latency)(const po_config *c, ENV *e, double new_latency) {
+  if (new_latency < c->time_step) {
+    e->use_latency = 0;
+  } else {
+    e->use_latency = 1;
+    e->buf_size = (int)(new_latency / c->time_step);
+    if (e->buf_size > PO_MAX_LAT) e->buf_size = PO_MAX_LAT;
+    memset(e->action_buffer, 0, sizeof(e->action_buffer));
+    e->action_idx = 0;
+    /* last_action / action_history keep pointing at the OLD buffer object, which nothing writes any more */
+    if (e->last_action_alias) e->last_action_alias = 0;
+    for (int h = 0; h < PO_HIST; ++h) e->hist_alias[h] = 0;
+  }
 }
 
 /* envs/agents.py:208-224 update_motor_dynamics (note the hard-coded 0.028 in K, :224) */
@@ -298,12 +324,19 @@ void SUF(po_apply_action)(const po_config *c, ENV *e, const REAL a[4], po_rng *r
                           REAL *z_torque) {
   REAL torques[4];
   const REAL sigma = (REAL)(0.2 * c->motor_thrust_noise); /* agents.py:206 */
-  for (int i = 0; i < 4; ++i) e->last_action[i] = a[i];   /* :264 */
+  for (int i = 0; i < 4; ++i) e->last_action[i] = a[i];   /* :264 last_action = action.copy() */
+  e->last_action_alias = 0;
+  REAL applied[4] = {a[0], a[1], a[2], a[3]};
+  if (e->use_latency) {                                    /* :267-274 */
+    for (int i = 0; i < 4; ++i) applied[i] = e->action_buffer[e->action_idx][i];   /* delayed action */
+    for (int i = 0; i < 4; ++i) e->action_buffer[e->action_idx][i] = a[i];
+    e->action_idx = (e->action_idx + 1) % e->buf_size;
+  }
   if (c->control_mode == 0) {
     for (int i = 0; i < 4; ++i)                            /* PWM.act, control.py:98-99 */
-      e->pwm[i] = (REAL)30000 + clipr(a[i], -1, 1) * (REAL)30000;
+      e->pwm[i] = (REAL)30000 + clipr(applied[i], -1, 1) * (REAL)30000;
   } else {
-    control_pid(c, e, a);                                  /* AttitudeRate.act / Attitude.act */
+    control_pid(c, e, applied);                            /* AttitudeRate.act / Attitude.act */
   }
   for (int i = 0; i < 4; ++i) { /* utils.py:105-107: dx = theta*(mu-x) + sigma*randn; theta .15 mu 0 */
     REAL x = e->ou[i];
@@ -562,10 +595,14 @@ static void compute_history(const po_config *c, ENV *e, po_rng *rng, REAL *obs) 
   int k = 0;
   for (int h = 0; h < PO_HIST; ++h) {
     for (int i = 0; i < n; ++i) obs[k++] = e->obs_hist[h][i];
-    for (int i = 0; i < 4; ++i) obs[k++] = e->act_hist[h][i];
+    /* an entry that is still the view action_buffer[-1, :] shows the buffer's CURRENT content */
+    const REAL *ah = e->hist_alias[h] ? e->action_buffer[e->buf_size - 1] : e->act_hist[h];
+    for (int i = 0; i < 4; ++i) obs[k++] = ah[i];
   }
   memcpy(e->act_hist[0], e->act_hist[1], sizeof(REAL) * 4);
-  memcpy(e->act_hist[1], e->last_action, sizeof(REAL) * 4);
+  e->hist_alias[0] = e->hist_alias[1];
+  memcpy(e->act_hist[1], e->last_action, sizeof(REAL) * 4); /* append(drone.last_action): the object itself */
+  e->hist_alias[1] = e->last_action_alias;
 }
 
 /* envs/base.py:433-475 DroneBaseEnv.step + gymnasium TimeLimit (__init__.py:8-50) */
@@ -598,6 +635,9 @@ void SUF(po_reset)(const po_config *c, ENV *e, const po_reset_sample *s, po_rng 
   /* drone.reset(): agents.py:380-386 */
   for (int i = 0; i < 4; ++i) { e->x[i] = 0; e->y[i] = 0; e->last_action[i] = 0; }
   for (int i = 0; i < 3; ++i) { e->rate_int[i] = e->rate_err[i] = e->att_int[i] = e->att_err[i] = 0; } /* control.reset() */
+  e->action_idx = 0;                                        /* :384 */
+  memset(e->action_buffer, 0, sizeof(e->action_buffer));    /* :385 */
+  e->last_action_alias = 1;                                 /* :386 last_action = action_buffer[-1, :] (a view) */
 
   /* ---- task_specific_reset ---- */
   REAL pos[3] = {(REAL)c->init_xyz[0], (REAL)c->init_xyz[1], (REAL)c->init_xyz[2]};
@@ -634,13 +674,19 @@ void SUF(po_reset)(const po_config *c, ENV *e, const po_reset_sample *s, po_rng 
       /* hover.py:223-229 / circle.py:251-257 */
       for (int i = 0; i < 4; ++i) e->x[i] = (REAL)s->motor_x[i];
       for (int i = 0; i < 4; ++i) e->y[i] = e->K[i] * e->x[i];
-      for (int i = 0; i < 4; ++i) e->last_action[i] = clipr((REAL)s->action[i], -1, 1);
+      /* action_buffer = clip(normal(HOVER_ACTION, .02, (buf_size, 4))); last_action = its last row (a view) */
+      for (int r = 0; r < e->buf_size - 1; ++r)
+        for (int i = 0; i < 4; ++i) e->action_buffer[r][i] = clipr((REAL)s->action_buf[r][i], -1, 1);
+      for (int i = 0; i < 4; ++i) e->action_buffer[e->buf_size - 1][i] = clipr((REAL)s->action[i], -1, 1);
+      for (int i = 0; i < 4; ++i) e->last_action[i] = e->action_buffer[e->buf_size - 1][i];
     }
   } else if (c->task == PO_TASK_CIRCLE) {
     /* target_pos / ref_offset keep their previous values (circle.py:222-226 not executed) */
   }
   if (c->task == PO_TASK_TAKEOFF) { /* takeoff.py:209-212, unconditional */
     for (int i = 0; i < 4; ++i) { e->x[i] = 0; e->y[i] = e->K[i] * e->x[i]; e->last_action[i] = -1; }
+    for (int r = 0; r < e->buf_size; ++r)
+      for (int i = 0; i < 4; ++i) e->action_buffer[r][i] = -1;      /* action_buffer[:] = -1 */
   }
   /* bc.resetBaseVelocity(angularVelocity = R.T @ rpy_dot): hover.py:237-243 */
   REAL R[9], w_world[3];
@@ -676,6 +722,7 @@ void SUF(po_reset)(const po_config *c, ENV *e, const po_reset_sample *s, po_rng 
   e->obs_len = n;
   for (int h = 0; h < PO_HIST; ++h) memcpy(e->obs_hist[h], o, sizeof(REAL) * n);
   for (int h = 0; h < PO_HIST; ++h) memcpy(e->act_hist[h], e->last_action, sizeof(REAL) * 4);
+  for (int h = 0; h < PO_HIST; ++h) e->hist_alias[h] = e->last_action_alias;       /* :425-426 the view itself */
   for (int i = 0; i < 4; ++i) e->env_last_action[i] = e->last_action[i]; /* :428 */
   compute_history(c, e, rng, obs);                                 /* :429 */
 }
@@ -762,6 +809,21 @@ void SUF(po_philox_reset_sample)(const po_config *c, uint64_t seed, uint64_t env
   for (int i = 0; i < 4; ++i) s->dr_T[i] = DRV(r[7][i], c->motor_time_constant);
   for (int i = 0; i < 4; ++i) s->dr_t2w[i] = DRV(r[8][i], k.THRUST2WEIGHT_RATIO);
 #undef DRV
+  /* rows 0..B-2 of the latency action buffer: blocks 9.. (csrc/pds_reset.h kBlkLatRows) */
+  if (c->use_latency && c->latency >= c->time_step) {
+    int B = (int)floor(c->latency / c->time_step);
+    if (B < 1) B = 1;
+    if (B > PO_MAX_LAT) B = PO_MAX_LAT;
+    for (int row = 0; row < B - 1; ++row) {
+      uint32_t ctr[4] = {(uint32_t)env_id, (uint32_t)tick, (uint32_t)(tick >> 32), 9u + (uint32_t)row};
+      uint32_t w[4];
+      po_philox4x32_10(ctr, key, w);
+      REAL y[4];
+      box_muller(w[0], w[1], &y[0], &y[1]);
+      box_muller(w[2], w[3], &y[2], &y[3]);
+      for (int i = 0; i < 4; ++i) s->action_buf[row][i] = (REAL)k.HOVER_ACTION + (REAL)0.02 * y[i];
+    }
+  }
 }
 
 /* In-kernel NOISE streams of the new framework (Philox4x32-7; block ids as in csrc/pds_reset.h),

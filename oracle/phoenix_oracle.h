@@ -33,6 +33,7 @@ extern "C" {
 #define PO_TASK_TAKEOFF 2
 #define PO_MAX_OBS 24 /* largest single observation o (TakeOff noise-free: 20) rounded up */
 #define PO_HIST 2     /* observation_history_size default (envs/base.py:44) */
+#define PO_MAX_LAT 8  /* rows of drone.action_buffer the oracle can hold (envs/agents.py:180-182) */
 
 /* Mirror of the env ctor kwargs on the path (envs/base.py:26-48, envs/hover.py:7-24). */
 typedef struct po_config {
@@ -53,7 +54,8 @@ typedef struct po_config {
   double init_xyz[3];
   double init_rpy[3], init_xyz_dot[3], init_rpy_dot[3]; /* envs/base.py:84-91; mutated by simopt callers */
   int32_t control_mode;              /* 0 PWM, 1 AttitudeRate, 2 Attitude (envs/control.py:91-287) */
-  int32_t pad2_;
+  int32_t use_latency;               /* CrazyFlieAgent(use_latency=...), envs/agents.py:125,165; Simple agent: False (:492) */
+  double latency;                    /* [s] envs/base.py:40; buf_size = max(1, int(latency // time_step)), agents.py:180 */
 } po_config;
 
 /* Values drawn by one reset() in the reference's draw order (the *sampled values*, i.e. what
@@ -69,6 +71,9 @@ typedef struct po_reset_sample {
   double dr_dt, dr_m, dr_J[3], dr_ftf0, dr_ftf1, dr_T[4], dr_t2w[4];
   int32_t ref_offset;   /* Circle: randint(0,300) */
   int32_t pad_;
+  /* rows 0..B-2 of np.random.normal(HOVER_ACTION, .02, size=(buf_size, 4)) before clipping (hover.py:226-228);
+   * the last row is `action` above (it becomes drone.last_action) */
+  double action_buf[PO_MAX_LAT - 1][4];
 } po_reset_sample;
 
 /* Source of standard variates for the stochastic parts (OU thrust noise, SensorNoise).
@@ -89,8 +94,14 @@ typedef struct po_rng {
     REAL dt, m, J[3], ftf0, ftf1, A[4], B[4], K[4], T[4], t2w[4], T_s;                             \
     REAL ou[4], gyro_bias[3], lpf[3], kf_state[17];                                                 \
     REAL rate_int[3], rate_err[3], att_int[3], att_err[3]; /* PID integrals / last errors */        \
+    REAL action_buffer[PO_MAX_LAT][4]; /* drone.action_buffer, rows [0, buf_size) */                \
     int32_t iteration, ref_offset, elapsed_steps, obs_len;                                          \
+    int32_t use_latency, buf_size, action_idx; /* envs/agents.py:165,180,183 */                    \
+    /* action_history[h] / drone.last_action still ARE the numpy view action_buffer[-1, :] that    \
+     * drone.reset() / task_specific_reset hand out (agents.py:386, hover.py:229) */                \
+    int32_t hist_alias[PO_HIST], last_action_alias;                                                 \
   } po_env##SUF;                                                                                    \
+  void po_set_latency##SUF(const po_config *c, po_env##SUF *e, double new_latency);                 \
   int po_sizeof_env##SUF(void);                                                                     \
   void po_quat_from_euler##SUF(const REAL rpy[3], REAL q[4]);                                       \
   void po_matrix_from_quat##SUF(const REAL q[4], REAL R[9]);                                        \

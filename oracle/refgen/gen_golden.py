@@ -91,7 +91,9 @@ class Recorder:
 STATE_FIELDS = ["xyz", "rpy", "quat", "xyz_dot", "rpy_dot", "x", "last_action", "env_last_action",
                 "act_hist", "obs_hist", "target_pos", "dt", "m", "J", "ftf0", "ftf1", "A", "B", "K",
                 "ou", "gyro_bias", "lpf", "kf_state", "iteration", "ref_offset",
-                "rate_int", "rate_err", "att_int", "att_err"]
+                "rate_int", "rate_err", "att_int", "att_err",
+                "action_buffer", "action_idx", "buf_size", "use_latency", "hist_alias", "last_action_alias"]
+MAX_LAT = 8
 
 
 def capture(env):
@@ -101,8 +103,13 @@ def capture(env):
     for i, o in enumerate(e.observation_history):
         oh[i, :len(o)] = o
     ah = np.zeros((2, 4))
+    alias = np.zeros(2, np.int32)
     for i, a in enumerate(e.action_history):
         ah[i] = np.array(a, dtype=np.float64)
+        # the deque entry may still BE the view action_buffer[-1, :] handed out by drone.reset() (agents.py:386)
+        alias[i] = int(isinstance(a, np.ndarray) and np.shares_memory(a, d.action_buffer))
+    ab = np.zeros((MAX_LAT, 4))
+    ab[:d.action_buffer.shape[0]] = d.action_buffer
     st = dict(
         xyz=np.array(d.xyz, dtype=np.float64), rpy=np.array(d.rpy, dtype=np.float64),
         quat=np.array(d.quaternion, dtype=np.float64), xyz_dot=np.array(d.xyz_dot, dtype=np.float64),
@@ -119,6 +126,9 @@ def capture(env):
         lpf=np.ones(3) * np.asarray(e.gyro_lpf._x, dtype=np.float64),
         kf_state=np.array(e.state, dtype=np.float64).reshape(-1)[:17],
         iteration=int(e.iteration), ref_offset=int(getattr(e, "ref_offset", 0)),
+        action_buffer=ab, action_idx=int(d.action_idx), buf_size=int(d.action_buffer.shape[0]),
+        use_latency=int(bool(d.use_latency)), hist_alias=alias,
+        last_action_alias=int(isinstance(d.last_action, np.ndarray) and np.shares_memory(d.last_action, d.action_buffer)),
     )
     # PID controller state (envs/control.py:133-134, 227-228, 239-241)
     ctl = d.control
@@ -132,12 +142,21 @@ def capture(env):
     return st
 
 
-def parse_reset_sample(task, calls, dr_on, motor_on, reset_dist):
+def _action_rows(s, v):
+    """np.random.normal(HOVER_ACTION, 0.02, size=action_buffer.shape): all rows but the last go to
+    action_buf, the last one (drone.last_action) to action."""
+    rows = v.reshape(-1, 4)
+    s["action"] = rows[-1]
+    s["action_buf"][:rows.shape[0] - 1] = rows[:-1]
+
+
+def parse_reset_sample(task, calls, dr_on, motor_on, reset_dist, buf_size=1):
     """Map the recorded np.random calls of one reset() onto po_reset_sample fields
     (draw order: hover.py:203-228, circle.py:225-257, takeoff.py:188-191, base.py:261-287)."""
     s = dict(pos_offset=np.zeros(3), rpy=np.zeros(3), vel=np.zeros(3), omega=np.zeros(3),
              motor_x=np.zeros(4), action=np.zeros(4), dr_dt=0.0, dr_m=0.0, dr_J=np.zeros(3),
-             dr_ftf0=0.0, dr_ftf1=0.0, dr_T=np.zeros(4), dr_t2w=np.zeros(4), ref_offset=0)
+             dr_ftf0=0.0, dr_ftf1=0.0, dr_T=np.zeros(4), dr_t2w=np.zeros(4), ref_offset=0,
+             action_buf=np.zeros((MAX_LAT - 1, 4)))
     it = iter(calls)
 
     used = dict(normal=0, uniform=0, randint=0)
@@ -157,7 +176,7 @@ def parse_reset_sample(task, calls, dr_on, motor_on, reset_dist):
             s["omega"] = nxt("uniform", 3).copy()
             s["omega"][2] = nxt("uniform", 1)[0]
             s["motor_x"] = nxt("normal", 4)
-            s["action"] = nxt("normal", 4)
+            _action_rows(s, nxt("normal", 4 * buf_size))
         elif task == "circle":
             s["ref_offset"] = int(nxt("randint", 1)[0])
             s["pos_offset"] = nxt("uniform", 3)
@@ -167,7 +186,7 @@ def parse_reset_sample(task, calls, dr_on, motor_on, reset_dist):
             s["omega"][:2] = nxt("uniform", 2)
             s["omega"][2] = nxt("uniform", 1)[0]
             s["motor_x"] = nxt("normal", 4)
-            s["action"] = nxt("normal", 4)
+            _action_rows(s, nxt("normal", 4 * buf_size))
         else:
             s["pos_offset"][:2] = nxt("uniform", 2)
             s["rpy"][2] = nxt("uniform", 1)[0]
@@ -185,20 +204,26 @@ def parse_reset_sample(task, calls, dr_on, motor_on, reset_dist):
 
 
 SAMPLE_FIELDS = ["pos_offset", "rpy", "vel", "omega", "motor_x", "action", "dr_dt", "dr_m", "dr_J",
-                 "dr_ftf0", "dr_ftf1", "dr_T", "dr_t2w", "ref_offset"]
+                 "dr_ftf0", "dr_ftf1", "dr_T", "dr_t2w", "ref_offset", "action_buf"]
 
 
 # ------------------------------------------------------------------------------------------------
 # scenario runner
 # ------------------------------------------------------------------------------------------------
 def run_scenario(name, task, kwargs, episodes, steps, action_fn, seed, motor=False,
-                 init_override=None, full_episode=False):
+                 init_override=None, full_episode=False, latency_on=False, set_latency=None):
     rec = Recorder(seed)
     rec.install()
     env = gym.make(ENV_IDS[task], **kwargs)
     e = env.unwrapped
     if motor:
         e.drone.use_motor_dynamics = True  # debug/compare_system_equations_with_PyBullet.py:26-30
+    if latency_on:
+        # the Simple agent is built with use_latency=False (agents.py:492); the flag is flipped the way
+        # use_motor_dynamics is, the buffer keeps its ctor size max(1, int(latency // time_step)) (agents.py:180)
+        e.drone.use_latency = True
+    if set_latency is not None:
+        e.drone.set_latency(set_latency)  # the sim-opt route, simopt/pybullet.py:248
     reset_dist = kwargs.get("enable_reset_distribution", True)
     dr_on = kwargs.get("domain_randomization", 0.10) > 0
     act_rs = np.random.RandomState(seed + 12345)
@@ -233,7 +258,7 @@ def run_scenario(name, task, kwargs, episodes, steps, action_fn, seed, motor=Fal
         rec.clear()
         out["z_off"].append(len(z_all)); out["u_off"].append(len(u_all))
         o, _ = env.reset()
-        smp = parse_reset_sample(task, rec.calls, dr_on, motor, reset_dist)
+        smp = parse_reset_sample(task, rec.calls, dr_on, motor, reset_dist, buf_size=e.drone.action_buffer.shape[0])
         for k in SAMPLE_FIELDS:
             samples[k].append(smp[k])
         out["z_skip"].append(smp["_z_skip"]); out["u_skip"].append(smp["_u_skip"])
@@ -261,7 +286,8 @@ def run_scenario(name, task, kwargs, episodes, steps, action_fn, seed, motor=Fal
         z_all.extend(rec.z); u_all.extend(rec.u)
     out["z_off"].append(len(z_all)); out["u_off"].append(len(u_all))
     meta = dict(name=name, task=task, kwargs={k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in kwargs.items()},
-                motor=bool(motor), episodes=E, steps=T, obs_dim=int(D), seed=seed,
+                motor=bool(motor), latency_on=bool(latency_on), set_latency=set_latency,
+                episodes=E, steps=T, obs_dim=int(D), seed=seed,
                 generator="oracle/refgen/gen_golden.py", reference="SvenGronauer/phoenix-drone-simulation v1.1")
     arrays = dict(meta=np.array(json.dumps(meta)), actions=actions, obs=obs, reward=reward, cost=cost,
                   terminated=terminated, truncated=truncated, valid=valid,
@@ -413,6 +439,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(HERE, "..", "..", "tests", "golden"))
     ap.add_argument("--rate", action="store_true", help="also time the reference python loop")
+    ap.add_argument("--only", default=None, help="comma-separated name fragments: regenerate only those scenarios")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     _orig = (np.random.normal, np.random.randn, np.random.uniform, np.random.randint)
@@ -439,22 +466,43 @@ def main():
     scen.append(("takeoff_edge", "takeoff", dict(DET, enable_reset_distribution=False), 3, 4, act_random(0.2, center=0.3), 191, False, edge_takeoff, True))
     scen.append(("circle_edge", "circle", dict(DET, enable_reset_distribution=False), 3, 4, act_random(0.2), 192, False, edge_circle, True))
     scen.append(("hover_bigact", "hover", dict(DET), 4, 6, lambda ep, t, rs, e: rs.uniform(-5, 5, 4), 193, False, None, True))
+    # delayed actions through drone.action_buffer (envs/agents.py:179-183, 267-276, 384-404)
+    lat = {}
+    def lat_scen(name, task, kw, E, T, fn, seed, motor=False, set_latency=None, latency_on=True):
+        scen.append((name, task, kw, E, T, fn, seed, motor, None, False))
+        lat[name] = dict(latency_on=latency_on, set_latency=set_latency)
+    lat_scen("hover_lat1", "hover", dict(DET), 10, 8, act_random(0.3), 300)                             # default 0.015 s: 1 row
+    lat_scen("hover_lat2_motor", "hover", dict(DET, latency=0.025), 10, 8, act_random(0.3), 301, motor=True)
+    lat_scen("circle_lat2_dr", "circle", dict(DET, latency=0.02, domain_randomization=0.1), 10, 8, act_random(0.3), 302)
+    lat_scen("takeoff_lat3", "takeoff", dict(DET, latency=0.035), 6, 8, act_random(0.3, center=0.2), 303)
+    lat_scen("hover_lat3_agg2", "hover", dict(DET, latency=0.035, aggregate_phy_steps=2), 8, 8, act_random(0.3), 304)
+    lat_scen("hover_lat2_noresetdist", "hover", dict(DET, latency=0.025, enable_reset_distribution=False), 4, 8, act_random(0.2), 305)
+    lat_scen("circle_rate_lat2", "circle", dict(DET, control_mode="AttitudeRate", latency=0.02), 8, 8, pid_act, 306)
+    lat_scen("hover_setlat4", "hover", dict(DET), 8, 8, act_random(0.3), 307, set_latency=0.045, latency_on=False)  # int(.045/.01) = 4
+    lat_scen("hover_lat2_defaults", "hover", dict(latency=0.025), 8, 8, act_random(0.2), 308)           # noise + DR + latency
 
+    only = set(args.only.split(",")) if args.only else None
     index = {}
+    if only is not None and os.path.exists(os.path.join(args.out, "INDEX.json")):
+        index = json.load(open(os.path.join(args.out, "INDEX.json")))
     for (name, task, kw, E, T, fn, seed, motor, ov, full) in scen:
         if kw is None:
             continue
-        arrays = run_scenario(name, task, kw, E, T, fn, seed, motor=motor, init_override=ov, full_episode=full)
+        if only is not None and not any(name.startswith(o) or o in name for o in only):
+            continue
+        arrays = run_scenario(name, task, kw, E, T, fn, seed, motor=motor, init_override=ov, full_episode=full,
+                              **lat.get(name, {}))
         path = os.path.join(args.out, name + ".npz")
         np.savez_compressed(path, **arrays)
         index[name] = dict(task=task, episodes=E, steps=T, bytes=os.path.getsize(path))
         print(f"{name:24s} {os.path.getsize(path) / 1024:8.1f} kB")
 
     (np.random.normal, np.random.randn, np.random.uniform, np.random.randint) = _orig
-    np.savez_compressed(os.path.join(args.out, "ground_effect.npz"), **ground_effect_vectors())
-    np.savez_compressed(os.path.join(args.out, "quaternion.npz"), **quaternion_vectors())
-    with open(os.path.join(args.out, "constants.json"), "w") as f:
-        json.dump(constants_vectors(), f, indent=1)
+    if only is None:
+        np.savez_compressed(os.path.join(args.out, "ground_effect.npz"), **ground_effect_vectors())
+        np.savez_compressed(os.path.join(args.out, "quaternion.npz"), **quaternion_vectors())
+        with open(os.path.join(args.out, "constants.json"), "w") as f:
+            json.dump(constants_vectors(), f, indent=1)
     if args.rate:
         rate = reference_cpu_rate()
         rate["_method"] = ("reference python step loop, 1 process, build container (8 cores visible), "

@@ -10,7 +10,7 @@ from oracle import oracle as po
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 SAMPLE_FIELDS = ["pos_offset", "rpy", "vel", "omega", "motor_x", "action", "dr_dt", "dr_m", "dr_J",
-                 "dr_ftf0", "dr_ftf1", "dr_T", "dr_t2w", "ref_offset"]
+                 "dr_ftf0", "dr_ftf1", "dr_T", "dr_t2w", "ref_offset", "action_buf"]
 DYN_FIELDS = ["xyz", "rpy", "quat", "xyz_dot", "rpy_dot"]
 
 
@@ -27,6 +27,8 @@ class Golden:
         self.task = self.meta["task"]
         self.kwargs = dict(self.meta["kwargs"])
         self.motor = self.meta["motor"]
+        self.latency_on = bool(self.meta.get("latency_on", False))  # drone.use_latency flipped after construction
+        self.set_latency = self.meta.get("set_latency")             # drone.set_latency(x) called after construction
         self.E, self.T, self.D = self.meta["episodes"], self.meta["steps"], self.meta["obs_dim"]
 
     def __getitem__(self, k):
@@ -35,6 +37,7 @@ class Golden:
     def oracle_kwargs(self):
         kw = dict(self.kwargs)
         kw["use_motor_dynamics"] = 1 if self.motor else 0
+        kw["use_latency"] = 1 if self.latency_on else 0
         # control_mode is passed through as a string (oracle.default_config maps it)
         if "enable_reset_distribution" in kw:
             kw["enable_reset_distribution"] = int(kw["enable_reset_distribution"])
@@ -48,7 +51,10 @@ class Golden:
 
 
 def make_oracle(g, precision="f64"):
-    return po.OracleEnv(g.task, precision=precision, **g.oracle_kwargs())
+    env = po.OracleEnv(g.task, precision=precision, **g.oracle_kwargs())
+    if g.set_latency is not None:
+        env.set_latency(g.set_latency)
+    return env
 
 
 def begin_episode(env, g, ep):

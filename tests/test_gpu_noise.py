@@ -31,7 +31,7 @@ def test_noisy_single_step_vs_reference(name):
     RTOL, ATOL = gu.tolerances(name)
     pre = {k: [] for k in ("xyz", "rpy", "quat", "xyz_dot", "rpy_dot", "x", "act_hist", "iteration", "ref_offset",
                            "dt", "m", "J", "ftf1", "A", "K", "ou", "gyro_bias", "lpf", "obs_hist",
-                           "rate_int", "rate_err", "att_int", "att_err")}
+                           "rate_int", "rate_err", "att_int", "att_err", "action_buffer", "action_idx")}
     exp = {k: [] for k in ("obs", "reward", "cost", "terminated", "truncated", "ou", "gyro_bias", "lpf", "xyz", "rpy_dot")}
     acts, variates = [], []
     for ep in range(g.E):
@@ -83,9 +83,12 @@ def test_noisy_reset_vs_reference(name):
     env.set_state("ou", g["pre_ou"])
     obs, _ = env.reset_from_samples(S)
     torch.cuda.synchronize()
-    gu.assert_close(obs.cpu().numpy(), g["reset_obs"], RTOL, ATOL, name + " reset obs")
+    # the filtered gyro is a sum of terms of up to |omega| ~ 3.5 rad/s (R^T R^T omega, turn-on bias, random walk,
+    # stale low-pass state) that can nearly cancel: 1e-6 RELATIVE TO THE TERMS is 3.5e-6 absolute on the sum
+    G_ATOL = 4e-6
+    gu.assert_close(obs.cpu().numpy(), g["reset_obs"], RTOL, G_ATOL, name + " reset obs")
     gu.assert_close(env.get_state("gyro_bias").cpu().numpy(), g["reset_gyro_bias"], RTOL, 1e-7, name + " bias")
-    gu.assert_close(env.get_state("gyro_lpf").cpu().numpy(), g["reset_lpf"], RTOL, ATOL, name + " lpf")
+    gu.assert_close(env.get_state("gyro_lpf").cpu().numpy(), g["reset_lpf"], RTOL, G_ATOL, name + " lpf")
     gu.assert_close(env.get_state("noisy_obs").cpu().numpy(), g["reset_obs_hist"][:, 1, :10], RTOL, ATOL, name + " kept obs")
     gu.assert_close(env.get_state("ou").cpu().numpy(), g["pre_ou"], 1e-6, 1e-9, name + " ou untouched")
     env.close()

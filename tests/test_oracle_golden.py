@@ -101,14 +101,23 @@ def _replay(name, precision, rtol, atol, resync):
             if resync and t > 0:
                 # single-step parity: restart every step from the reference's recorded state
                 for k in gu.DYN_FIELDS + ["x", "last_action", "env_last_action", "act_hist", "obs_hist", "ou", "gyro_bias", "lpf", "kf_state",
-                          "rate_int", "rate_err", "att_int", "att_err"]:
+                          "rate_int", "rate_err", "att_int", "att_err", "action_buffer", "action_idx", "hist_alias",
+                          "last_action_alias"]:
                     env.set(k, g["step_" + k][ep, t - 1])
             obs, r, term, trunc, cost = env.step(g["actions"][ep, t])
             w = f"{name} ep{ep} t{t}"
             gu.assert_close(obs, g["obs"][ep, t], rtol, atol, w + " obs")
             gu.assert_close(r, g["reward"][ep, t], rtol, atol * 10, w + " reward")
-            for k in gu.DYN_FIELDS + ["x", "ou", "gyro_bias", "lpf", "rate_int", "att_int"]:
+            for k in gu.DYN_FIELDS + ["x", "ou", "gyro_bias", "lpf", "rate_int", "att_int", "action_buffer", "act_hist"]:
+                if k == "act_hist":  # what the reference's deque shows, views of action_buffer[-1] resolved
+                    B = int(env.get("buf_size"))
+                    got = np.array([env.get("action_buffer")[B - 1] if env.get("hist_alias")[h] else env.get("act_hist")[h]
+                                    for h in range(2)])
+                    gu.assert_close(got, g["step_act_hist"][ep, t], rtol, atol, w + " act_hist")
+                    continue
                 gu.assert_close(env.get(k), g["step_" + k][ep, t], rtol, atol, w + " " + k)
+            assert int(env.get("action_idx")) == int(g["step_action_idx"][ep, t]), w
+            assert [int(v) for v in env.get("hist_alias")] == [int(v) for v in g["step_hist_alias"][ep, t]], w
             assert term == bool(g["terminated"][ep, t]), w
             assert trunc == bool(g["truncated"][ep, t]), w
             assert cost == g["cost"][ep, t], w
