@@ -22,12 +22,12 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(task, kw, target_seconds=12.0):
+def cpu_baseline(task, kw, n_cpu, target_seconds=12.0):
     """Time the CPU oracle (C restatement, float32, OpenMP over envs) on a bounded sample of the
-    same workload: N_cpu envs, same action recipe, auto-reset on.  Reported baseline only."""
+    same workload: the SAME number of envs as the GPU run, same action recipe, auto-reset on,
+    as many steps as fit in ~12 s.  Reported baseline only."""
     import numpy as np
     from oracle import oracle as po
-    n_cpu = 65536
     threads = po.lib().po_max_threads()
     orc = po.OracleBatch(task, n_cpu, precision="f32", nthreads=threads, **kw)
     orc.reset(0, 0)
@@ -36,9 +36,9 @@ def cpu_baseline(task, kw, target_seconds=12.0):
     acts = (hover + 0.1 * rs.standard_normal((8, n_cpu, 4))).astype(np.float32)
     orc.step(acts[0], seed=0, tick=1)  # first touch
     t0 = time.perf_counter()
-    for s in range(10):
+    for s in range(4):
         orc.step(acts[s % 8], seed=0, tick=1 + s)
-    one = (time.perf_counter() - t0) / 10
+    one = (time.perf_counter() - t0) / 4
     steps = int(max(4, min(8000, target_seconds / max(one, 1e-5))))
     t0 = time.perf_counter()
     for s in range(steps):
@@ -56,10 +56,21 @@ def cpu_baseline(task, kw, target_seconds=12.0):
         one_t.step(a1[k1 % 8], seed=0, tick=2 + k1)
         k1 += 1
     dt1 = time.perf_counter() - t0
-    return {"value": n_cpu * steps / dt, "unit": "env-steps/s", "cores": int(threads), "kind": "port",
-            "sample": f"oracle/phoenix_oracle.c float32 + OpenMP, {n_cpu} envs x {steps} steps "
-                      f"({dt:.1f} s), same Hover config and action recipe, auto-reset on",
-            "value_1_thread": n1 * k1 / dt1}
+    out = {"value": n_cpu * steps / dt, "unit": "env-steps/s", "cores": int(threads), "kind": "port",
+           "sample": f"oracle/phoenix_oracle.c (C restatement of the reference, float32) + OpenMP on {threads} host threads, "
+                     f"{n_cpu} envs (= the GPU run's N) x {steps} steps ({dt:.1f} s), same config and action recipe, "
+                     f"auto-reset on; value_1_thread: {n1} envs on 1 thread for 3 s",
+           "value_1_thread": n1 * k1 / dt1}
+    # the reference's own Python loop cannot travel to the GPU box; its rate was measured in the build
+    # container (1 process, Bullet calls stubbed => upper bound) by oracle/refgen/gen_golden.py --rate
+    ref = os.path.join(ROOT, "tests", "golden", "reference_cpu_rate.json")
+    if os.path.exists(ref):
+        r = json.load(open(ref))
+        key = f"{task}_det" if kw.get("observation_noise", 1) <= 0 else f"{task}_defaults"
+        if key in r:
+            out["reference_python_env_steps_per_s"] = r[key]
+            out["reference_python_note"] = "the reference's Python step loop, 1 process, build container (tests/golden/reference_cpu_rate.json), not this box"
+    return out
 
 
 def main():
@@ -77,8 +88,14 @@ def main():
                     help="eager: one pds_step launch per step (the headline); graph: the same launches captured "
                          "in ONE hipGraph per ring pass and replayed; stepk: open-loop pds_step_k, --k steps per launch")
     ap.add_argument("--k", type=int, default=8, help="steps per launch for --mode stepk")
-    ap.add_argument("--allgather-obs", action="store_true")
+    ap.add_argument("--allgather-obs", nargs="?", const="rccl", default=None, choices=["rccl", "p2p"],
+                    help="single-policy layout: gather every rank's observations after each step; rccl = "
+                         "all_gather_into_tensor, p2p = direct stores into the peers' buffers (sharding.P2PObsGather)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--same-device", action="store_true",
+                    help="TEST ONLY: every rank uses cuda:0 and the control collectives run over gloo, so that the "
+                         "multi-rank code path (incl. --allgather-obs p2p) can be exercised on a 1-GPU box; "
+                         "the numbers of such a run mean nothing")
     ap.add_argument("--no-auto-reset", action="store_true", help="diagnostic only: INVALID as a benchmark number")
     args = ap.parse_args()
 
@@ -91,10 +108,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = dev  # device of the small control tensors (timings)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.same_device:
+            dist.init_process_group("gloo")
+            cdev = torch.device("cpu")
+            if args.allgather_obs == "rccl":
+                raise SystemExit("--same-device has no RCCL: use --allgather-obs p2p")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     task = args.task
     n = 1 << 20
@@ -125,18 +151,29 @@ def main():
     g.manual_seed(rank)
     hover = -1.0 + 2.0 / 2.25
     ring = (hover + act_center_shift) + 0.1 * torch.randn(T, n, 4, generator=g, device=dev, dtype=torch.float32)
-    gathered = torch.empty(world * n, env.obs_dim, device=dev) if (args.allgather_obs and world > 1) else None
+    gather_mode = args.allgather_obs if world > 1 else None
+    gathered = torch.empty(world * n, env.obs_dim, device=dev) if gather_mode == "rccl" else None
+    p2p = None
+    if gather_mode == "p2p":
+        ctl = dist.new_group(backend="gloo")  # host-side hand-shake of the P2P gather (IPC handles, per-step barrier)
+        p2p = pds.P2PObsGather(n, env.obs_dim, dev, sync_group=ctl)
+        gathered = p2p.out
+
+    def do_gather(obs):
+        if gather_mode == "rccl":
+            dist.all_gather_into_tensor(gathered, obs)
+        elif gather_mode == "p2p":
+            p2p.gather(obs)
 
     def one_step(s):
         out = env.step(ring[s % T])
-        if gathered is not None:
-            dist.all_gather_into_tensor(gathered, out[0])
+        do_gather(out[0])
         return out
 
     env.reset()
     if args.mode != "eager":
         # diagnostic modes (never the headline `value` of the driver's default run): same env-steps, fewer launches
-        if gathered is not None:
+        if gather_mode is not None:
             raise SystemExit("--mode graph/stepk: no --allgather-obs")
         K = args.k if args.mode == "stepk" else T
         if args.steps % K or args.warmup % K:
@@ -174,10 +211,24 @@ def main():
     sync()
     wall = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / (args.steps // K)  # average launch-to-launch duration on the stream
+    per_rank_ms, gather_ms = None, None
     if world > 1:
-        t = torch.tensor([wall], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
+        mine = torch.tensor([wall], device=cdev, dtype=torch.float64)
+        allw = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allw, mine)
+        per_rank_ms = [float(x.item()) / args.steps * 1e3 for x in allw]  # every rank's own wall time per step
+        wall = max(float(x.item()) for x in allw)                          # the slowest rank defines the step
+        if gather_mode is not None:  # the exchange alone, same buffers, timed separately (not part of `value`)
+            reps = max(4, min(50, args.steps // 4))
+            last = env.step(ring[0])[0]
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                do_gather(last)
+            sync()
+            g = torch.tensor([(time.perf_counter() - t1) / reps * 1e3], device=cdev, dtype=torch.float64)
+            dist.all_reduce(g, op=dist.ReduceOp.MAX)
+            gather_ms = float(g.item())
 
     total_envs = n * world
     value = total_envs * args.steps / wall
@@ -186,11 +237,15 @@ def main():
     achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
     # HBM bytes per launch measured with the PMC counters (separate rocprofv3 passes,
     # profiles/run_profile.sh) for exactly this workload; null for workloads that were not profiled
-    traffic = None
-    if args.config == 0 and task == "hover" and n == (1 << 20) and not args.no_auto_reset:
-        tf = os.path.join(ROOT, "profiles", "r01_traffic_headline.json")
-        if os.path.exists(tf):
-            traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+    traffic, traffic_src = None, None
+    if args.config == 0 and task == "hover" and n == (1 << 20) and not args.no_auto_reset and args.mode == "eager":
+        for name in ("r02_traffic_headline.json", "r01_traffic_headline.json"):
+            tf = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(tf):
+                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+                traffic_src = (f"profiles/{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                               "(profiles/run_profile.sh), recorded, NOT measured in this run")
+                break
     if rank == 0:
         line = {
             "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
@@ -201,23 +256,31 @@ def main():
                                    f"{'on' if kw['observation_noise'] > 0 else 'off'}, thrust noise {kw['motor_thrust_noise']}, "
                                    f"domain randomisation {kw['domain_randomization']}, auto-reset on, "
                                    f"action ring [64,N,4] = hover{act_center_shift:+.1f} + 0.1*N(0,1)"
-                                   + (", RCCL all-gather of obs" if gathered is not None else ""),
+                                   + (f", all-gather of obs ({gather_mode})" if gather_mode else ""),
                        "envs_per_gpu": n, "obs_dim": env.obs_dim, "bytes_per_env_step": bytes_per,
-                       "parallelism": f"env-shard x{world}, no data-path collective" if gathered is None
-                       else f"env-shard x{world} + all-gather(obs)"},
+                       "parallelism": f"env-shard x{world}, no data-path collective" if gather_mode is None
+                       else f"env-shard x{world} + all-gather(obs, {gather_mode})"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         # the same fraction from the wall clock of the timed region (host launch gaps included)
+                         "frac_wall": launch_bytes / K / (wall / args.steps) / 1e9 / HBM_PEAK_GBS,
                          "kernel": "pds::step_kernel" if args.mode != "stepk" else "pds::step_k_kernel",
                          "avg_launch_ms": kernel_ms, "steps_per_launch": K, "mode": args.mode,
                          "algorithmic_bytes_per_launch": launch_bytes},
         }
+        if per_rank_ms is not None:
+            line["per_rank_ms_per_step"] = per_rank_ms
+        if gather_ms is not None:
+            line["allgather_ms"] = gather_ms  # the exchange alone (max over ranks), for reading the scaling curve
         if not args.no_cpu_baseline and world == 1:
             try:
-                line["cpu_baseline"] = cpu_baseline(task, {k: (int(v) if isinstance(v, bool) else v) for k, v in kw.items()})
+                line["cpu_baseline"] = cpu_baseline(task, {k: (int(v) if isinstance(v, bool) else v) for k, v in kw.items()}, n)
             except Exception as e:  # the baseline is reported, never required for the GPU number
                 line["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port",
                                         "sample": f"failed: {e}"}
         print(json.dumps(line))
+    if p2p is not None:
+        p2p.release()
     env.close()
     if world > 1:
         dist.destroy_process_group()

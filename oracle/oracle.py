@@ -271,9 +271,7 @@ class OracleBatch:
         self.n = int(n)
         Env = EnvF64 if precision == "f64" else EnvF32
         self.envs = (Env * self.n)()
-        init = getattr(self.L, "po_env_init" + self.suf)
-        for i in range(self.n):
-            init(C.byref(self.cfg), C.byref(self.envs[i]))
+        getattr(self.L, "po_env_init_batch" + self.suf)(C.byref(self.cfg), self.envs, C.c_int64(self.n))
         self.obs_dim = getattr(self.L, "po_obs_dim" + self.suf)(C.byref(self.cfg))
         self.nthreads = nthreads or self.L.po_max_threads()
         self.obs = np.zeros((self.n, self.obs_dim), self.np_real)

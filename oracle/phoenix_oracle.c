@@ -968,4 +968,8 @@ void SUF(po_step_batch)(const po_config *c, ENV *envs, int64_t n, const REAL *ac
   (void)nthreads;
 }
 
+void SUF(po_env_init_batch)(const po_config *c, ENV *envs, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) SUF(po_env_init)(c, &envs[i]);
+}
+
 int SUF(po_sizeof_env)(void) { return (int)sizeof(ENV); }

@@ -8,8 +8,8 @@ from .build import build_library, library_path  # noqa: F401
 from .envs import (DroneVecEnv, DroneHoverSimpleEnv, DroneCircleSimpleEnv, DroneTakeOffSimpleEnv,  # noqa: F401
                    make, register, registry, Box)
 from . import native  # noqa: F401
-from .sharding import shard_range, make_sharded, all_gather_obs  # noqa: F401
+from .sharding import shard_range, make_sharded, all_gather_obs, P2PObsGather  # noqa: F401
 
 __all__ = ["make", "register", "registry", "DroneVecEnv", "DroneHoverSimpleEnv",
            "DroneCircleSimpleEnv", "DroneTakeOffSimpleEnv", "Box", "build_library", "library_path",
-           "native", "shard_range", "make_sharded", "all_gather_obs"]
+           "native", "shard_range", "make_sharded", "all_gather_obs", "P2PObsGather"]

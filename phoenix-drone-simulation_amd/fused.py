@@ -22,6 +22,23 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_NULL = _NullCtx()
+
+
+def _on(t):
+    """Context that makes t's device current if it is not (a process that holds envs / networks on several
+    GPUs must not launch on, or take the stream of, whichever device happens to be current)."""
+    return _NULL if t.device.index == torch.cuda.current_device() else torch.cuda.device(t.device)
+
+
 class FusedMLP:
     """View of `nn.Sequential(Linear, act, Linear, act, Linear[, Identity])` as a struct pds_mlp."""
 
@@ -58,16 +75,19 @@ class FusedMLP:
                                                                        l[2].weight, l[2].bias))
 
     @staticmethod
-    def _stream():
-        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    def _stream(t=None):
+        """The caller's current stream ON THE TENSOR'S DEVICE (the kernels of pds_mlp / pds_train / pds_gae run
+        on the current device: `_on(t)` makes that the tensor's one for the duration of the call)."""
+        return C.c_void_p(torch.cuda.current_stream(t.device if t is not None else None).cuda_stream)
 
     def forward(self, x, index=None, mean=None, std=None, eps=1e-5, out=None):
         """y[B, d_out] = net(standardise(x[index]))."""
         self._bind()
         B = x.shape[0] if index is None else index.shape[0]
         y = out if out is not None else torch.empty(B, self.m.d_out, device=x.device)
-        rc = self.lib.pds_mlp_forward(C.byref(self.m), _ptr(x), _ptr(index), B, _ptr(mean), _ptr(std), float(eps),
-                                      _ptr(y), self._stream())
+        with _on(x):
+            rc = self.lib.pds_mlp_forward(C.byref(self.m), _ptr(x), _ptr(index), B, _ptr(mean), _ptr(std), float(eps),
+                                          _ptr(y), self._stream(x))
         if rc != native.OK:
             raise RuntimeError(f"pds_mlp_forward -> {rc}")
         return y
@@ -76,9 +96,10 @@ class FusedMLP:
         """Fills the parameters' .grad with d loss_pi / d theta; returns the stats tensor
         [sum(-min(..)), sum(ratio), sum(0.5 z^2), B] (device, no sync)."""
         self._bind()
-        rc = self.lib.pds_ppo_policy_grad(C.byref(self.m), _ptr(x), _ptr(act), _ptr(adv), _ptr(logp_old), _ptr(log_std),
-                                          x.shape[0], float(clip_ratio), _ptr(self.flat_grad), _ptr(self.stats),
-                                          _ptr(self.workspace), self._stream())
+        with _on(x):
+            rc = self.lib.pds_ppo_policy_grad(C.byref(self.m), _ptr(x), _ptr(act), _ptr(adv), _ptr(logp_old), _ptr(log_std),
+                                              x.shape[0], float(clip_ratio), _ptr(self.flat_grad), _ptr(self.stats),
+                                              _ptr(self.workspace), self._stream(x))
         if rc != native.OK:
             raise RuntimeError(f"pds_ppo_policy_grad -> {rc}")
         return self.stats
@@ -91,9 +112,10 @@ class FusedMLP:
             self.adam_steps = 0
         self.adam_steps += 1
         self._bind()
-        rc = self.lib.pds_adam_step(C.byref(self.m), _ptr(self.flat_grad), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
-                                    self.adam_steps, float(lr), float(betas[0]), float(betas[1]), float(eps),
-                                    self._stream())
+        with _on(self.flat_grad):
+            rc = self.lib.pds_adam_step(C.byref(self.m), _ptr(self.flat_grad), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
+                                        self.adam_steps, float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                        self._stream(self.flat_grad))
         if rc != native.OK:
             raise RuntimeError(f"pds_adam_step -> {rc}")
 
@@ -101,8 +123,9 @@ class FusedMLP:
         """Fills .grad with d mse(net(x[index]), target[index]) / d theta; stats[0] = sum of squared errors."""
         self._bind()
         B = x.shape[0] if index is None else index.shape[0]
-        rc = self.lib.pds_value_grad(C.byref(self.m), _ptr(x), _ptr(index), _ptr(target), B, _ptr(self.flat_grad),
-                                     _ptr(self.stats), _ptr(self.workspace), self._stream())
+        with _on(x):
+            rc = self.lib.pds_value_grad(C.byref(self.m), _ptr(x), _ptr(index), _ptr(target), B, _ptr(self.flat_grad),
+                                         _ptr(self.stats), _ptr(self.workspace), self._stream(x))
         if rc != native.OK:
             raise RuntimeError(f"pds_value_grad -> {rc}")
         return self.stats
@@ -110,17 +133,19 @@ class FusedMLP:
 
 def gaussian_sample(mu, log_std, act_out, logp_out, seed, call, id_base=0, deterministic=False):
     """act_out[n, d] = mu + exp(log_std) * z, logp_out[n] = log N(act | mu, sigma) summed over d."""
-    rc = native.load().pds_gaussian_sample(_ptr(mu), _ptr(log_std), mu.shape[0], mu.shape[1], int(seed), int(call),
-                                           int(id_base), int(bool(deterministic)), _ptr(act_out), _ptr(logp_out),
-                                           FusedMLP._stream())
+    with _on(mu):
+        rc = native.load().pds_gaussian_sample(_ptr(mu), _ptr(log_std), mu.shape[0], mu.shape[1], int(seed), int(call),
+                                               int(id_base), int(bool(deterministic)), _ptr(act_out), _ptr(logp_out),
+                                               FusedMLP._stream(mu))
     if rc != native.OK:
         raise RuntimeError(f"pds_gaussian_sample -> {rc}")
 
 
 def rollout_record(rew, term, trunc, rew_buf_t, term_buf_t, trunc_buf_t, ep_ret, ep_len, stats):
     """One step of the rollout bookkeeping (see include/pds.h pds_rollout_record)."""
-    rc = native.load().pds_rollout_record(_ptr(rew), _ptr(term), _ptr(trunc), rew.shape[0], _ptr(rew_buf_t),
-                                          _ptr(term_buf_t), _ptr(trunc_buf_t), _ptr(ep_ret), _ptr(ep_len), _ptr(stats),
-                                          FusedMLP._stream())
+    with _on(rew):
+        rc = native.load().pds_rollout_record(_ptr(rew), _ptr(term), _ptr(trunc), rew.shape[0], _ptr(rew_buf_t),
+                                              _ptr(term_buf_t), _ptr(trunc_buf_t), _ptr(ep_ret), _ptr(ep_len), _ptr(stats),
+                                              FusedMLP._stream(rew))
     if rc != native.OK:
         raise RuntimeError(f"pds_rollout_record -> {rc}")

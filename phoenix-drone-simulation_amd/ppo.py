@@ -182,11 +182,12 @@ def gae(rew, val, terminated, truncated, final_val, last_val, gamma, lam, rew_sc
     T, N = rew.shape
     out = [torch.empty_like(rew) for _ in range(3)]
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
-    rc = native.load().pds_gae(p(rew.contiguous()), p(val.contiguous()), p(terminated.contiguous()),
-                               p(truncated.contiguous()), p(final_val), p(last_val.contiguous()),
-                               C.c_float(gamma), C.c_float(lam), C.c_float(rew_scale), C.c_float(rew_clip),
-                               T, N, p(out[0]), p(out[1]), p(out[2]),
-                               C.c_void_p(torch.cuda.current_stream(rew.device).cuda_stream))
+    with torch.cuda.device(rew.device):  # pds_gae launches on the current device
+        rc = native.load().pds_gae(p(rew.contiguous()), p(val.contiguous()), p(terminated.contiguous()),
+                                   p(truncated.contiguous()), p(final_val), p(last_val.contiguous()),
+                                   C.c_float(gamma), C.c_float(lam), C.c_float(rew_scale), C.c_float(rew_clip),
+                                   T, N, p(out[0]), p(out[1]), p(out[2]),
+                                   C.c_void_p(torch.cuda.current_stream(rew.device).cuda_stream))
     if rc != 0:
         raise RuntimeError(f"pds_gae failed ({rc})")
     return out
@@ -446,7 +447,16 @@ class PPOTrainer:
             self.ac.update(frac=self.epoch / self.epochs)
         stats = self.roll_out()
         info = self.update()
-        if not (math.isfinite(info["loss_pi"]) and math.isfinite(info["loss_v"])):
+        bad_here = not (math.isfinite(info["loss_pi"]) and math.isfinite(info["loss_v"]))
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            # the losses are rank-local (the shard that holds a NaN env sees it first): decide TOGETHER, or the
+            # other ranks would walk into the next all-reduce and hang until the RCCL timeout
+            flag = torch.tensor([1.0 if bad_here else 0.0], device=self.env.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            bad_any = bool(flag.item() > 0)
+        else:
+            bad_any = bad_here
+        if bad_any:
             # the reference only guards NPG (algs/npg/npg.py:118,126); a poisoned batch would train NaNs
             bad = self.env.count_nonfinite() if hasattr(self.env, "count_nonfinite") else "?"
             raise FloatingPointError(f"non-finite loss in epoch {self.epoch + 1}: {bad} envs hold a NaN/Inf state "

@@ -32,17 +32,30 @@ def make_sharded(env_id, total_envs, rank=None, world_size=None, device=None, **
     return make(env_id, num_envs=stop - start, env_id_base=start, device=device, **kwargs)
 
 
+_SIZES = {}  # (group id, local rows) -> rows of every rank: the all_gather of the sizes happens once
+
+
+def shard_sizes(rows, device, group=None):
+    """Rows of every rank's shard, gathered once per (group, local size) and cached: a per-call gather of
+    the sizes plus `.item()` would put a host synchronisation on every step of the gather path."""
+    key = (id(group), int(rows))
+    if key not in _SIZES:
+        world = dist.get_world_size(group)
+        n = torch.tensor([int(rows)], device=device, dtype=torch.int64)
+        sizes = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(sizes, n, group=group)
+        _SIZES[key] = [int(x.item()) for x in sizes]
+    return _SIZES[key]
+
+
 def all_gather_obs(obs, out=None, group=None):
     """Gather every rank's [n_r, D] observation block into one [sum n_r, D] tensor, ordered by
     global env id.  Equal shards use all_gather_into_tensor (one RCCL call); ragged shards fall
-    back to all_gather on a list."""
+    back to all_gather on a list.  No host synchronisation after the first call."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return obs
     world = dist.get_world_size(group)
-    n = torch.tensor([obs.shape[0]], device=obs.device, dtype=torch.int64)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n, group=group)
-    sizes = [int(s.item()) for s in sizes]
+    sizes = shard_sizes(obs.shape[0], obs.device, group)
     if len(set(sizes)) == 1:
         if out is None:
             out = torch.empty((sum(sizes),) + tuple(obs.shape[1:]), dtype=obs.dtype, device=obs.device)
@@ -58,6 +71,111 @@ def all_gather_obs(obs, out=None, group=None):
     parts = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(parts, padded, group=group)
     return torch.cat([p[:s] for p, s in zip(parts, sizes)], 0)
+
+
+class P2PObsGather:
+    """All-gather of the observation shards by direct peer-to-peer STORES: every rank owns
+    a full-size [sum n_r, D] buffer that its peers have opened through the HIP IPC handle of its
+    allocation; after a step each rank copies its [n_r, D] block straight into the matching rows of every
+    peer's buffer -- G-1 independent transfers that use all xGMI links of the GPU at once (the fabric is
+    point to point: 7 links per MI355X), where a ring all-gather moves the same bytes over one link per
+    hop.  Reference role: none of its own -- the reference's workers never exchange env data
+    (utils/mpi_tools.py:117-187 only averages gradients and statistics); this is the optional layout in
+    which ONE policy consumes the whole batch.
+
+    Synchronisation (no device-wide sync on the host): the copies run on a side stream behind the
+    producer's step; each rank then records an inter-process event; a host barrier on `sync_group`
+    (a gloo group: microseconds on one node) guarantees that every record is enqueued before any rank
+    enqueues `wait_event` on its peers' events; the consumer's stream waits for them on the GPU.  The
+    buffers are coarse-grained device memory, coherent across devices at kernel boundaries, which is
+    what the event wait provides.
+
+    On CPU tensors (the world-2 gloo tests) the peer buffers are files under /dev/shm mapped by both
+    processes and the events degenerate to the barrier: same slicing and hand-shake logic, no HIP.
+    """
+
+    def __init__(self, rows, width, device, dtype=torch.float32, group=None, sync_group=None, tag="pds_p2p"):
+        if not dist.is_initialized():
+            raise RuntimeError("P2PObsGather needs an initialised process group")
+        self.group, self.sync_group = group, sync_group if sync_group is not None else group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.device = torch.device(device)
+        self.sizes = shard_sizes(rows, self.device if self.device.type == "cuda" else torch.device("cpu"), group)
+        self.offsets = [sum(self.sizes[:r]) for r in range(self.world)]
+        self.total, self.width = sum(self.sizes), int(width)
+        self._step = 0
+        self._files = []
+        if self.device.type == "cuda":
+            self.out = torch.empty(self.total, self.width, dtype=dtype, device=self.device)
+            handle = self.out.untyped_storage()._share_cuda_()
+            handles = [None] * self.world
+            dist.all_gather_object(handles, handle, group=self.sync_group)
+            self.peers = []
+            for r, h in enumerate(handles):
+                if r == self.rank:
+                    self.peers.append(self.out)
+                    continue
+                st = torch.UntypedStorage._new_shared_cuda(*h)
+                self.peers.append(torch.empty(0, dtype=dtype, device=st.device).set_(st, 0, (self.total, self.width)))
+            self.copy_stream = torch.cuda.Stream(self.device)
+            self.events = [torch.cuda.Event(interprocess=True) for _ in range(2)]
+            ev_handles = [None] * self.world
+            dist.all_gather_object(ev_handles, [e.ipc_handle() for e in self.events], group=self.sync_group)
+            self.peer_events = [None if r == self.rank else
+                                [torch.cuda.Event.from_ipc_handle(self.device, hh) for hh in ev_handles[r]]
+                                for r in range(self.world)]
+        else:
+            import os
+            import tempfile
+            nbytes = self.total * self.width
+            base = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir(), f"{tag}_{os.getppid()}")
+            mine = f"{base}_{self.rank}"
+            self.out = torch.from_file(mine, shared=True, size=nbytes, dtype=dtype).view(self.total, self.width)
+            self._files.append(mine)
+            dist.barrier(group=self.sync_group)  # every file exists
+            self.peers = [self.out if r == self.rank else
+                          torch.from_file(f"{base}_{r}", shared=True, size=nbytes, dtype=dtype).view(self.total, self.width)
+                          for r in range(self.world)]
+
+    def gather(self, obs):
+        """Store `obs` [n_r, width] into rows [offset_r, offset_r + n_r) of every rank's buffer and return
+        this rank's full [total, width] buffer once all peers' blocks have arrived (stream-ordered on GPUs)."""
+        lo, n = self.offsets[self.rank], self.sizes[self.rank]
+        assert obs.shape == (n, self.width), (tuple(obs.shape), n, self.width)
+        if self.device.type == "cuda":
+            cur = torch.cuda.current_stream(self.device)
+            j = self._step & 1
+            self.copy_stream.wait_stream(cur)  # the step that produced `obs`
+            with torch.cuda.stream(self.copy_stream):
+                for k in range(self.world):  # start with the next rank so that the G ranks do not all hit one target
+                    r = (self.rank + k) % self.world
+                    self.peers[r][lo:lo + n].copy_(obs, non_blocking=True)
+                self.events[j].record(self.copy_stream)
+            dist.barrier(group=self.sync_group)  # every rank has ENQUEUED its record (host only, no device sync)
+            cur.wait_event(self.events[j])
+            for r in range(self.world):
+                if r != self.rank:
+                    cur.wait_event(self.peer_events[r][j])
+        else:
+            for r in range(self.world):
+                self.peers[r][lo:lo + n].copy_(obs)
+            dist.barrier(group=self.sync_group)
+        self._step += 1
+        return self.out
+
+    def release(self):
+        """Call on every rank before the buffers go away: no peer may still be writing into them."""
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        dist.barrier(group=self.sync_group)
+        self.peers = []
+        import os
+        for f in self._files:
+            try:
+                os.unlink(f)
+            except OSError:
+                pass
+        self._files = []
 
 
 def max_over_ranks(value, device):

@@ -30,3 +30,23 @@ def test_bench_json_line():
     assert abs(d["value"] - 65536 * 30 / (d["ms_per_step"] * 30e-3)) < 1e-6 * d["value"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and c["value_1_thread"] > 0
+    assert "65536 envs" in c["sample"]  # timed at the GPU run's N
+    assert 0 < r["frac_wall"] <= r["frac"] * 1.05
+
+
+def test_bench_multi_rank_code_path_on_one_gpu():
+    """`bench.py --gpus 2` under torch.distributed.run, both ranks on cuda:0 (--same-device, gloo control
+    plane): the sharded launch, the max-over-ranks timing, per-rank times and the P2P-store observation
+    gather run end to end; the figures of such a run are meaningless and not checked."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29733", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "4",
+           "--envs-per-gpu", "65536", "--same-device", "--allgather-obs", "p2p"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and len(d["per_rank_ms_per_step"]) == 2 and d["allgather_ms"] > 0
+    assert "cpu_baseline" not in d and "p2p" in d["config"]["parallelism"]
+    assert abs(d["value"] - 2 * 65536 * 20 / (d["ms_per_step"] * 20e-3)) < 1e-6 * d["value"]

@@ -219,6 +219,8 @@ def test_closed_loop_short_horizon(scen):
     ("hover", {}), ("circle", dict(use_motor_dynamics=True, domain_randomization=0.1)),
     ("takeoff", dict(use_ground_effect=True)), ("hover", dict(domain_randomization=0.1)),
     ("circle", dict(aggregate_phy_steps=2)),
+    ("hover", dict(use_latency=True, latency=0.035, use_motor_dynamics=True)),  # action-buffer rows from Philox blocks 9..
+    ("circle", dict(use_latency=True, latency=0.015, domain_randomization=0.1)),
 ])
 def test_lockstep_autoreset_vs_f32_oracle(task, kw):
     """In-kernel Philox reset + auto-reset + TimeLimit, draw for draw against the float32 oracle on

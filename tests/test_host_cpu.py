@@ -123,6 +123,15 @@ obs = (torch.arange(a, b, dtype=torch.float32)[:, None] * 100 + torch.arange(D, 
 full = pds.all_gather_obs(obs)
 want = (torch.arange(total, dtype=torch.float32)[:, None] * 100 + torch.arange(D, dtype=torch.float32)[None])
 assert full.shape == (total, D) and torch.equal(full, want), rank
+full2 = pds.all_gather_obs(obs)  # shard sizes come from the cache now: no size exchange on the second call
+assert torch.equal(full2, want)
+# the peer-to-peer STORE variant (SURVEY 8e): same result, ordered by global env id, over several steps
+gat = pds.P2PObsGather(b - a, D, "cpu")
+for step in range(3):
+    got = gat.gather(obs + step)
+    assert got.shape == (total, D) and torch.equal(got, want + step), (rank, step)
+    dist.barrier()  # (the test re-reads `got` above before the peers overwrite it in the next step)
+gat.release()
 from phoenix_drone_simulation_amd.sharding import max_over_ranks
 assert max_over_ranks(float(rank + 1), torch.device("cpu")) == float(world)
 dist.barrier()
