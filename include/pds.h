@@ -151,8 +151,10 @@ enum pds_field {
  * u ~ U[0,1)) one env.step() consumes, in the reference's draw order restricted to the draws whose
  * value reaches the state or the observation (aggregate_phy_steps == 1):
  *   OUNoise.noise (envs/utils.py:106) | first add_noise call (envs/base.py:464, only its gyro part
- *   survives) | second add_noise call (envs/base.py:468 -> compute_history) */
-#define PDS_NOISE_FLOATS 37
+ *   survives at obs_rate 1) | second add_noise call (envs/base.py:468 -> compute_history) | the rest of the
+ *   first call.  With obs_rate > 1 a call at an iteration that is not a multiple of obs_rate only draws the
+ *   gyro part (add_noise_to_omega, envs/sensors.py:121-134); the unused entries are ignored. */
+#define PDS_NOISE_FLOATS 52
 #define PDS_N_OU 0        /* 4 z */
 #define PDS_N_A_BIAS 4    /* 3 z  gyro bias random walk   (envs/sensors.py:130) */
 #define PDS_N_A_RW 7      /* 3 z  gyro_random_walk term   (envs/sensors.py:133) */
@@ -166,6 +168,13 @@ enum pds_field {
 #define PDS_N_OBS_TO 15    /* 3 z */
 #define PDS_N_OBS_TH_Z 18  /* 3 z */
 #define PDS_N_OBS_TH_U 21  /* 3 u */
+/* position / velocity / angle draws of the FIRST call: they reach the observation only through the held
+ * "Kalman" state when obs_rate = sim_freq // observation_frequency > 1 (envs/hover.py:134-156) */
+#define PDS_N_A_POS_Z 37  /* 3 z */
+#define PDS_N_A_POS_U 40  /* 3 u */
+#define PDS_N_A_VEL_Z 43  /* 3 z */
+#define PDS_N_A_TH_Z 46   /* 3 z */
+#define PDS_N_A_TH_U 49   /* 3 u */
 
 int pds_version(void);
 

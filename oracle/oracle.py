@@ -38,6 +38,7 @@ class Config(C.Structure):
         ("target_pos", C.c_double * 3), ("init_xyz", C.c_double * 3),
         ("init_rpy", C.c_double * 3), ("init_xyz_dot", C.c_double * 3), ("init_rpy_dot", C.c_double * 3),
         ("control_mode", C.c_int32), ("use_latency", C.c_int32), ("latency", C.c_double),
+        ("ref_points", C.c_int32), ("pad3_", C.c_int32),
     ]
 
 
@@ -126,6 +127,12 @@ def default_config(task, **overrides):
             c.observation_noise = 1 if v > 0 else 0
         elif k == "use_latency":
             c.use_latency = int(bool(v))
+        elif k == "observation_frequency":
+            # obs_rate = sim_freq // observation_frequency (envs/base.py:108), sim_freq = 100 on the Simple envs
+            # (envs/hover.py:262); Circle: num_ref_points = 3 * observation_frequency (envs/circle.py:49)
+            c.obs_rate = int(100 // int(v))
+            if c.task == TASK_CIRCLE:
+                c.ref_points = 3 * int(v)
         elif k == "control_mode":
             c.control_mode = {"PWM": 0, "AttitudeRate": 1, "Attitude": 2}[v] if isinstance(v, str) else int(v)
         else:

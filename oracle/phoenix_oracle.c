@@ -105,6 +105,7 @@ void po_default_config(int task, po_config *c) {
   c->init_xyz[2] = (task == PO_TASK_TAKEOFF) ? (double)0.0125f : 1.0; /* float32 literal, takeoff.py:51 */
   c->use_latency = 0;  /* CrazyFlieSimpleAgent passes use_latency=False, agents.py:492 */
   c->latency = 0.015;  /* envs/base.py:40 */
+  c->ref_points = 300; /* 3 s * observation_frequency (100), circle.py:47-49; TakeOff: 300 fixed, takeoff.py:43 */
 }
 
 /* Philox4x32-10 (Salmon et al., SC'11).  This is the in-kernel RNG of the NEW framework (the
@@ -461,8 +462,8 @@ static void sensor_add_noise(ENV *e, REAL dt, po_rng *rng, REAL pos[3], REAL vel
  * reference tables circle.py:45-56 (300 points, radius .25), takeoff.py:43-47 (z = k/300). */
 static void update_target(const po_config *c, ENV *e) {
   if (c->task == PO_TASK_CIRCLE) {
-    int t = (e->iteration / c->aggregate_phy_steps + e->ref_offset) % 300;
-    double ts = 2 * PO_PI * (double)t / 300;
+    int t = (e->iteration / c->aggregate_phy_steps + e->ref_offset) % c->ref_points;
+    double ts = 2 * PO_PI * (double)t / c->ref_points;
     e->target_pos[0] = (REAL)(0.25 * (1 - cos(ts)));
     e->target_pos[1] = (REAL)(0.25 * sin(ts));
     e->target_pos[2] = (REAL)1.;
@@ -656,7 +657,7 @@ void SUF(po_reset)(const po_config *c, ENV *e, const po_reset_sample *s, po_rng 
       for (int i = 0; i < 3; ++i) w_s[i] = (i < 2) ? w_s[i] + (REAL)s->omega[i] : (REAL)s->omega[i]; /* :216-217 */
     } else if (c->task == PO_TASK_CIRCLE) {
       e->ref_offset = s->ref_offset;                               /* circle.py:225 */
-      double ts = 2 * PO_PI * (double)s->ref_offset / 300;
+      double ts = 2 * PO_PI * (double)s->ref_offset / c->ref_points;
       e->target_pos[0] = (REAL)(0.25 * (1 - cos(ts)));
       e->target_pos[1] = (REAL)(0.25 * sin(ts));
       e->target_pos[2] = (REAL)1.;
@@ -805,7 +806,7 @@ void SUF(po_philox_reset_sample)(const po_config *c, uint64_t seed, uint64_t env
   s->dr_J[2] = DRV(r[6][0], k.IZZ);
   s->dr_ftf0 = DRV(r[6][1], k.FORCE_TORQUE_FACTOR_0);
   s->dr_ftf1 = DRV(r[6][2], k.FORCE_TORQUE_FACTOR_1);
-  s->ref_offset = (int32_t)(((uint64_t)r[6][3] * 300u) >> 32);
+  s->ref_offset = (int32_t)(((uint64_t)r[6][3] * (uint32_t)c->ref_points) >> 32);
   for (int i = 0; i < 4; ++i) s->dr_T[i] = DRV(r[7][i], c->motor_time_constant);
   for (int i = 0; i < 4; ++i) s->dr_t2w[i] = DRV(r[8][i], k.THRUST2WEIGHT_RATIO);
 #undef DRV
@@ -834,6 +835,7 @@ void SUF(po_philox_reset_sample)(const po_config *c, uint64_t seed, uint64_t env
 #define PO_BLK_RESET_NOISE 32u
 #define PO_BLK_OBS_NOISE 64u
 #define PO_BLK_SUB_NOISE 128u
+#define PO_BLK_SUB_NOISE_X 256u
 
 static void philox_words(uint64_t seed, uint64_t env_id, uint64_t tick, uint32_t blk0, int nblk, uint32_t *w) {
   uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
@@ -859,12 +861,15 @@ static void obs_call_streams(uint64_t seed, uint64_t env_id, uint64_t tick, uint
   u[7] = (double)u01_lo16(w[11]); u[8] = (double)u01_hi16(w[11]);
 }
 
-/* streams of one env.step() (aggregate_phy_steps sub-steps): per sub-step OU z4 + discarded call
- * (z24, u9); then the observing call (z24, u9) */
-static void step_streams(const po_config *c, uint64_t seed, uint64_t env_id, uint64_t tick, double *z, double *u,
-                         int *nz, int *nu) {
+/* streams of one env.step() (aggregate_phy_steps sub-steps): per sub-step OU z4 + discarded call, then
+ * the observing call.  A call at an iteration that is a multiple of obs_rate is a full add_noise
+ * (z24, u9); otherwise only add_noise_to_omega draws (z9) -- envs/hover.py:134-156.  `iteration` is
+ * the env's iteration counter before the step. */
+static void step_streams(const po_config *c, uint64_t seed, uint64_t env_id, uint64_t tick, int iteration, double *z,
+                         double *u, int *nz, int *nu) {
   int iz = 0, iu = 0;
   const int on = c->observation_noise > 0;
+  const int R = c->obs_rate > 0 ? c->obs_rate : 1;
   for (int sub = 0; sub < c->aggregate_phy_steps; ++sub) {
     uint32_t w[8];
     philox_words(seed, env_id, tick, PO_BLK_SUB_NOISE + 2u * (uint32_t)sub, on ? 2 : 1, w);
@@ -875,15 +880,39 @@ static void step_streams(const po_config *c, uint64_t seed, uint64_t env_id, uin
     if (on) for (int p = 2; p < 7; ++p) box_muller_word(w[p], &n[2 * p], &n[2 * p + 1]);
     for (int i = 0; i < 4; ++i) z[iz++] = (double)n[i];             /* OUNoise randn(4) */
     if (on) {
-      for (int i = 0; i < 6; ++i) z[iz++] = 0;                      /* pos, vel (discarded) */
-      for (int i = 0; i < 9; ++i) z[iz++] = (double)n[4 + i];       /* bias, rw, turn-on */
-      for (int i = 0; i < 9; ++i) z[iz++] = 0;                      /* theta, acc (discarded) */
-      for (int i = 0; i < 9; ++i) u[iu++] = 0.5;
+      const int fresh = ((iteration + sub) % R) == 0;
+      if (R == 1) {
+        for (int i = 0; i < 6; ++i) z[iz++] = 0;                    /* pos, vel (discarded) */
+        for (int i = 0; i < 9; ++i) z[iz++] = (double)n[4 + i];     /* bias, rw, turn-on */
+        for (int i = 0; i < 9; ++i) z[iz++] = 0;                    /* theta, acc (discarded) */
+        for (int i = 0; i < 9; ++i) u[iu++] = 0.5;
+      } else if (fresh) {  /* the call refreshes the held state: its position / velocity / angle draws count */
+        uint32_t x[8];
+        philox_words(seed, env_id, tick, PO_BLK_SUB_NOISE_X + 2u * (uint32_t)sub, 2, x);
+        REAL y[10];
+        for (int p = 0; p < 5; ++p) box_muller_word(x[p], &y[2 * p], &y[2 * p + 1]);
+        for (int i = 0; i < 6; ++i) z[iz++] = (double)y[i];         /* pos3, vel3 */
+        for (int i = 0; i < 9; ++i) z[iz++] = (double)n[4 + i];     /* bias, rw, turn-on */
+        for (int i = 0; i < 3; ++i) z[iz++] = (double)y[6 + i];     /* theta3 */
+        for (int i = 0; i < 6; ++i) z[iz++] = 0;                    /* acc (unused) */
+        u[iu++] = (double)u01_lo16(x[5]); u[iu++] = (double)u01_hi16(x[5]); u[iu++] = (double)u01_lo16(x[6]); /* pos */
+        for (int i = 0; i < 3; ++i) u[iu++] = 0.5;                  /* vel (range 0) */
+        u[iu++] = (double)u01_hi16(x[6]); u[iu++] = (double)u01_lo16(x[7]); u[iu++] = (double)u01_hi16(x[7]); /* theta */
+      } else {
+        for (int i = 0; i < 9; ++i) z[iz++] = (double)n[4 + i];     /* add_noise_to_omega only */
+      }
     }
   }
   if (on) {
-    obs_call_streams(seed, env_id, tick, PO_BLK_OBS_NOISE, z + iz, u + iu);
-    iz += 24; iu += 9;
+    const int fresh = ((iteration + c->aggregate_phy_steps) % R) == 0;
+    double zz[24], uu[9];
+    obs_call_streams(seed, env_id, tick, PO_BLK_OBS_NOISE, zz, uu);
+    if (fresh) {
+      for (int i = 0; i < 24; ++i) z[iz++] = zz[i];
+      for (int i = 0; i < 9; ++i) u[iu++] = uu[i];
+    } else {
+      for (int i = 0; i < 9; ++i) z[iz++] = zz[6 + i];              /* bias, rw, turn-on of that call */
+    }
   }
   *nz = iz; *nu = iu;
 }
@@ -941,11 +970,11 @@ void SUF(po_step_batch)(const po_config *c, ENV *envs, int64_t n, const REAL *ac
 #endif
   for (int64_t i = 0; i < n; ++i) {
     int32_t term, trunc;
-    double z[4 * 28 + 24], u[4 * 9 + 9];
+    double z[64 * 28 + 24], u[64 * 9 + 9]; /* aggregate_phy_steps <= 64 */
     po_rng rng = {z, u, 0, 0, 0, 0};
     if (c->observation_noise > 0 || c->motor_thrust_noise > 0) {
       int nz = 0, nu = 0;
-      step_streams(c, seed, (uint64_t)i, tick, z, u, &nz, &nu);
+      step_streams(c, seed, (uint64_t)i, tick, envs[i].iteration, z, u, &nz, &nu);
       rng.nz = nz; rng.nu = nu;
     }
     SUF(po_step)(c, &envs[i], actions + 4 * i, &rng, obs + i * D, &reward[i], &term, &trunc, &cost[i]);

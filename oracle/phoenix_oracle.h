@@ -56,6 +56,8 @@ typedef struct po_config {
   int32_t control_mode;              /* 0 PWM, 1 AttitudeRate, 2 Attitude (envs/control.py:91-287) */
   int32_t use_latency;               /* CrazyFlieAgent(use_latency=...), envs/agents.py:125,165; Simple agent: False (:492) */
   double latency;                    /* [s] envs/base.py:40; buf_size = max(1, int(latency // time_step)), agents.py:180 */
+  int32_t ref_points;                /* Circle: num_ref_points = circle_time (3 s) * observation_frequency, circle.py:47-49 */
+  int32_t pad3_;
 } po_config;
 
 /* Values drawn by one reset() in the reference's draw order (the *sampled values*, i.e. what

@@ -480,6 +480,14 @@ def main():
     lat_scen("circle_rate_lat2", "circle", dict(DET, control_mode="AttitudeRate", latency=0.02), 8, 8, pid_act, 306)
     lat_scen("hover_setlat4", "hover", dict(DET), 8, 8, act_random(0.3), 307, set_latency=0.045, latency_on=False)  # int(.045/.01) = 4
     lat_scen("hover_lat2_defaults", "hover", dict(latency=0.025), 8, 8, act_random(0.2), 308)           # noise + DR + latency
+    # observation_frequency != 100: obs_rate = 100 // f > 1 takes the Kalman-hold branch of compute_observation
+    # (hover.py:150-156 and the circle / takeoff equivalents); Circle sizes its reference from it (circle.py:47-49)
+    scen.append(("hover_obsf50", "hover", dict(observation_frequency=50, domain_randomization=-1), 8, 10, act_random(0.2), 320, False, None, False))
+    scen.append(("hover_obsf50_agg2_defaults", "hover", dict(observation_frequency=50, aggregate_phy_steps=2), 8, 8, act_random(0.2), 321, False, None, False))
+    scen.append(("circle_obsf50", "circle", dict(observation_frequency=50, domain_randomization=-1), 8, 10, act_random(0.2), 322, False, None, False))
+    scen.append(("takeoff_obsf25", "takeoff", dict(observation_frequency=25, domain_randomization=-1), 6, 10, act_random(0.2, center=0.2), 323, False, None, False))
+    scen.append(("circle_obsf50_det", "circle", dict(DET, observation_frequency=50), 8, 10, act_random(0.3), 324, False, None, False))
+    scen.append(("hover_obsf33_agg3", "hover", dict(observation_frequency=33, aggregate_phy_steps=3, domain_randomization=-1), 6, 8, act_random(0.2), 325, False, None, False))
 
     only = set(args.only.split(",")) if args.only else None
     index = {}

@@ -355,6 +355,11 @@ static void fill_consts(const pds_config &c, Consts &k) {
   k.agg = c.aggregate_phy_steps; k.max_steps = c.max_episode_steps;
   k.reset_dist = c.enable_reset_distribution ? 1 : 0;
   k.ref_points = (c.task == PDS_TASK_CIRCLE) ? 3 * c.observation_frequency : kRefPoints;  // envs/circle.py:47-49
+  k.obs_rate = 1;
+  if (c.observation_noise > 0) {  // obs_rate = sim_freq // observation_frequency, envs/base.py:108
+    const int r = (int)llround(1.0 / c.time_step) / c.observation_frequency;
+    k.obs_rate = r < 1 ? 1 : r;
+  }
   set_latency_consts(k, c.use_latency ? latency_steps_ctor(c.latency, c.time_step) : 0, c.aggregate_phy_steps);
 }
 
@@ -424,8 +429,6 @@ extern "C" int pds_create(const pds_config *cfg, pds_handle **out) {
     const int sim_freq = (int)llround(1.0 / cfg->time_step);
     const int obs_rate = sim_freq / cfg->observation_frequency;
     if (obs_rate < 1) PDS_CREATE_FAIL(PDS_EINVAL, "observation_frequency %d above sim_freq %d: obs_rate 0 (the reference divides by it)", cfg->observation_frequency, sim_freq);
-    if (obs_rate != 1)
-      PDS_CREATE_FAIL(PDS_EUNSUPPORTED, "observation noise with obs_rate %d != 1 (Kalman-hold branch of compute_observation) is not built", obs_rate);
   }
   const int lat_steps = cfg->use_latency ? latency_steps_ctor(cfg->latency, cfg->time_step) : 0;
   if (lat_steps > kMaxLatSteps) PDS_CREATE_FAIL(PDS_EUNSUPPORTED, "latency %g s = %d steps (limit %d)", cfg->latency, lat_steps, kMaxLatSteps);

@@ -14,6 +14,7 @@ constexpr uint32_t kBlkLatRows = 9;      // 9..15  rows 0..6 of the latency acti
 constexpr uint32_t kBlkResetNoise = 32;  // 32..37 two add_noise calls inside reset (7 rounds)
 constexpr uint32_t kBlkObsNoise = 64;    // 64..66 the add_noise call that produces o(k+1) (7 rounds)
 constexpr uint32_t kBlkSubNoise = 128;   // 128+2*sub+{0,1}: OU + the discarded add_noise call (7 rounds)
+constexpr uint32_t kBlkSubNoiseX = 256;  // 256+2*sub+{0,1}: position / velocity / angle draws of that call (obs_rate > 1)
 
 // Where the Philox words of a reset come from: computed on the spot by the resetting thread
 // (explicit reset kernel), or read back from an LDS scratch that the whole wave filled

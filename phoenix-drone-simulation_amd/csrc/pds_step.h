@@ -243,6 +243,7 @@ PDS_DEV void control_pwm(float dt, const EnvRegs &e, const float av[4], PidState
 // add_noise call whose observation is discarded (envs/base.py:464): 9 z.
 struct SubNoise {
   float ou[4], bias_z[3], rw_z[3], to_z[3];
+  ObsNoise full;  // obs_rate > 1: the whole call (its gyro members alias the three above)
 };
 
 template <class V>
@@ -253,6 +254,14 @@ PDS_DEV void sub_noise(const StepArgs &a, const RngKey &rk, uint32_t env_id, lon
     for (int j = 0; j < 4; ++j) n.ou[j] = p[PDS_N_OU + j];
 #pragma unroll
     for (int j = 0; j < 3; ++j) { n.bias_z[j] = p[PDS_N_A_BIAS + j]; n.rw_z[j] = p[PDS_N_A_RW + j]; n.to_z[j] = p[PDS_N_A_TO + j]; }
+    if (V::ON && a.k.obs_rate != 1) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        n.full.pos_z[j] = p[PDS_N_A_POS_Z + j]; n.full.pos_u[j] = p[PDS_N_A_POS_U + j]; n.full.vel_z[j] = p[PDS_N_A_VEL_Z + j];
+        n.full.th_z[j] = p[PDS_N_A_TH_Z + j]; n.full.th_u[j] = p[PDS_N_A_TH_U + j];
+        n.full.bias_z[j] = n.bias_z[j]; n.full.rw_z[j] = n.rw_z[j]; n.full.to_z[j] = n.to_z[j];
+      }
+    }
     return;
   }
   // words 0,1 -> OU z[0..3]; words 2..6 -> bias, random walk, turn-on z[4..12] (one pair per word)
@@ -276,6 +285,25 @@ PDS_DEV void sub_noise(const StepArgs &a, const RngKey &rk, uint32_t env_id, lon
   for (int j = 0; j < 4; ++j) n.ou[j] = z[j];
 #pragma unroll
   for (int j = 0; j < 3; ++j) { n.bias_z[j] = z[4 + j]; n.rw_z[j] = z[7 + j]; n.to_z[j] = z[10 + j]; }
+  if (V::ON && a.k.obs_rate != 1) {  // wave-uniform: the held state may be refreshed by this call
+    const uint32_t bx = kBlkSubNoiseX + 2u * (uint32_t)sub;
+    const U4 x0 = philox4x32_7(env_id, rk.tick_lo, rk.tick_hi, bx, rk.seed_lo, rk.seed_hi);
+    const U4 x1 = philox4x32_7(env_id, rk.tick_lo, rk.tick_hi, bx + 1u, rk.seed_lo, rk.seed_hi);
+    float y[10];
+    box_muller_word(x0.x, y[0], y[1]);
+    box_muller_word(x0.y, y[2], y[3]);
+    box_muller_word(x0.z, y[4], y[5]);
+    box_muller_word(x0.w, y[6], y[7]);
+    box_muller_word(x1.x, y[8], y[9]);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      n.full.pos_z[j] = y[j]; n.full.vel_z[j] = y[3 + j]; n.full.th_z[j] = y[6 + j];
+      n.full.bias_z[j] = n.bias_z[j]; n.full.rw_z[j] = n.rw_z[j]; n.full.to_z[j] = n.to_z[j];
+    }
+    n.full.pos_u[0] = u01_lo16(x1.y); n.full.pos_u[1] = u01_hi16(x1.y);
+    n.full.pos_u[2] = u01_lo16(x1.z); n.full.th_u[0] = u01_hi16(x1.z);
+    n.full.th_u[1] = u01_lo16(x1.w); n.full.th_u[2] = u01_hi16(x1.w);
+  }
 }
 
 // How an env that finished is reset inside the step (all three produce the same bits):
@@ -373,6 +401,7 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
 
   // ---- aggregate_phy_steps x SimplePhysics.step_forward (envs/base.py:457-465) ---------------
   float *xm = S.xm;
+  NoisyObs held = S.oh;  // ON, obs_rate > 1: self.state[0:10] of the reference
   uint32_t lat_idx = ctr_lat(ctr);
   // divisions by the per-env mass / inertia become multiplications by v_rcp_f32 results (1 ulp)
   const float inv_m = fast_rcp(par.m), inv_Jx = fast_rcp(par.Jx), inv_Jy = fast_rcp(par.Jy), inv_Jz = fast_rcp(par.Jz);
@@ -446,7 +475,22 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
     e.pz = fmaxf(e.pz, 0.f);                                                             // :182
     // envs/base.py:464: compute_observation() whose result is dropped still advances the gyro
     // bias random walk and the low-pass filter
-    if (V::ON) gyro_update(k, e, sn.bias_z, sn.rw_z, sn.to_z, ns);
+    if (V::ON) {
+      if (k.obs_rate == 1) {
+        gyro_update(k, e, sn.bias_z, sn.rw_z, sn.to_z, ns);
+      } else {
+        // ... and, at an iteration that is a multiple of obs_rate, refreshes the held position / attitude /
+        // velocity that later calls re-use (envs/hover.py:134-156)
+        const int it = step * k.agg + sub;
+        const bool fresh = (it % k.obs_rate) == 0;
+        NoisyObs cand;
+        sensor_observe(k, e, sn.full, ns, cand);  // (its gyro part == gyro_update with the same variates)
+        held.x = fresh ? cand.x : held.x; held.y = fresh ? cand.y : held.y; held.z = fresh ? cand.z : held.z;
+        held.qx = fresh ? cand.qx : held.qx; held.qy = fresh ? cand.qy : held.qy; held.qz = fresh ? cand.qz : held.qz;
+        held.qw = fresh ? cand.qw : held.qw;
+        held.vx = fresh ? cand.vx : held.vx; held.vy = fresh ? cand.vy : held.vy; held.vz = fresh ? cand.vz : held.vz;
+      }
+    }
   }
   PDS_STAMP(3);
 
@@ -505,6 +549,13 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
     if (a.noise != nullptr) obs_noise_load(a.noise + ii * PDS_NOISE_FLOATS + PDS_N_OBS, n);
     else obs_noise_philox(env_id, rk, kBlkObsNoise, n);
     sensor_observe(k, e, n, ns, S.oh);
+    if (k.obs_rate != 1) {  // wave-uniform; per env: fresh observation or the held one + the fresh gyro
+      const bool fresh = (((step + 1) * k.agg) % k.obs_rate) == 0;
+      S.oh.x = fresh ? S.oh.x : held.x; S.oh.y = fresh ? S.oh.y : held.y; S.oh.z = fresh ? S.oh.z : held.z;
+      S.oh.qx = fresh ? S.oh.qx : held.qx; S.oh.qy = fresh ? S.oh.qy : held.qy; S.oh.qz = fresh ? S.oh.qz : held.qz;
+      S.oh.qw = fresh ? S.oh.qw : held.qw;
+      S.oh.vx = fresh ? S.oh.vx : held.vx; S.oh.vy = fresh ? S.oh.vy : held.vy; S.oh.vz = fresh ? S.oh.vz : held.vz;
+    }
     write_noisy_half<TASK>(row + O + 4, S.oh, ns.lpf, act, tx, ty, tz, pa2);
   } else {
     write_obs_half<TASK>(row + O + 4, e, q, act, tx, ty, tz, pa2);

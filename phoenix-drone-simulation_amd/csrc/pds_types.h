@@ -101,6 +101,7 @@ struct Consts {
   int lat_steps;   // buf_size of the latency ring (0: use_latency False)
   int lat_own1, lat_own2;  // step whose action action_buffer[-1] holds after env.step 1 / 2 (0: still the reset row)
   int ref_points;  // Circle: circle_time * observation_frequency (envs/circle.py:49), <= kRefPoints
+  int obs_rate;    // sim_freq // observation_frequency (envs/base.py:108); > 1: Kalman-hold branch of compute_observation
 };
 
 struct StepArgs {

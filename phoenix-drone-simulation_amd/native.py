@@ -12,7 +12,7 @@ TASK_HOVER, TASK_CIRCLE, TASK_TAKEOFF = 0, 1, 2
 OK, EINVAL, ENODEVICE, EHIP, ENOMEM, EUNSUPPORTED = 0, -1, -2, -3, -4, -5
 SAMPLE_FLOATS = 112
 MAX_LATENCY_STEPS = 8
-NOISE_FLOATS = 37
+NOISE_FLOATS = 52
 # field ids (enum pds_field)
 FIELDS = dict(pos=0, rpy=1, vel=2, omega=3, quat=4, motor_x=5, last_action=6, prev_action=7,
               step_count=8, quat_sign=9, ref_offset=10, params=11, motor_A=12, motor_K=13, ou=14,
@@ -27,7 +27,7 @@ SAMPLE_LAYOUT = dict(pos_offset=(0, 3), rpy=(3, 3), vel=(6, 3), omega=(9, 3), mo
 # one add_noise call (PDS_N_OBS_*): offsets inside its 24 floats
 OBS_NOISE_LAYOUT = dict(pos_z=0, pos_u=3, vel_z=6, bias_z=9, rw_z=12, to_z=15, th_z=18, th_u=21)
 # step noise row (PDS_N_*)
-STEP_NOISE_LAYOUT = dict(ou=0, a_bias=4, a_rw=7, a_to=10, obs=13)
+STEP_NOISE_LAYOUT = dict(ou=0, a_bias=4, a_rw=7, a_to=10, obs=13, a_pos_z=37, a_pos_u=40, a_vel_z=43, a_th_z=46, a_th_u=49)
 
 EXPORTS = ["pds_version", "pds_default_config", "pds_create", "pds_destroy", "pds_obs_dim",
            "pds_num_envs", "pds_reset", "pds_reset_from_samples", "pds_step", "pds_step_with_variates",

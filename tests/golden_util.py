@@ -124,18 +124,49 @@ def reset_noise_variates(g, ep):
     return np.concatenate([_obs_call_variates(z[0:24], u[0:9]), _obs_call_variates(z[24:48], u[9:18])])
 
 
+def obs_rate(g):
+    """sim_freq // observation_frequency (envs/base.py:108; sim_freq = 100 on the Simple envs)."""
+    return int(100 // int(g.kwargs.get("observation_frequency", 100)))
+
+
+def _stream_offsets(g, t):
+    """(z, u) offsets of env.step() number t (aggregate_phy_steps == 1) inside the episode's recorded streams,
+    and which of its two add_noise calls are full ones: a call at an iteration that is not a multiple of
+    obs_rate only draws the 9 gyro normals (envs/hover.py:134-156)."""
+    R = obs_rate(g)
+    zs, us = 2 * Z_CALL, 2 * U_CALL  # reset(): two full calls at iteration 0
+    for k in range(t):
+        for it in (k, k + 1):
+            full = (it % R) == 0
+            zs += Z_CALL if full else 9
+            us += U_CALL if full else 0
+        zs += 4  # OUNoise
+    return zs, us, (t % R) == 0, ((t + 1) % R) == 0
+
+
 def step_noise_variates(g, ep, t):
-    """[37]: OU z4 | gyro part of the discarded call (bias3 rw3 to3) | the observing call (24)."""
+    """[52]: OU z4 | gyro part of the first call (bias3 rw3 to3) | the observing call (24) | position /
+    velocity / angle draws of the first call (pos_z3 pos_u3 vel_z3 th_z3 th_u3; they matter when obs_rate > 1)."""
     z, u = episode_streams(g, ep)
-    out = np.zeros(37)
+    out = np.zeros(52)
     if noisy(g):
-        zs, us = 2 * Z_CALL + t * (4 + 2 * Z_CALL), 2 * U_CALL + t * 2 * U_CALL
+        assert int(g.kwargs.get("aggregate_phy_steps", 1)) == 1
+        zs, us, full_a, full_b = _stream_offsets(g, t)
         out[0:4] = z[zs:zs + 4]
-        za = z[zs + 4:zs + 4 + Z_CALL]
-        out[4:13] = za[6:15]
-        zb = z[zs + 4 + Z_CALL:zs + 4 + 2 * Z_CALL]
-        ub = u[us + U_CALL:us + 2 * U_CALL]
-        out[13:37] = _obs_call_variates(zb, ub)
+        zs += 4
+        if full_a:
+            za, ua = z[zs:zs + Z_CALL], u[us:us + U_CALL]
+            out[4:13] = za[6:15]
+            out[37:40], out[40:43], out[43:46] = za[0:3], ua[0:3], za[3:6]
+            out[46:49], out[49:52] = za[15:18], ua[6:9]
+            zs += Z_CALL; us += U_CALL
+        else:
+            out[4:13] = z[zs:zs + 9]
+            zs += 9
+        if full_b:
+            out[13:37] = _obs_call_variates(z[zs:zs + Z_CALL], u[us:us + U_CALL])
+        else:
+            out[13 + 9:13 + 18] = z[zs:zs + 9]  # bias, random walk, turn-on of add_noise_to_omega
     else:
         out[0:4] = z[4 * t:4 * t + 4]
     return out

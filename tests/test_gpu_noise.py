@@ -15,7 +15,12 @@ from test_gpu_parity import ENV_ID, RTOL, ATOL, _make, _inject, _samples_from_go
 
 pytestmark = pytest.mark.gpu
 
-NOISE_SCENARIOS = [n for n in gu.scenario_names() if any(s in n for s in ("defaults", "noise_only"))]
+def _is_noisy(n):
+    return gu.noisy(gu.Golden(n)) and "det" not in n
+
+
+# every scenario with observation noise; the injected-variate interface covers aggregate_phy_steps == 1
+NOISE_SCENARIOS = [n for n in gu.scenario_names() if _is_noisy(n) and int(gu.Golden(n).kwargs.get("aggregate_phy_steps", 1)) == 1]
 
 
 def _inject_noise_state(env, ou, bias, lpf, noisy_obs10):

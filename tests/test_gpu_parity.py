@@ -15,8 +15,7 @@ pytestmark = pytest.mark.gpu
 
 RTOL, ATOL = 1e-6, 2e-6
 
-DET_SCENARIOS = [n for n in gu.scenario_names()
-                 if not any(s in n for s in ("defaults", "noise_only"))]
+DET_SCENARIOS = [n for n in gu.scenario_names() if not gu.noisy(gu.Golden(n))]
 
 ENV_ID = {"hover": "DroneHoverSimpleEnv-v0", "circle": "DroneCircleSimpleEnv-v0",
           "takeoff": "DroneTakeOffSimpleEnv-v0"}
@@ -221,6 +220,11 @@ def test_closed_loop_short_horizon(scen):
     ("circle", dict(aggregate_phy_steps=2)),
     ("hover", dict(use_latency=True, latency=0.035, use_motor_dynamics=True)),  # action-buffer rows from Philox blocks 9..
     ("circle", dict(use_latency=True, latency=0.015, domain_randomization=0.1)),
+    # obs_rate = 100 // observation_frequency > 1: Kalman-hold branch of compute_observation, Philox streams
+    ("hover", dict(observation_noise=1, observation_frequency=50)),
+    ("hover", dict(observation_noise=1, observation_frequency=33, aggregate_phy_steps=3, motor_thrust_noise=0.05)),
+    ("circle", dict(observation_noise=1, observation_frequency=50, domain_randomization=0.1)),
+    ("circle", dict(observation_frequency=50)),  # noise-free: 150 reference points instead of 300 (circle.py:47-49)
 ])
 def test_lockstep_autoreset_vs_f32_oracle(task, kw):
     """In-kernel Philox reset + auto-reset + TimeLimit, draw for draw against the float32 oracle on
