@@ -16,22 +16,63 @@
 
 namespace pds {
 
+// Row stride of the per-wave LDS observation tile.  The lanes write their rows side by side, so the
+// lane-to-lane stride decides the bank pattern of those writes (ds_write*: bank = (addr / 4) mod 32):
+// D = 42 / 34 (Hover) is conflict-free for the 8-byte writes the compiler emits, but D = 40 (Circle) and
+// D = 48 (TakeOff) put 8 / 16 lanes of every 32 on the same bank (SQ_LDS_BANK_CONFLICT 230-400 and
+// 860-1100 cycles per wave, profiles/r02_pmc_sq_configs_round1_kernels.txt).  Those rows (D % 8 == 0: both
+// halves 16-byte aligned) are therefore written as float4 (ds_write_b128: groups of 8 lanes) with the stride
+// padded to D + 4 floats, an odd multiple of 16 B: 8 consecutive lanes then cover all 32 banks exactly once.
+template <int D>
+constexpr int tile_stride() {
+  return (D % 8 == 0) ? D + 4 : D;
+}
+
+template <int N>
+PDS_DEV void lds_store_row(float *dst, const float *src) {  // dst 16-byte aligned
+  static_assert(N % 4 == 0, "float4 rows");
+#pragma unroll
+  for (int j = 0; j < N / 4; ++j)
+    reinterpret_cast<float4 *>(dst)[j] = make_float4(src[4 * j], src[4 * j + 1], src[4 * j + 2], src[4 * j + 3]);
+}
+
 // Wave-cooperative copy of this wave's [rows, D] LDS tile to global memory (contiguous region).
 template <int D, int TR>
 PDS_DEV void flush_tile(const float *tile, float *gdst, int rows, int lane) {
+  constexpr int TS = tile_stride<D>();
   // (an [N, D] slice of a [K, N, D] tensor is only 8-byte aligned when N D is not a multiple of 4)
-  if (rows == TR && (reinterpret_cast<uintptr_t>(gdst) & 15u) == 0) {  // wave-uniform
-    constexpr int NV = TR * D / 4;  // float4 count (D is even, 32*D divisible by 4)
-    const float4 *src = reinterpret_cast<const float4 *>(tile);
-    float4 *dst = reinterpret_cast<float4 *>(gdst);
+  const bool fast = rows == TR && (reinterpret_cast<uintptr_t>(gdst) & 15u) == 0;  // wave-uniform
+  if constexpr (TS == D) {
+    if (fast) {
+      constexpr int NV = TR * D / 4;  // float4 count (D is even, 32*D divisible by 4)
+      const float4 *src = reinterpret_cast<const float4 *>(tile);
+      float4 *dst = reinterpret_cast<float4 *>(gdst);
 #pragma unroll
-    for (int it = 0; it < (NV + kWave - 1) / kWave; ++it) {
-      const int idx = it * kWave + lane;
-      if (idx < NV) nt_store4(dst + idx, src[idx]);
+      for (int it = 0; it < (NV + kWave - 1) / kWave; ++it) {
+        const int idx = it * kWave + lane;
+        if (idx < NV) nt_store4(dst + idx, src[idx]);
+      }
+      return;
     }
   } else {
-    const int n = rows * D;
-    for (int idx = lane; idx < n; idx += kWave) gdst[idx] = tile[idx];
+    if (fast) {
+      // padded rows: Q float4 per row, RP whole rows per pass (6 x 10 or 5 x 12 lanes); the region a pass
+      // stores is still contiguous in the [N, D] tensor (rows follow each other without padding there)
+      constexpr int Q = D / 4, RP = kWave / Q, NP = (TR + RP - 1) / RP;
+      const int r0 = lane / Q, c = lane - r0 * Q;
+      const float4 *src = reinterpret_cast<const float4 *>(tile + r0 * TS + 4 * c);
+      float4 *dst = reinterpret_cast<float4 *>(gdst) + r0 * Q + c;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        if (r0 < RP && p * RP + r0 < TR) nt_store4(dst + p * RP * Q, src[p * RP * (TS / 4)]);
+      }
+      return;
+    }
+  }
+  const int n = rows * D;
+  for (int idx = lane; idx < n; idx += kWave) {
+    const int r = idx / D;
+    gdst[idx] = tile[r * TS + (idx - r * D)];
   }
 }
 
@@ -239,6 +280,31 @@ PDS_DEV void control_pwm(float dt, const EnvRegs &e, const float av[4], PidState
   pwm[3] = clampf(thrust + r - p + y, 0.f, 60000.f);
 }
 
+// a row half into the LDS tile: scalar stores in place, or (padded float4 rows) built in registers
+// and stored as ds_write_b128
+template <int TASK, int N, bool VEC>
+PDS_DEV void put_obs_half(float *dst, const EnvRegs &e, const Quat &q, const float4 &la, float tx, float ty, float tz,
+                          const float4 &ha) {
+  if constexpr (VEC) {
+    float h[N];
+    write_obs_half<TASK>(h, e, q, la, tx, ty, tz, ha);
+    lds_store_row<N>(dst, h);
+  } else {
+    write_obs_half<TASK>(dst, e, q, la, tx, ty, tz, ha);
+  }
+}
+template <int TASK, int N, bool VEC>
+PDS_DEV void put_noisy_half(float *dst, const NoisyObs &o, const float lpf[3], const float4 &la, float tx, float ty,
+                            float tz, const float4 &ha) {
+  if constexpr (VEC) {
+    float h[N];
+    write_noisy_half<TASK>(h, o, lpf, la, tx, ty, tz, ha);
+    lds_store_row<N>(dst, h);
+  } else {
+    write_noisy_half<TASK>(dst, o, lpf, la, tx, ty, tz, ha);
+  }
+}
+
 // Standard variates of one physics sub-step: OUNoise.noise (4 z) and the gyro part of the
 // add_noise call whose observation is discarded (envs/base.py:464): 9 z.
 struct SubNoise {
@@ -348,13 +414,15 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
   constexpr int TASK = V::TASK;
   constexpr int D = V::D;
   constexpr int O = V::O;
+  constexpr int TS = tile_stride<D>();
+  constexpr bool VEC = (TS != D) && TR == kWave;  // padded rows written in place as float4 halves
   static_assert(RM != RM_MERGED || (!V::ON && !V::LAT), "merged reset: variants without observation noise / latency");
   static_assert(RM != RM_INLINE || TR == kWave, "inline reset: full tile only");
   static_assert(RM != RM_DEFERRED || STORE, "deferred drain: the state must be in HBM before it");
   const Consts &k = a.k;
   // full tile: the row is built in place in LDS; half tile: in registers, staged pass by pass
   float rowbuf[(TR == kWave) ? 1 : D];
-  float *row = (TR == kWave) ? tile + lane * D : rowbuf;
+  float *row = (TR == kWave) ? tile + lane * TS : rowbuf;
   const uint32_t env_id = (uint32_t)(a.env_id_base + (unsigned long long)ii);
   const float4 h1 = S.h1, h2 = S.h2;
   const uint32_t ctr = S.ctr;
@@ -391,11 +459,11 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
     float tx, ty, tz;
     target_at<TASK>(k, ref_lds, target_index<TASK>(step, k.agg, phase), tx, ty, tz);
     if (V::ON) {
-      write_noisy_half<TASK>(row, S.oh, ns.lpf, h1, tx, ty, tz, pa1);
+      put_noisy_half<TASK, O + 4, VEC>(row, S.oh, ns.lpf, h1, tx, ty, tz, pa1);
     } else {
       Quat qk = q;
       if (ctr_sign(ctr)) { qk.x = -q.x; qk.y = -q.y; qk.z = -q.z; qk.w = -q.w; }
-      write_obs_half<TASK>(row, e, qk, h1, tx, ty, tz, pa1);
+      put_obs_half<TASK, O + 4, VEC>(row, e, qk, h1, tx, ty, tz, pa1);
     }
   }
 
@@ -556,9 +624,9 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
       S.oh.qw = fresh ? S.oh.qw : held.qw;
       S.oh.vx = fresh ? S.oh.vx : held.vx; S.oh.vy = fresh ? S.oh.vy : held.vy; S.oh.vz = fresh ? S.oh.vz : held.vz;
     }
-    write_noisy_half<TASK>(row + O + 4, S.oh, ns.lpf, act, tx, ty, tz, pa2);
+    put_noisy_half<TASK, O + 4, VEC>(row + O + 4, S.oh, ns.lpf, act, tx, ty, tz, pa2);
   } else {
-    write_obs_half<TASK>(row + O + 4, e, q, act, tx, ty, tz, pa2);
+    put_obs_half<TASK, O + 4, VEC>(row + O + 4, e, q, act, tx, ty, tz, pa2);
   }
 
   S.ctr = ctr_pack((uint32_t)(step + 1), 0u, (uint32_t)phase1, lat_idx);
@@ -610,9 +678,13 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
   for (int pass = 0; pass < kWave / TR; ++pass) {
     if (TR != kWave) {
       if ((lane / TR) == pass) {
-        float *dst = tile + (lane % TR) * D;
+        float *dst = tile + (lane % TR) * TS;
+        if constexpr (TS != D) {
+          lds_store_row<D>(dst, rowbuf);
+        } else {
 #pragma unroll
-        for (int j = 0; j < D; ++j) dst[j] = rowbuf[j];
+          for (int j = 0; j < D; ++j) dst[j] = rowbuf[j];
+        }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -626,7 +698,7 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
       const int src_lane = __builtin_ctzll(m);
       m &= m - 1ull;
       // non-temporal like the other streamed outputs (same box: 57.7 vs 58.4 us on Hover 2^20)
-      if (lane < D) nt_store(a.final_obs + (o1 + wave_base + src_lane) * D + lane, tile[(src_lane % TR) * D + lane]);
+      if (lane < D) nt_store(a.final_obs + (o1 + wave_base + src_lane) * D + lane, tile[(src_lane % TR) * TS + lane]);
     }
     if (RM != RM_DEFERRED && reset_mask != 0ull) {  // wave-uniform: the reset envs' rows become [o0, u0, o0', u0]
       if constexpr (RM == RM_INLINE) {
@@ -648,16 +720,16 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
           for (int j = 0; j < 3; ++j) { ps.rate_int[j] = ps.rate_err[j] = ps.att_int[j] = ps.att_err[j] = 0.f; }
           float tx0, ty0, tz0;
           target_at<TASK>(k, ref_lds, target_index<TASK>(0, k.agg, (int)ctr_off(r.ctr)), tx0, ty0, tz0);
-          float *dst = tile + lane * D;
+          float *dst = tile + lane * TS;
           if (V::ON) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) { ns.bias[j] = r.ns.bias[j]; ns.lpf[j] = r.ns.lpf[j]; }
             S.oh = r.ob;
-            write_noisy_half<TASK>(dst, r.oa, r.lpf_a, r.u0, tx0, ty0, tz0, r.u0);
-            write_noisy_half<TASK>(dst + O + 4, r.ob, r.ns.lpf, r.u0, tx0, ty0, tz0, r.u0);
+            put_noisy_half<TASK, O + 4, (TS != D)>(dst, r.oa, r.lpf_a, r.u0, tx0, ty0, tz0, r.u0);
+            put_noisy_half<TASK, O + 4, (TS != D)>(dst + O + 4, r.ob, r.ns.lpf, r.u0, tx0, ty0, tz0, r.u0);
           } else {
-            write_obs_half<TASK>(dst, r.e, r.q, r.u0, tx0, ty0, tz0, r.u0);
-            write_obs_half<TASK>(dst + O + 4, r.e, r.q, r.u0, tx0, ty0, tz0, r.u0);
+            put_obs_half<TASK, O + 4, (TS != D)>(dst, r.e, r.q, r.u0, tx0, ty0, tz0, r.u0);
+            put_obs_half<TASK, O + 4, (TS != D)>(dst + O + 4, r.e, r.q, r.u0, tx0, ty0, tz0, r.u0);
           }
           if constexpr (V::LAT) {
 #pragma unroll
@@ -669,9 +741,9 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
         if (need_reset && (TR == kWave || (lane / TR) == pass)) {
           float tx0, ty0, tz0;
           target_at<TASK>(k, ref_lds, target_index<TASK>(0, k.agg, (int)ctr_off(S.ctr)), tx0, ty0, tz0);
-          float *dst = tile + (lane % TR) * D;
-          write_obs_half<TASK>(dst, e, q, S.h1, tx0, ty0, tz0, S.h1);
-          write_obs_half<TASK>(dst + O + 4, e, q, S.h1, tx0, ty0, tz0, S.h1);
+          float *dst = tile + (lane % TR) * TS;
+          put_obs_half<TASK, O + 4, (TS != D)>(dst, e, q, S.h1, tx0, ty0, tz0, S.h1);
+          put_obs_half<TASK, O + 4, (TS != D)>(dst + O + 4, e, q, S.h1, tx0, ty0, tz0, S.h1);
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -743,7 +815,7 @@ PDS_DEV void prefetch_kernargs() {
 }
 
 #define PDS_WAVE_SETUP(V, TR, RM)                                                                      \
-  __shared__ __attribute__((aligned(16))) float tile_all[(kBlock / kWave) * TR * V::D];               \
+  __shared__ __attribute__((aligned(16))) float tile_all[(kBlock / kWave) * TR * tile_stride<V::D>()]; \
   __shared__ float2 ref_lds[(V::TASK == PDS_TASK_CIRCLE) ? kRefPoints : 1];                           \
   __shared__ uint32_t queue_all[(kBlock / kWave) * kQueueCap];                                        \
   __shared__ U4 scratch_all[(RM == RM_MERGED) ? (kBlock / kWave) * kMergedScratchU4 : 1];             \
@@ -756,7 +828,7 @@ PDS_DEV void prefetch_kernargs() {
     __syncthreads();                                                                                   \
   }                                                                                                    \
   uint32_t *queue = queue_all + wave * kQueueCap;                                                      \
-  float *tile = tile_all + wave * (TR * V::D);                                                         \
+  float *tile = tile_all + wave * (TR * tile_stride<V::D>());                                          \
   const long long ntiles = (a.n + kWave - 1) / kWave;                                                  \
   const long long t = (long long)blockIdx.x * (kBlock / kWave) + wave;                                 \
   if (t >= ntiles) return; /* wave-uniform */                                                          \
