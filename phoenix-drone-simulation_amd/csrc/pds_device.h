@@ -115,6 +115,25 @@ PDS_DEV U4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32
   return U4{c0, c1, c2, c3};
 }
 
+// Both variants in ONE instruction stream: lanes with `seven` keep the state after round 7, the others
+// after round 10.  (A wave whose lanes compute different blocks side by side would otherwise run the
+// 10-round and the 7-round code one after the other: the 32-bit multiplies are quarter rate, ~64 cycles of
+// the wave's VALU time per round whatever the number of active lanes.)
+PDS_DEV U4 philox4x32_10_or_7(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, bool seven) {
+  U4 at7{0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    if (r == 7) at7 = U4{c0, c1, c2, c3};
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0;
+    const uint32_t n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return seven ? at7 : U4{c0, c1, c2, c3};
+}
+
 // reset sampling: the standard 10 rounds
 PDS_DEV U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
   return philox4x32<10>(c0, c1, c2, c3, k0, k1);

@@ -32,11 +32,14 @@ struct DirectWords {
   PDS_DEV U4 reset_block(uint32_t b) const { return philox4x32_10(env_id, tick_lo, tick_hi, kBlkReset + b, seed_lo, seed_hi); }
   PDS_DEV U4 noise_block(uint32_t b) const { return philox4x32_7(env_id, tick_lo, tick_hi, kBlkResetNoise + b, seed_lo, seed_hi); }
   PDS_DEV U4 lat_block(uint32_t r) const { return philox4x32_10(env_id, tick_lo, tick_hi, kBlkLatRows + r, seed_lo, seed_hi); }
-  // scratch slot j of the cooperative fill (LdsWords layout)
+  // scratch slot j of the cooperative fill (LdsWords layout): reset / latency-row blocks take 10 rounds, the
+  // noise blocks 7 -- evaluated in one instruction stream for all lanes of the wave
   PDS_DEV U4 scratch_block(int j) const {
-    if (j < kResetBlocks) return reset_block((uint32_t)j);
-    if (j < kResetBlocks + kResetNoiseBlocks) return noise_block((uint32_t)(j - kResetBlocks));
-    return lat_block((uint32_t)(j - kResetBlocks - kResetNoiseBlocks));
+    const bool noise = j >= kResetBlocks && j < kResetBlocks + kResetNoiseBlocks;
+    const uint32_t blk = j < kResetBlocks ? kBlkReset + (uint32_t)j
+                         : (noise ? kBlkResetNoise + (uint32_t)(j - kResetBlocks)
+                                  : kBlkLatRows + (uint32_t)(j - kResetBlocks - kResetNoiseBlocks));
+    return philox4x32_10_or_7(env_id, tick_lo, tick_hi, blk, seed_lo, seed_hi, noise);
   }
 };
 struct LdsWords {
@@ -357,8 +360,8 @@ PDS_DEV void reset_env(const Consts &k, const float2 *ref_lds, const Sample &s, 
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float T = fmaxf(s.T[i], par.dt);
-        par.A[i] = 1.0f - par.dt / T;
-        par.K[i] = 0.028f * k.G * s.t2w[i] / 4.0f;
+        par.A[i] = 1.0f - par.dt * fast_rcp(T);  // v_rcp_f32: 1 ulp (an IEEE division is ~12 instructions)
+        par.K[i] = (0.028f * k.G * s.t2w[i]) * 0.25f;
       }
     }
   }
@@ -509,33 +512,41 @@ constexpr int kResetsPerPass = kWave / kLanesPerReset;
 template <class V>
 PDS_DEV void drain_reset_queue(const StepArgs &a, const RngKey &rk, const float2 *ref_lds, const uint32_t *queue,
                                int qcount, int lane, long long wave_base, float *tile) {
+  // Two costs per pass, both paid by the whole wave whatever the number of active lanes: one Philox (~650
+  // cycles: quarter-rate 32-bit multiplies) per round of block computations, and one evaluation of the
+  // reset (~2000 cycles) by the owner lanes.  So: up to 8 envs per pass share ONE reset evaluation, and their
+  // Philox blocks are computed L lanes per env (8, 16 or 32 for the 9 / 15 / 22 blocks a variant can need),
+  // i.e. in as few rounds as the number of queued envs allows (one round for up to 64 / L envs).
+  constexpr int NB = scratch_blocks_used<V>();
+  constexpr int L = NB <= 8 ? 8 : (NB <= 16 ? 16 : 32);  // lanes per env in a Philox round
+  constexpr int EPR = kWave / L;                           // envs per Philox round
   static_assert(kResetsPerPass * kScratchBlocks * 16 <= kHalfTileRows * V::D * 4, "scratch must fit in the wave's tile");
   U4 *scratch = reinterpret_cast<U4 *>(tile);
-  const int g = lane / kLanesPerReset, b = lane % kLanesPerReset;
+  const int g = lane / L, j = lane % L;
+  const int og = lane / kLanesPerReset;  // owner lanes: the first of every 8
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   for (int base = 0; base < qcount; base += kResetsPerPass) {
-    const int idx = base + g;
-    const bool on = idx < qcount;
-    uint32_t ent = 0;
-    if (on) ent = queue[idx];
-    const long long i = wave_base + (long long)(ent & 63u);
-    const uint32_t env_id = (uint32_t)(a.env_id_base + (unsigned long long)i);
-    if (on) {
+    const int cnt = min(kResetsPerPass, qcount - base);  // wave-uniform
+    for (int sub = 0; sub < cnt; sub += EPR) {
+      const int slot = sub + g;  // env of the pass this lane computes a block for
+      const bool on = slot < cnt;
+      uint32_t ent = 0;
+      if (on) ent = queue[base + slot];
+      const uint32_t env_id = (uint32_t)(a.env_id_base + (unsigned long long)(wave_base + (long long)(ent & 63u)));
       const DirectWords dw(env_id, rk);
+      bool need = false;
 #pragma unroll
-      for (int jj = 0; jj < (scratch_blocks_used<V>() + kLanesPerReset - 1) / kLanesPerReset; ++jj) {
-        const int j = jj * kLanesPerReset + b;
-        bool need = false;
-#pragma unroll
-        for (int c = 0; c < scratch_blocks_used<V>(); ++c) need = need || (c == j && block_needed<V>(c));
-        if (need) scratch[g * kScratchBlocks + j] = dw.scratch_block(j);
-      }
+      for (int c = 0; c < NB; ++c) need = need || (c == j && block_needed<V>(c));
+      if (on && need) scratch[slot * kScratchBlocks + j] = dw.scratch_block(j);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const bool owner = on && b == 0;
+    const bool owner = og < cnt && (lane % kLanesPerReset) == 0;
+    uint32_t ent = 0;
+    if (owner) ent = queue[base + og];
+    const long long i = wave_base + (long long)(ent & 63u);
     ResetOut r;
     float stale_w[3] = {0.f, 0.f, 0.f}, bias[3] = {0.f, 0.f, 0.f};
     if (V::ON) {
@@ -548,7 +559,7 @@ PDS_DEV void drain_reset_queue(const StepArgs &a, const RngKey &rk, const float2
       }
     }
     if (owner) {
-      const LdsWords lw{scratch + g * kScratchBlocks};
+      const LdsWords lw{scratch + og * kScratchBlocks};
       reset_compute<V>(a, ref_lds, lw, ctr_pack(0u, 0u, ent >> 6), nullptr, stale_w, bias, r);
     }
     if (!V::ON) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -580,23 +591,34 @@ PDS_DEV void reset_in_registers(const StepArgs &a, const RngKey &rk, const float
                                 int count, bool mine, int pos, int lane, long long wave_base, int ref_offset,
                                 U4 *scratch, EnvRegs &e, Quat &q, float4 &u0, float4 &mx, Params &par, uint32_t &ctr) {
   static_assert(!V::ON && !V::LAT, "observation-noise / latency variants use the deferred drain or the inline reset");
+  // One Philox4x32-10 block costs ~650 cycles of the wave's VALU time (40 quarter-rate 32-bit multiplies),
+  // however many lanes compute one -- so all blocks of a pass are computed side by side: 8 envs x 8 blocks,
+  // or, for the variants that need a ninth block (PT1 + DR), 4 envs x 8 blocks on lanes 0..31 and the ninth
+  // blocks of those 4 envs on lanes 32, 40, 48, 56 (a second round if more than 4 envs finished); the reset
+  // itself (~2000 cycles) is then evaluated ONCE for up to 8 finished envs.
+  constexpr bool NINE = V::MOTOR && V::DR;
+  constexpr int EPR = NINE ? kResetsPerPass / 2 : kResetsPerPass;  // envs per Philox round
   const int g = lane / kLanesPerReset, b = lane % kLanesPerReset;
-  for (int base = 0; base < count; base += kResetsPerPass) {
-    const bool on = base + g < count;
-    const int src = on ? (int)lanes[base + g] : lane;
-    const uint32_t env_id = (uint32_t)(a.env_id_base + (unsigned long long)(wave_base + src));
-    const DirectWords dw(env_id, rk);
-    bool need = false;
+  const int ge = NINE ? (g & 3) : g;                          // env of the round this lane works for
+  const uint32_t blk = (NINE && g >= 4) ? 8u : (uint32_t)b;  // block it computes
+  bool need = false;
 #pragma unroll
-    for (int c = 0; c < kLanesPerReset; ++c) need = need || (c == b && block_needed<V>(c));
-    if (on && need) scratch[g * kMergedScratchBlocks + b] = dw.reset_block((uint32_t)b);
-    if (V::MOTOR && V::DR) {  // ninth block: the group's first lane
-      if (on && b == 0) scratch[g * kMergedScratchBlocks + 8] = dw.reset_block(8u);
+  for (int c = 0; c < kMergedScratchBlocks; ++c) need = need || (c == (int)blk && block_needed<V>(c));
+  if (NINE && g >= 4 && b != 0) need = false;
+  for (int base = 0; base < count; base += kResetsPerPass) {
+    const int cnt = min(kResetsPerPass, count - base);  // wave-uniform
+    for (int sub = 0; sub < cnt; sub += EPR) {
+      const int slot = sub + ge;
+      const bool on = slot < cnt;
+      const int src = on ? (int)lanes[base + slot] : lane;
+      const uint32_t env_id = (uint32_t)(a.env_id_base + (unsigned long long)(wave_base + src));
+      const DirectWords dw(env_id, rk);
+      if (on && need) scratch[slot * kMergedScratchBlocks + blk] = dw.reset_block(blk);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (mine && pos >= base && pos < base + kResetsPerPass) {
+    if (mine && pos >= base && pos < base + kResetsPerPass) {  // one evaluation for up to 8 finished envs
       const LdsWords lw{scratch + (pos - base) * kMergedScratchBlocks};
       Sample s;
       sample_philox<V>(a.k, lw, s);

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--envs", type=int, default=None)
     ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--no-auto-reset", action="store_true")
     args = ap.parse_args()
     import torch
     import phoenix_drone_simulation_amd as pds
@@ -37,7 +38,7 @@ def main():
     if args.envs:
         n = args.envs
     env_id = {"hover": "DroneHoverSimpleEnv-v0", "circle": "DroneCircleSimpleEnv-v0", "takeoff": "DroneTakeOffSimpleEnv-v0"}[task]
-    env = pds.make(env_id, num_envs=n, seed=0, **kw)
+    env = pds.make(env_id, num_envs=n, seed=0, auto_reset=not args.no_auto_reset, **kw)
     lib = env.lib
     lib.pds_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong]
     assert lib.pds_debug_stamps(env._handle, None, 0) == 0, "not a -DPDS_STAMPS build (set PDS_LIB)"
