@@ -430,6 +430,12 @@ extern "C" int pds_create(const pds_config *cfg, pds_handle **out) {
     const int obs_rate = sim_freq / cfg->observation_frequency;
     if (obs_rate < 1) PDS_CREATE_FAIL(PDS_EINVAL, "observation_frequency %d above sim_freq %d: obs_rate 0 (the reference divides by it)", cfg->observation_frequency, sim_freq);
   }
+  if (cfg->observation_noise > 0) {
+    const int obs_rate = (int)llround(1.0 / cfg->time_step) / cfg->observation_frequency;
+    if (obs_rate != 1 && (cfg->control_mode != PDS_CTRL_PWM || cfg->use_latency || cfg->use_ground_effect))
+      PDS_CREATE_FAIL(PDS_EUNSUPPORTED, "observation noise with obs_rate %d > 1 (Kalman-hold branch) is built for control_mode PWM "
+                      "without latency / ground effect", obs_rate);
+  }
   const int lat_steps = cfg->use_latency ? latency_steps_ctor(cfg->latency, cfg->time_step) : 0;
   if (lat_steps > kMaxLatSteps) PDS_CREATE_FAIL(PDS_EUNSUPPORTED, "latency %g s = %d steps (limit %d)", cfg->latency, lat_steps, kMaxLatSteps);
   if (cfg->use_latency && cfg->use_ground_effect) PDS_CREATE_FAIL(PDS_EUNSUPPORTED, "use_latency with the ground-effect extension is not built");
@@ -449,6 +455,7 @@ extern "C" int pds_create(const pds_config *cfg, pds_handle **out) {
   h->flags.on = cfg->observation_noise > 0;
   h->flags.ctrl = cfg->control_mode;
   h->flags.lat = lat_steps > 0;
+  h->flags.hold = h->k.obs_rate != 1;
   h->flags.half_tile = false;
   if (const char *ft = getenv("PDS_FORCE_TILE")) h->force_tile = (ft[0] == 'h') ? 1 : ((ft[0] == 'f') ? 2 : 0);
   const size_t n = (size_t)cfg->num_envs;
@@ -590,6 +597,7 @@ extern "C" int pds_set_latency(pds_handle *h, double latency) {
   h->cfg.use_latency = steps > 0;
   h->flags.lat = steps > 0;
   set_latency_consts(h->k, steps, h->cfg.aggregate_phy_steps);
+  if (steps > 0 && h->flags.hold) return fail(h, PDS_EUNSUPPORTED, "latency with obs_rate > 1 is not built");
   if (steps > 0) {
     const int rc = ensure_latency_buffer(h);
     if (rc != PDS_OK) return rc;
@@ -646,7 +654,11 @@ static void base_args(pds_handle *h, StepArgs &a) {
 
 static void launch_family(pds_handle *h, int kind, const LaunchFlags &lf, dim3 grid, hipStream_t s, const StepArgs &a) {
   const int task = h->cfg.task;
-  if (lf.lat) {
+  if (lf.hold && kind != kLaunchReset) {  // (a reset observes at iteration 0: always a fresh observation)
+    if (task == PDS_TASK_HOVER) launch_hover_hold(kind, lf, grid, s, a);
+    else if (task == PDS_TASK_CIRCLE) launch_circle_hold(kind, lf, grid, s, a);
+    else launch_takeoff_hold(kind, lf, grid, s, a);
+  } else if (lf.lat) {
     if (task == PDS_TASK_HOVER) launch_hover_lat(kind, lf, grid, s, a);
     else if (task == PDS_TASK_CIRCLE) launch_circle_lat(kind, lf, grid, s, a);
     else launch_takeoff_lat(kind, lf, grid, s, a);

@@ -320,7 +320,7 @@ PDS_DEV void sub_noise(const StepArgs &a, const RngKey &rk, uint32_t env_id, lon
     for (int j = 0; j < 4; ++j) n.ou[j] = p[PDS_N_OU + j];
 #pragma unroll
     for (int j = 0; j < 3; ++j) { n.bias_z[j] = p[PDS_N_A_BIAS + j]; n.rw_z[j] = p[PDS_N_A_RW + j]; n.to_z[j] = p[PDS_N_A_TO + j]; }
-    if (V::ON && a.k.obs_rate != 1) {
+    if (V::ON && V::HOLD) {
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         n.full.pos_z[j] = p[PDS_N_A_POS_Z + j]; n.full.pos_u[j] = p[PDS_N_A_POS_U + j]; n.full.vel_z[j] = p[PDS_N_A_VEL_Z + j];
@@ -351,7 +351,7 @@ PDS_DEV void sub_noise(const StepArgs &a, const RngKey &rk, uint32_t env_id, lon
   for (int j = 0; j < 4; ++j) n.ou[j] = z[j];
 #pragma unroll
   for (int j = 0; j < 3; ++j) { n.bias_z[j] = z[4 + j]; n.rw_z[j] = z[7 + j]; n.to_z[j] = z[10 + j]; }
-  if (V::ON && a.k.obs_rate != 1) {  // wave-uniform: the held state may be refreshed by this call
+  if (V::ON && V::HOLD) {  // the held state may be refreshed by this call
     const uint32_t bx = kBlkSubNoiseX + 2u * (uint32_t)sub;
     const U4 x0 = philox4x32_7(env_id, rk.tick_lo, rk.tick_hi, bx, rk.seed_lo, rk.seed_hi);
     const U4 x1 = philox4x32_7(env_id, rk.tick_lo, rk.tick_hi, bx + 1u, rk.seed_lo, rk.seed_hi);
@@ -544,7 +544,7 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
     // envs/base.py:464: compute_observation() whose result is dropped still advances the gyro
     // bias random walk and the low-pass filter
     if (V::ON) {
-      if (k.obs_rate == 1) {
+      if (!V::HOLD) {
         gyro_update(k, e, sn.bias_z, sn.rw_z, sn.to_z, ns);
       } else {
         // ... and, at an iteration that is a multiple of obs_rate, refreshes the held position / attitude /
@@ -617,7 +617,7 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
     if (a.noise != nullptr) obs_noise_load(a.noise + ii * PDS_NOISE_FLOATS + PDS_N_OBS, n);
     else obs_noise_philox(env_id, rk, kBlkObsNoise, n);
     sensor_observe(k, e, n, ns, S.oh);
-    if (k.obs_rate != 1) {  // wave-uniform; per env: fresh observation or the held one + the fresh gyro
+    if (V::HOLD) {  // per env: fresh observation or the held one + the fresh gyro
       const bool fresh = (((step + 1) * k.agg) % k.obs_rate) == 0;
       S.oh.x = fresh ? S.oh.x : held.x; S.oh.y = fresh ? S.oh.y : held.y; S.oh.z = fresh ? S.oh.z : held.z;
       S.oh.qx = fresh ? S.oh.qx : held.qx; S.oh.qy = fresh ? S.oh.qy : held.qy; S.oh.qz = fresh ? S.oh.qz : held.qz;
@@ -938,22 +938,22 @@ inline void launch_variant(int kind, bool half_tile, dim3 grid, hipStream_t s, c
   }
 }
 
-template <int TASK, int CTRL, bool LAT, bool MOTOR, bool DR, bool GE, bool TN, bool ON>
+template <int TASK, int CTRL, bool LAT, bool HOLD, bool MOTOR, bool DR, bool GE, bool TN, bool ON>
 struct MakeVariant {
-  using type = Variant<TASK, MOTOR, DR, GE, TN, ON, CTRL, LAT>;
+  using type = Variant<TASK, MOTOR, DR, GE, TN, ON, CTRL, LAT, HOLD>;
 };
 
 // binds the boolean flags one by one: Bs... = MOTOR, DR, GE, TN, ON
-template <int TASK, int CTRL, bool LAT, bool... Bs>
+template <int TASK, int CTRL, bool LAT, bool HOLD, bool... Bs>
 struct VariantDispatch {
   template <typename... Rest>
   static void run(int kind, bool half, dim3 grid, hipStream_t s, const StepArgs &a, bool first, Rest... rest) {
-    if (first) VariantDispatch<TASK, CTRL, LAT, Bs..., true>::run(kind, half, grid, s, a, rest...);
-    else VariantDispatch<TASK, CTRL, LAT, Bs..., false>::run(kind, half, grid, s, a, rest...);
+    if (first) VariantDispatch<TASK, CTRL, LAT, HOLD, Bs..., true>::run(kind, half, grid, s, a, rest...);
+    else VariantDispatch<TASK, CTRL, LAT, HOLD, Bs..., false>::run(kind, half, grid, s, a, rest...);
   }
   static void run(int kind, bool half, dim3 grid, hipStream_t s, const StepArgs &a) {
     static_assert(sizeof...(Bs) == 5, "MOTOR, DR, GE, TN, ON");
-    launch_variant<typename MakeVariant<TASK, CTRL, LAT, Bs...>::type>(kind, half, grid, s, a);
+    launch_variant<typename MakeVariant<TASK, CTRL, LAT, HOLD, Bs...>::type>(kind, half, grid, s, a);
   }
 };
 
@@ -964,21 +964,38 @@ struct VariantDispatch {
 // The reset kernel does not depend on GE / TN / CTRL: those flags are folded to false / 0 for it.
 template <int TASK>
 inline void launch_base(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a) {
-  if (kind == kLaunchReset) VariantDispatch<TASK, 0, false>::run(kind, false, grid, s, a, f.motor, f.dr, false, false, f.on);
-  else VariantDispatch<TASK, 0, false>::run(kind, f.half_tile, grid, s, a, f.motor, f.dr, f.ge, f.tn, f.on);
+  if (kind == kLaunchReset) VariantDispatch<TASK, 0, false, false>::run(kind, false, grid, s, a, f.motor, f.dr, false, false, f.on);
+  else VariantDispatch<TASK, 0, false, false>::run(kind, f.half_tile, grid, s, a, f.motor, f.dr, f.ge, f.tn, f.on);
 }
 template <int TASK>
 inline void launch_pid(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a) {
-  if (f.ctrl == 1) VariantDispatch<TASK, 1, false>::run(kind, f.half_tile, grid, s, a, f.motor, f.dr, false, f.tn, f.on);
-  else VariantDispatch<TASK, 2, false>::run(kind, f.half_tile, grid, s, a, f.motor, f.dr, false, f.tn, f.on);
+  if (f.ctrl == 1) VariantDispatch<TASK, 1, false, false>::run(kind, f.half_tile, grid, s, a, f.motor, f.dr, false, f.tn, f.on);
+  else VariantDispatch<TASK, 2, false, false>::run(kind, f.half_tile, grid, s, a, f.motor, f.dr, false, f.tn, f.on);
 }
 template <int TASK>
 inline void launch_lat(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a) {
-  if (kind == kLaunchReset) { VariantDispatch<TASK, 0, true>::run(kind, false, grid, s, a, f.motor, f.dr, false, false, f.on); return; }
-  if (TASK == PDS_TASK_TAKEOFF || f.ctrl == 0) VariantDispatch<TASK, 0, true>::run(kind, false, grid, s, a, f.motor, f.dr, false, f.tn, f.on);
+  if (kind == kLaunchReset) { VariantDispatch<TASK, 0, true, false>::run(kind, false, grid, s, a, f.motor, f.dr, false, false, f.on); return; }
+  if (TASK == PDS_TASK_TAKEOFF || f.ctrl == 0) VariantDispatch<TASK, 0, true, false>::run(kind, false, grid, s, a, f.motor, f.dr, false, f.tn, f.on);
   else if constexpr (TASK != PDS_TASK_TAKEOFF) {  // TakeOff fixes control_mode='PWM', envs/takeoff.py:225
-    if (f.ctrl == 1) VariantDispatch<TASK, 1, true>::run(kind, false, grid, s, a, f.motor, f.dr, false, f.tn, f.on);
-    else VariantDispatch<TASK, 2, true>::run(kind, false, grid, s, a, f.motor, f.dr, false, f.tn, f.on);
+    if (f.ctrl == 1) VariantDispatch<TASK, 1, true, false>::run(kind, false, grid, s, a, f.motor, f.dr, false, f.tn, f.on);
+    else VariantDispatch<TASK, 2, true, false>::run(kind, false, grid, s, a, f.motor, f.dr, false, f.tn, f.on);
+  }
+}
+
+// hold: observation noise with obs_rate > 1 (control_mode PWM, no latency, no ground effect): motor x DR x TN
+template <int TASK>
+inline void launch_hold(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a) {
+  // MOTOR, DR, GE = false, TN, ON = true: bind the two constants first
+  if (f.motor) {
+    if (f.dr) { if (f.tn) launch_variant<Variant<TASK, true, true, false, true, true, 0, false, true>>(kind, false, grid, s, a);
+                else launch_variant<Variant<TASK, true, true, false, false, true, 0, false, true>>(kind, false, grid, s, a); }
+    else { if (f.tn) launch_variant<Variant<TASK, true, false, false, true, true, 0, false, true>>(kind, false, grid, s, a);
+           else launch_variant<Variant<TASK, true, false, false, false, true, 0, false, true>>(kind, false, grid, s, a); }
+  } else {
+    if (f.dr) { if (f.tn) launch_variant<Variant<TASK, false, true, false, true, true, 0, false, true>>(kind, false, grid, s, a);
+                else launch_variant<Variant<TASK, false, true, false, false, true, 0, false, true>>(kind, false, grid, s, a); }
+    else { if (f.tn) launch_variant<Variant<TASK, false, false, false, true, true, 0, false, true>>(kind, false, grid, s, a);
+           else launch_variant<Variant<TASK, false, false, false, false, true, 0, false, true>>(kind, false, grid, s, a); }
   }
 }
 

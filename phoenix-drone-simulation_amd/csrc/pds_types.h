@@ -131,8 +131,12 @@ struct RngKey {
 };
 
 // Compile-time variant of the fused step: task and feature flags.
-template <int TASK_, bool MOTOR_, bool DR_, bool GE_, bool TN_, bool ON_, int CTRL_ = 0, bool LAT_ = false>
+template <int TASK_, bool MOTOR_, bool DR_, bool GE_, bool TN_, bool ON_, int CTRL_ = 0, bool LAT_ = false, bool HOLD_ = false>
 struct Variant {
+  // obs_rate = sim_freq // observation_frequency > 1: Kalman-hold branch of compute_observation (envs/hover.py:150-156).
+  // A template flag, not a run-time branch: its registers (held state, full first-call noise) pushed the
+  // observation-noise variants to the 168-VGPR cap with spills (Hover 2^20 noise + DR: 95 vs 90.7 us).
+  static constexpr bool HOLD = HOLD_;
   static constexpr int CTRL = CTRL_;     // 0 PWM, 1 AttitudeRate PID, 2 cascaded Attitude PID (envs/control.py)
   static constexpr bool LAT = LAT_;      // delayed actions through the latency ring (envs/agents.py:267-276)
   static constexpr int TASK = TASK_;
@@ -216,6 +220,7 @@ struct LaunchFlags {
   bool motor, dr, ge, tn, on;
   int ctrl;
   bool lat;
+  bool hold;
   bool half_tile;  // per launch: use the 32-row observation tile (variants without observation noise)
 };
 enum LaunchKind { kLaunchStep = 0, kLaunchStepK = 1, kLaunchReset = 2 };
@@ -228,5 +233,8 @@ void launch_circle_pid(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s,
 void launch_hover_lat(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
 void launch_circle_lat(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
 void launch_takeoff_lat(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
+void launch_hover_hold(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
+void launch_circle_hold(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
+void launch_takeoff_hold(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
 
 }  // namespace pds
