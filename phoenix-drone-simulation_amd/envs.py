@@ -265,7 +265,10 @@ class DroneVecEnv:
                  "final_observation": final_hist.reshape(N, -1)})
 
     def step(self, action, noise_variates=None):
-        """env.step(action).  `noise_variates` [N, 37] (native.STEP_NOISE_LAYOUT) replaces the in-kernel
+        """env.step(action).  The returned tensors are OWNED by the env: two buffer sets alternate, so the
+        result of a step stays valid during the next one (`o` and `next_o` of a rollout loop) and is
+        overwritten by the one after -- clone() what must live longer (the reference returns fresh arrays,
+        envs/base.py:311).  `noise_variates` [N, 52] (native.STEP_NOISE_LAYOUT) replaces the in-kernel
         Philox draws of the OU thrust noise / SensorNoise with caller-supplied standard variates
         (parity tests replay the reference's numpy draws this way)."""
         a = action
