@@ -202,6 +202,19 @@ static REAL rng_uniform01(po_rng *rng) { /* numpy uniform: low + (high-low)*u */
   return (REAL)rng->u[rng->iu++];
 }
 
+/* Python's `a // b` for floats (Objects/floatobject.c float_divmod): NOT floor(a / b) -- 0.03 // 0.01 == 2.0
+ * while 0.03 / 0.01 == 3.0 -- because the remainder is taken exactly (fmod) first. */
+static double SUF(py_float_floordiv)(double vx, double wx) {
+  double mod = fmod(vx, wx);
+  double div = (vx - mod) / wx;
+  if (mod != 0 && ((wx < 0) != (mod < 0))) div -= 1.0;
+  if (div == 0) return 0.0;
+  double fl = floor(div);
+  if (div - fl > 0.5) fl += 1.0;
+  return fl;
+}
+
+
 /* ------------------------------------------------------------------------------------------------
  * agent construction: envs/agents.py:114-206 (CrazyFlieAgent.__init__), AgentBase :21-79
  * ---------------------------------------------------------------------------------------------- */
@@ -230,7 +243,7 @@ void SUF(po_env_init)(const po_config *c, ENV *e) {
   /* agents.py:165,179-183 */
   e->use_latency = (c->use_latency && c->latency >= c->time_step) ? 1 : 0;
   {
-    int b = (int)floor(c->latency / c->time_step); /* Python float // float */
+    int b = (int)SUF(py_float_floordiv)(c->latency, c->time_step); /* int(self.LATENCY // time_step) */
     e->buf_size = b < 1 ? 1 : b;
     if (e->buf_size > PO_MAX_LAT) e->buf_size = PO_MAX_LAT;
   }
@@ -812,7 +825,7 @@ void SUF(po_philox_reset_sample)(const po_config *c, uint64_t seed, uint64_t env
 #undef DRV
   /* rows 0..B-2 of the latency action buffer: blocks 9.. (csrc/pds_reset.h kBlkLatRows) */
   if (c->use_latency && c->latency >= c->time_step) {
-    int B = (int)floor(c->latency / c->time_step);
+    int B = (int)SUF(py_float_floordiv)(c->latency, c->time_step);
     if (B < 1) B = 1;
     if (B > PO_MAX_LAT) B = PO_MAX_LAT;
     for (int row = 0; row < B - 1; ++row) {

@@ -480,6 +480,7 @@ def main():
     lat_scen("circle_rate_lat2", "circle", dict(DET, control_mode="AttitudeRate", latency=0.02), 8, 8, pid_act, 306)
     lat_scen("hover_setlat4", "hover", dict(DET), 8, 8, act_random(0.3), 307, set_latency=0.045, latency_on=False)  # int(.045/.01) = 4
     lat_scen("hover_lat2_defaults", "hover", dict(latency=0.025), 8, 8, act_random(0.2), 308)           # noise + DR + latency
+    lat_scen("hover_lat2_floordiv", "hover", dict(DET, latency=0.03), 4, 6, act_random(0.3), 309)       # 0.03 // 0.01 == 2.0 (0.03 / 0.01 == 3.0)
     # observation_frequency != 100: obs_rate = 100 // f > 1 takes the Kalman-hold branch of compute_observation
     # (hover.py:150-156 and the circle / takeoff equivalents); Circle sizes its reference from it (circle.py:47-49)
     scen.append(("hover_obsf50", "hover", dict(observation_frequency=50, domain_randomization=-1), 8, 10, act_random(0.2), 320, False, None, False))

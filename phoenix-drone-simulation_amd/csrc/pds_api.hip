@@ -291,11 +291,23 @@ extern "C" int pds_default_config(int task, pds_config *c) {
   return PDS_OK;
 }
 
+/* Python's `a // b` for floats (Objects/floatobject.c float_divmod): NOT floor(a / b) -- 0.03 // 0.01 == 2.0
+ * while 0.03 / 0.01 == 3.0 -- because the remainder is taken exactly (fmod) first. */
+static double py_float_floordiv(double vx, double wx) {
+  double mod = fmod(vx, wx);
+  double div = (vx - mod) / wx;
+  if (mod != 0 && ((wx < 0) != (mod < 0))) div -= 1.0;
+  if (div == 0) return 0.0;
+  double fl = floor(div);
+  if (div - fl > 0.5) fl += 1.0;
+  return fl;
+}
+
 // buf_size of the delayed-action ring: ctor form max(1, int(LATENCY // time_step)) (envs/agents.py:180),
 // set_latency form int(latency / TIME_STEP) (envs/agents.py:401); 0 = no delay
 static int latency_steps_ctor(double latency, double time_step) {
   if (!(latency >= time_step)) return 0;  // use_latency if latency >= time_step else False, agents.py:165
-  const int b = (int)floor(latency / time_step);  // Python's float // float
+  const int b = (int)py_float_floordiv(latency, time_step);
   return b < 1 ? 1 : b;
 }
 
