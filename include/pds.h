@@ -319,6 +319,14 @@ int pds_value_grad(const pds_mlp *m, const float *d_x, const int64_t *d_index, c
 int pds_gaussian_sample(const float *d_mu, const float *d_log_std, int64_t n, int d_out, uint64_t seed, uint64_t call,
                         uint64_t id_base, int deterministic, float *d_act, float *d_logp, void *stream);
 
+/* The same with the call counter split into a DEVICE word and a by-value offset: call = *d_call_base + call_offset.
+ * A rollout captured into a hipGraph passes the step index as the offset and advances the device word once
+ * per replay with pds_counter_add (*d_counter += inc, one thread), so every replay draws fresh variates. */
+int pds_gaussian_sample_dev(const float *d_mu, const float *d_log_std, int64_t n, int d_out, uint64_t seed,
+                            const uint64_t *d_call_base, uint64_t call_offset, uint64_t id_base, int deterministic,
+                            float *d_act, float *d_logp, void *stream);
+int pds_counter_add(uint64_t *d_counter, uint64_t inc, void *stream);
+
 /* One rollout step's bookkeeping (buf.store + episode statistics of IWPGAlgorithm.roll_out,
  * algs/iwpg/iwpg.py:350-385): copies reward / terminated / truncated [n] into their [T, N] slices, adds
  * the reward to the running episode return and 1 to the length, and for finished envs adds

@@ -15,10 +15,12 @@ namespace pds_train_detail {  // named (not anonymous) so that profiler kernel n
 // a = mu + sigma z, z ~ N(0,1) from Philox4x32-10 keyed by (seed, call counter); one thread per env
 // (d_out <= 8: at most 2 blocks).  logp = -sum(0.5 z^2 + log sigma + 0.5 log 2 pi).
 __global__ __launch_bounds__(256) void sample_kernel(const float *mu, const float *log_std, long long n, int d,
-                                                     uint64_t seed, uint64_t call, unsigned long long id_base,
-                                                     int deterministic, float *act, float *logp) {
+                                                     uint64_t seed, uint64_t call, const unsigned long long *call_base,
+                                                     unsigned long long id_base, int deterministic, float *act,
+                                                     float *logp) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (call_base != nullptr) call += *call_base;  // device-side part of the call counter (hipGraph replays)
   float z[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) z[j] = 0.f;
@@ -92,15 +94,33 @@ __global__ __launch_bounds__(256) void adam_kernel(pds_mlp m, const float *g, fl
   *dst = *dst - (lr / bc1) * (mm / denom);
 }
 
+// *c += inc by one thread (the device-side call counter of a captured rollout)
+__global__ void counter_add_kernel(unsigned long long *c, unsigned long long inc) { *c += inc; }
+
 }  // namespace pds_train_detail
 using namespace pds_train_detail;
+
+
+extern "C" int pds_gaussian_sample_dev(const float *d_mu, const float *d_log_std, int64_t n, int d_out, uint64_t seed,
+                                       const uint64_t *d_call_base, uint64_t call_offset, uint64_t id_base,
+                                       int deterministic, float *d_act, float *d_logp, void *stream) {
+  if (!d_mu || !d_log_std || !d_act || !d_logp || n < 1 || d_out < 1 || d_out > 8) return PDS_EINVAL;
+  hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_mu, d_log_std,
+                     (long long)n, d_out, seed, call_offset, reinterpret_cast<const unsigned long long *>(d_call_base),
+                     (unsigned long long)id_base, deterministic, d_act, d_logp);
+  return hipGetLastError() == hipSuccess ? PDS_OK : PDS_EHIP;
+}
 
 extern "C" int pds_gaussian_sample(const float *d_mu, const float *d_log_std, int64_t n, int d_out, uint64_t seed,
                                    uint64_t call, uint64_t id_base, int deterministic, float *d_act, float *d_logp,
                                    void *stream) {
-  if (!d_mu || !d_log_std || !d_act || !d_logp || n < 1 || d_out < 1 || d_out > 8) return PDS_EINVAL;
-  hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_mu, d_log_std,
-                     (long long)n, d_out, seed, call, (unsigned long long)id_base, deterministic, d_act, d_logp);
+  return pds_gaussian_sample_dev(d_mu, d_log_std, n, d_out, seed, nullptr, call, id_base, deterministic, d_act, d_logp, stream);
+}
+
+extern "C" int pds_counter_add(uint64_t *d_counter, uint64_t inc, void *stream) {
+  if (!d_counter) return PDS_EINVAL;
+  hipLaunchKernelGGL(pds_train_detail::counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream,
+                     reinterpret_cast<unsigned long long *>(d_counter), (unsigned long long)inc);
   return hipGetLastError() == hipSuccess ? PDS_OK : PDS_EHIP;
 }
 

@@ -131,12 +131,21 @@ class FusedMLP:
         return self.stats
 
 
-def gaussian_sample(mu, log_std, act_out, logp_out, seed, call, id_base=0, deterministic=False):
-    """act_out[n, d] = mu + exp(log_std) * z, logp_out[n] = log N(act | mu, sigma) summed over d."""
+def counter_add(counter, inc):
+    """counter (int64 device tensor of one element) += inc, stream-ordered (captured-rollout call counter)."""
+    with _on(counter):
+        rc = native.load().pds_counter_add(_ptr(counter), int(inc), FusedMLP._stream(counter))
+    if rc != native.OK:
+        raise RuntimeError(f"pds_counter_add -> {rc}")
+
+
+def gaussian_sample(mu, log_std, act_out, logp_out, seed, call, id_base=0, deterministic=False, call_base=None):
+    """act_out[n, d] = mu + exp(log_std) * z, logp_out[n] = log N(act | mu, sigma) summed over d.  The Philox
+    call counter is `call` (+ the int64 device word `call_base` when given: hipGraph-capturable form)."""
     with _on(mu):
-        rc = native.load().pds_gaussian_sample(_ptr(mu), _ptr(log_std), mu.shape[0], mu.shape[1], int(seed), int(call),
-                                               int(id_base), int(bool(deterministic)), _ptr(act_out), _ptr(logp_out),
-                                               FusedMLP._stream(mu))
+        rc = native.load().pds_gaussian_sample_dev(_ptr(mu), _ptr(log_std), mu.shape[0], mu.shape[1], int(seed),
+                                                   _ptr(call_base), int(call), int(id_base), int(bool(deterministic)),
+                                                   _ptr(act_out), _ptr(logp_out), FusedMLP._stream(mu))
     if rc != native.OK:
         raise RuntimeError(f"pds_gaussian_sample -> {rc}")
 

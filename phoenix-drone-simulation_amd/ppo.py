@@ -25,7 +25,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from . import native
-from .fused import gaussian_sample, rollout_record
+from .fused import counter_add, gaussian_sample, rollout_record
 
 
 class OnlineMeanStd(nn.Module):
@@ -64,9 +64,10 @@ class OnlineMeanStd(nn.Module):
             dist.all_reduce(batch_var)
             batch_var /= world
         M2_AB = n_A * torch.square(self.std) + n_B * batch_var + delta ** 2 * (n_A * n_B / n_AB)
-        self.mean.data = mean_new
-        self.count.data = n_AB
-        self.std.data = torch.sqrt(M2_AB / n_AB)
+        # in place: the fused kernels (and a captured rollout graph) hold the addresses of these tensors
+        self.mean.data.copy_(mean_new)
+        self.count.data.copy_(n_AB)
+        self.std.data.copy_(torch.sqrt(M2_AB / n_AB))
 
 
 def _mlp(sizes, activation):
@@ -215,7 +216,7 @@ class PPOTrainer:
                  train_v_iterations=5, num_mini_batches=16, target_kl=0.01, use_kl_early_stopping=False,
                  use_linear_lr_decay=True, use_exploration_noise_anneal=True, use_reward_scaling=True,
                  use_standardized_obs=True, use_max_grad_norm=False, max_grad_norm=0.5, ac_kwargs=None,
-                 seed=0, fused=None):
+                 seed=0, fused=None, graph_rollout=None):
         self.env, self.T, self.N = env, int(rollout_len), env.num_envs
         self.epochs, self.gamma, self.lam, self.clip_ratio = epochs, gamma, lam, clip_ratio
         self.entropy_coef = entropy_coef if use_entropy else 0.0
@@ -241,6 +242,13 @@ class PPOTrainer:
         self._pi_activation = kw["pi"]["activation"]
         self.fused = (dev.type == "cuda") if fused is None else bool(fused)
         self._sample_seed, self._sample_calls = (seed + 10000 * rank) & 0xFFFFFFFFFFFFFFFF, 0
+        # hipGraph capture of the whole rollout (fused path, even rollout length so that the env's two output
+        # sets line up from replay to replay): the env step is capturable (tick / parity in device memory), the
+        # sampling call counter gets a device word that the graph advances once per replay
+        if graph_rollout is None:  # default: on where it pays (small batches are launch-bound) and is possible
+            graph_rollout = env.num_envs <= 262144 and getattr(env, "observation_history_size", 2) == 2
+        self.graph_rollout = bool(graph_rollout) and self.fused and (rollout_len % 2 == 0)
+        self._graph, self._graph_stats, self._call_base = None, None, None
         if self.fused:
             from .fused import FusedMLP
             self.fm_pi = FusedMLP(self.ac.pi.net, kw["pi"]["activation"])
@@ -263,9 +271,33 @@ class PPOTrainer:
     def roll_out(self):
         """algs/iwpg/iwpg.py:350-385 over all envs at once.  Returns per-epoch episode statistics."""
         self.ac.train()
+        if self.graph_rollout:
+            return self._roll_out_graph()
+        return self._roll_out_eager()
+
+    def _roll_out_graph(self):
+        """The same launches, captured once (7 per step x T) and replayed per epoch: one host call per rollout."""
+        if self._graph is None:
+            dev = self.env.device
+            self._call_base = torch.full((1,), self._sample_calls, dtype=torch.int64, device=dev)
+            self._graph_stats = torch.zeros(3, device=dev)
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._roll_out_eager(stats=self._graph_stats)
+                counter_add(self._call_base, self.T)
+            self._graph = g
+        self._graph.replay()
+        self._sample_calls += self.T
+        return self._graph_stats
+
+    def _roll_out_eager(self, stats=None):
         o = self.obs
-        done_ret, done_len, done_cnt = 0.0, 0.0, 0.0
-        stats = torch.zeros(3, device=o.device)
+        capturing = stats is not None
+        if capturing:
+            stats.zero_()
+        else:
+            stats = torch.zeros(3, device=o.device)
         for t in range(self.T):
             if self.fused:
                 a, logp = self._fused_step(o, t)
@@ -314,9 +346,14 @@ class PPOTrainer:
         mean, std, eps = self._oms()
         self._fused_value(obs, out=self.val_buf[t])
         mu = self.fm_pi.forward(obs, mean=mean, std=std, eps=eps)
-        self._sample_calls += 1
-        gaussian_sample(mu, self.ac.pi.log_std, self.act_buf[t], self.logp_buf[t], self._sample_seed, self._sample_calls,
-                        id_base=self.env.env_id_base, deterministic=not self.ac.training)
+        if self._call_base is not None and torch.cuda.is_current_stream_capturing():
+            # captured: call = device word (advanced by T per replay) + step index
+            gaussian_sample(mu, self.ac.pi.log_std, self.act_buf[t], self.logp_buf[t], self._sample_seed, t + 1,
+                            id_base=self.env.env_id_base, deterministic=not self.ac.training, call_base=self._call_base)
+        else:
+            self._sample_calls += 1
+            gaussian_sample(mu, self.ac.pi.log_std, self.act_buf[t], self.logp_buf[t], self._sample_seed, self._sample_calls,
+                            id_base=self.env.env_id_base, deterministic=not self.ac.training)
         return self.act_buf[t], self.logp_buf[t]
 
     def update(self):

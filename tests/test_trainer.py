@@ -266,3 +266,37 @@ def test_save_checkpoint_roundtrip(tmp_path):
     assert torch.allclose(ac2.step(obs)[0], a1, atol=1e-6)
     assert torch.allclose(pol(obs), a1, atol=1e-5)
     env.close()
+
+
+@pytest.mark.gpu
+def test_graph_captured_rollout_equals_eager_rollout_bitwise():
+    """The whole rollout (env step, actor + critic inference, sampling, bookkeeping: 7 launches per step)
+    captured into ONE hipGraph and replayed per epoch gives bit for bit what the eager loop gives, epoch
+    after epoch (updates in between): the env's tick / action-ring parity and the sampler's call counter
+    live in device memory, the running statistics and the exploration noise are updated in place."""
+    import phoenix_drone_simulation_amd as pds
+    from phoenix_drone_simulation_amd.ppo import PPOTrainer
+    mk = lambda g: PPOTrainer(pds.make("DroneHoverSimpleEnv-v0", num_envs=1024, seed=3, max_episode_steps=40),
+                              rollout_len=16, epochs=6, train_pi_iterations=4, train_v_iterations=2, seed=3, fused=True,
+                              graph_rollout=g)
+    a, b = mk(True), mk(False)
+    assert a.graph_rollout and not b.graph_rollout
+    for ep in range(4):
+        for tr in (a, b):
+            tr.ac.update(frac=ep / 6)
+        sa, sb = a.roll_out(), b.roll_out()
+        torch.cuda.synchronize()
+        for name in ("obs_buf", "act_buf", "logp_buf", "val_buf", "fval_buf", "rew_buf", "term_buf", "trunc_buf"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), (ep, name)
+        assert torch.equal(a.last_val, b.last_val) and torch.equal(a.obs, b.obs), ep
+        # finished-episode statistics: block partials are added with float atomics (order varies run to run)
+        assert float(sa[2]) == float(sb[2]) > 0 and float(sa[1]) == float(sb[1]), ep
+        assert abs(float(sa[0]) - float(sb[0])) <= 1e-5 * abs(float(sb[0])), ep
+        torch.manual_seed(100 + ep)  # the value mini-batches are drawn from torch's global generator
+        ia = a.update()
+        torch.manual_seed(100 + ep)
+        ib = b.update()
+        assert ia["loss_pi"] == ib["loss_pi"] and ia["loss_v"] == ib["loss_v"], (ep, ia, ib)
+    assert a._sample_calls == b._sample_calls == 64
+    assert a.env.sync_tick() == b.env.tick
+    a.env.close(); b.env.close()
