@@ -120,9 +120,12 @@ class P2PObsGather:
             self.copy_stream = torch.cuda.Stream(self.device)
             self.events = [torch.cuda.Event(interprocess=True) for _ in range(2)]
             ev_handles = [None] * self.world
-            dist.all_gather_object(ev_handles, [e.ipc_handle() for e in self.events], group=self.sync_group)
+            dist.all_gather_object(ev_handles, (self.device.index, [e.ipc_handle() for e in self.events]),
+                                   group=self.sync_group)
+            # (an IPC event is re-opened on the device it was created on: the producer's)
             self.peer_events = [None if r == self.rank else
-                                [torch.cuda.Event.from_ipc_handle(self.device, hh) for hh in ev_handles[r]]
+                                [torch.cuda.Event.from_ipc_handle(torch.device("cuda", ev_handles[r][0]), hh)
+                                 for hh in ev_handles[r][1]]
                                 for r in range(self.world)]
         else:
             import os
