@@ -19,6 +19,9 @@ VARIANTS = [
     ("hover", dict(DET, aggregate_phy_steps=2)),
     ("hover", dict(DET, use_latency=True, latency=0.025, use_motor_dynamics=True)),
     ("circle", dict(DET, control_mode="AttitudeRate")),                         # no K-step kernel: loop of pds_step
+    ("hover", dict(observation_frequency=50)),                                  # Kalman-hold variant, noise + DR
+    ("takeoff", dict(observation_frequency=25, domain_randomization=-1, use_motor_dynamics=True)),
+    ("circle", dict(use_latency=True, latency=0.02)),                           # latency + noise + DR (inline reset)
 ]
 
 
