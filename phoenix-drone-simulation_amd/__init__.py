@@ -2,7 +2,7 @@
 
 Drop-in for ONE hot path of SvenGronauer/phoenix-drone-simulation: the per-env
 `env.reset()/env.step()` loop of the three `*SimpleEnv-v0` ids, replaced by a lockstep HIP kernel
-over N environments (csrc/pds_kernels.hip) behind the C ABI of include/pds.h.
+over N environments (csrc/pds_step.h, instantiated in csrc/pds_task_*.hip) behind the C ABI of include/pds.h.
 """
 from .build import build_library, library_path  # noqa: F401
 from .envs import (DroneVecEnv, DroneHoverSimpleEnv, DroneCircleSimpleEnv, DroneTakeOffSimpleEnv,  # noqa: F401

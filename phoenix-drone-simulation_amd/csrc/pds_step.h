@@ -1,12 +1,15 @@
 // pds_step.h -- the fused lockstep CrazyFlie SimplePhysics step for MI355X (gfx950, wave64).
 //
 // One thread per environment.  Per step a thread streams its SoA state quads (16 B/lane, fully
-// coalesced), advances PWM->thrust, Newton-Euler force/torque, semi-implicit Euler and
-// Euler->quaternion in registers, evaluates the task's reward / cost / termination, queues finished
-// envs for a deferred reset from a counter-based Philox stream, and stages its observation row in a
-// per-wave LDS tile so that the row-major [N, D] observation tensor is written with contiguous
+// coalesced), advances PWM->thrust (optionally through the latency ring, the PID cascade, the PT1
+// motor model), Newton-Euler force/torque, semi-implicit Euler and Euler->quaternion in registers,
+// evaluates the task's reward / cost / termination, resets finished envs from a counter-based Philox
+// stream (in registers before its stores, or in a drain after them), and stages its observation row in
+// a per-wave LDS tile so that the row-major [N, D] observation tensor is written with contiguous
 // 1 KiB wave stores instead of 64 strided rows.  HBM-bound by design: no MFMA (there is no dense
-// contraction on this path).
+// contraction on this path).  step_once = one env.step() in registers; step_kernel = one step per
+// launch, step_k_kernel = K open-loop steps per launch.  Tick and action-ring parity live in device
+// memory (one clock word per tile), so launches are hipGraph-capturable.
 //
 // Reference (paths relative to phoenix_drone_simulation/): envs/physics.py:130-200,
 // envs/agents.py:259-298, envs/control.py:94-100, envs/base.py:303-319,433-475, envs/hover.py,
