@@ -73,6 +73,41 @@ def cpu_baseline(task, kw, n_cpu, target_seconds=12.0):
     return out
 
 
+def measure_traffic(argv_tail, timeout=150):
+    """HBM bytes per launch of pds::step_kernel, measured NOW: two child runs of this very command under
+    `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE need separate passes: MI355X_MICROARCH.md, rocprofv3 PMC slots),
+    corrected as that guide's HBM section prescribes (FETCH_SIZE x2 on gfx950, both counters in KiB).
+    Returns (bytes or None, description)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return None, "rocprofv3 not found"
+    total = 0.0
+    env = dict(os.environ, TMPDIR="/tmp")
+    for counter, scale in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+        out = tempfile.mkdtemp(prefix="pds_pmc_", dir="/tmp")
+        cmd = [rp, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+               "--steps", "30", "--warmup", "5", "--no-cpu-baseline", "--no-traffic"] + argv_tail
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=True)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            vals = [float(r["Counter_Value"]) for f in files for r in csv.DictReader(open(f))
+                    if r.get("Counter_Name") == counter and "step_kernel" in r.get("Kernel_Name", "")]
+            if not vals:
+                return None, f"no {counter} rows for pds::step_kernel"
+            total += sum(vals) / len(vals) * 1024.0 * scale
+        except Exception as e:  # profiler unavailable / refused on this box: the caller falls back to the recorded value
+            return None, f"rocprofv3 --pmc {counter} failed: {type(e).__name__}"
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    return total, ("measured in this run: child passes `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` of the same command "
+                   "(30 steps), FETCH_SIZE x2 (gfx950), KiB -> bytes, mean over the step_kernel dispatches")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,6 +127,8 @@ def main():
                     help="single-policy layout: gather every rank's observations after each step; rccl = "
                          "all_gather_into_tensor, p2p = direct stores into the peers' buffers (sharding.P2PObsGather)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="do not measure roofline.traffic with child rocprofv3 --pmc passes (the children pass this)")
     ap.add_argument("--same-device", action="store_true",
                     help="TEST ONLY: every rank uses cuda:0 and the control collectives run over gloo, so that the "
                          "multi-rank code path (incl. --allgather-obs p2p) can be exercised on a 1-GPU box; "
@@ -238,13 +275,20 @@ def main():
     # HBM bytes per launch measured with the PMC counters (separate rocprofv3 passes,
     # profiles/run_profile.sh) for exactly this workload; null for workloads that were not profiled
     traffic, traffic_src = None, None
-    if args.config == 0 and task == "hover" and n == (1 << 20) and not args.no_auto_reset and args.mode == "eager":
+    if rank == 0 and world == 1 and args.mode == "eager" and not args.no_traffic and not args.no_auto_reset:
+        tail = ["--config", str(args.config), "--task", args.task]
+        if args.envs_per_gpu is not None:
+            tail += ["--envs-per-gpu", str(args.envs_per_gpu)]
+        traffic, traffic_src = measure_traffic(tail)
+    if traffic is None and args.config == 0 and task == "hover" and n == (1 << 20) and not args.no_auto_reset and args.mode == "eager":
+        why = traffic_src
         for name in ("r02_traffic_headline.json", "r01_traffic_headline.json"):
             tf = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tf):
                 traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
                 traffic_src = (f"profiles/{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
-                               "(profiles/run_profile.sh), recorded, NOT measured in this run")
+                               "(profiles/run_profile.sh), recorded, NOT measured in this run"
+                               + (f" ({why})" if why else ""))
                 break
     if rank == 0:
         line = {

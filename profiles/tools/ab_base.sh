@@ -7,7 +7,8 @@ REPS=${2:-3}
 for c in $CFGS; do
   for r in $(seq $REPS); do
     for tree in .ab_base .; do
-      (cd $REPO/$tree && python3 bench.py --config $c --no-cpu-baseline 2>/dev/null | python3 -c "
+      extra=""; [ "$tree" = "." ] && extra="--no-traffic"  # (the round-1 bench.py has no such flag)
+      (cd $REPO/$tree && python3 bench.py --config $c --no-cpu-baseline $extra 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); print('config $c tree %-8s us/step %.2f  kernel %.2f' % ('$tree', d['ms_per_step']*1e3, d['roofline']['avg_launch_ms']*1e3))")
     done

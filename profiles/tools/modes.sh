@@ -2,7 +2,7 @@
 # eager vs hipGraph replay vs pds_step_k for the small-batch configs (launch / latency bound)
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $REPO
-run() { python3 bench.py --no-cpu-baseline "$@" 2>&1 | python3 -c "
+run() { python3 bench.py --no-cpu-baseline --no-traffic "$@" 2>&1 | python3 -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):

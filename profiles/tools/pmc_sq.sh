@@ -3,7 +3,7 @@
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/pmc_sq_${1:-x}
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT -- python3 $REPO/bench.py --steps 30 --warmup 5 --no-cpu-baseline ${BENCH_ARGS:-} > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT -- python3 $REPO/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-traffic ${BENCH_ARGS:-} > /dev/null 2>&1
 cd $REPO && python3 - <<PY
 import csv, glob, collections
 f = glob.glob("$OUT/**/*counter_collection.csv", recursive=True)[0]
