@@ -85,6 +85,43 @@ def test_no_silent_cpu_fallback():
     assert b"no CPU fallback" in pds.native.load().pds_last_error(None)
 
 
+_BAD_CONFIGS = [
+    # (task, overrides, expected code, fragment of pds_last_error)
+    (0, dict(struct_size=8), "EINVAL", b"size mismatch"),
+    (0, dict(num_envs=0), "EINVAL", b"invalid pds_config"),
+    (0, dict(max_episode_steps=70000), "EINVAL", b"invalid pds_config"),
+    (0, dict(num_envs=(1 << 30) + 1), "EINVAL", b"2^30"),
+    (0, dict(env_id_base=-1), "EINVAL", b"global env id range"),
+    (0, dict(env_id_base=(1 << 32) - 4, num_envs=8), "EINVAL", b"global env id range"),
+    (0, dict(device=-1), "EINVAL", b"negative"),
+    (0, dict(control_mode=3), "EINVAL", b"control_mode"),
+    (2, dict(control_mode=1), "EUNSUPPORTED", b"PID modes"),
+    (0, dict(observation_frequency=0), "EINVAL", b"observation_frequency"),
+    (1, dict(observation_frequency=101), "EUNSUPPORTED", b"reference points"),
+    (0, dict(observation_frequency=200), "EINVAL", b"obs_rate 0"),       # base.py:108 would divide by 0
+    (0, dict(observation_frequency=50, use_latency=1), "EUNSUPPORTED", b"Kalman-hold"),
+    (0, dict(observation_frequency=50, control_mode=1), "EUNSUPPORTED", b"Kalman-hold"),
+    (0, dict(use_latency=1, latency=0.10), "EUNSUPPORTED", b"latency"),  # 10 rows > PDS_MAX_LATENCY_STEPS
+    (0, dict(use_latency=1, use_ground_effect=1), "EUNSUPPORTED", b"ground-effect"),
+]
+
+
+@pytest.mark.parametrize("task,over,code,frag", _BAD_CONFIGS)
+def test_create_validates_the_config_before_touching_a_device(task, over, code, frag):
+    """pds_create rejects what the kernels are not built for (or what the reference itself would
+    crash on) with a code and a message; the checks run before any HIP call, so they hold on a
+    machine without a GPU as well."""
+    import phoenix_drone_simulation_amd as pds
+    lib = pds.native.load()
+    cfg = pds.native.default_config(task)
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    h = C.c_void_p()
+    rc = lib.pds_create(C.byref(cfg), C.byref(h))
+    assert rc == getattr(pds.native, code) and not h, (rc, lib.pds_last_error(None))
+    assert frag in lib.pds_last_error(None), lib.pds_last_error(None)
+
+
 def test_product_never_imports_the_oracle():
     """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
     pkg = os.path.join(ROOT, "phoenix-drone-simulation_amd")
