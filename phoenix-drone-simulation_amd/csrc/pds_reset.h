@@ -464,7 +464,12 @@ PDS_DEV void reset_store(const StepArgs &a, const float2 *ref_lds, long long i, 
   if constexpr (V::LAT) {
 #pragma unroll
     for (int b = 0; b < kMaxLatSteps; ++b)
-      if (b < a.k.lat_steps) a.st.lat[(long long)b * a.n + i] = (b == a.k.lat_steps - 1 || b == kMaxLatSteps - 1) ? r.u0 : r.lat.r[b < kMaxLatSteps - 1 ? b : 0];
+      if (b < a.k.lat_steps) {
+        // (by value: a conditional between the two lvalues would select a POINTER and push `r` into scratch memory)
+        float4 v = r.lat.r[b < kMaxLatSteps - 1 ? b : 0];
+        if (b == a.k.lat_steps - 1 || b == kMaxLatSteps - 1) v = r.u0;
+        a.st.lat[(long long)b * a.n + i] = v;
+      }
   }
   if (V::DR) {
     a.st.par0[i] = make_float4(r.par.dt, r.par.m, r.par.Jx, r.par.Jy);

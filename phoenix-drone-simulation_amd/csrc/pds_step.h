@@ -737,7 +737,12 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
           if constexpr (V::LAT) {
 #pragma unroll
             for (int b = 0; b < kMaxLatSteps; ++b)
-              if (b < k.lat_steps) a.st.lat[(long long)b * a.n + i] = (b == k.lat_steps - 1 || b == kMaxLatSteps - 1) ? r.u0 : r.lat.r[b < kMaxLatSteps - 1 ? b : 0];
+              if (b < k.lat_steps) {
+        // (by value: a conditional between the two lvalues would select a POINTER and push `r` into scratch memory)
+        float4 v = r.lat.r[b < kMaxLatSteps - 1 ? b : 0];
+        if (b == k.lat_steps - 1 || b == kMaxLatSteps - 1) v = r.u0;
+        a.st.lat[(long long)b * a.n + i] = v;
+      }
           }
         }
       } else {

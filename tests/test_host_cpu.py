@@ -122,6 +122,27 @@ def test_create_validates_the_config_before_touching_a_device(task, over, code, 
     assert frag in lib.pds_last_error(None), lib.pds_last_error(None)
 
 
+def test_no_hot_kernel_keeps_a_local_object_in_scratch_memory():
+    """Private (scratch) memory beyond the register spills means a local struct was forced into memory
+    (a pointer select or a dynamic index): the latency variants ran at half speed for that in round 2.
+    Read from the code-object metadata of the shipped library (profiles/tools/kernel_resources.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "profiles", "tools"))
+    try:
+        import kernel_resources as kr
+    finally:
+        sys.path.pop(0)
+    if not os.path.exists(kr.READELF):
+        pytest.skip("llvm-readelf not found")
+    rows = kr.kernel_table()
+    hot = [r for r in rows if "step_kernel" in r[0] or "step_k_kernel" in r[0]]
+    assert len(hot) > 100
+    bad = [r for r in hot if kr.forced_scratch(r)]
+    assert not bad, bad[:5]
+    # the four headline-family kernels (Hover, full and half tile) stay within 4 waves per SIMD, spill-free or nearly
+    lean = [r for r in hot if "step_kernel<pds::Variant<0, false, false, false, false, false, 0, false, false>" in r[0]]
+    assert len(lean) == 2 and all(r[1] <= 128 and r[2] <= 8 for r in lean), lean
+
+
 def test_product_never_imports_the_oracle():
     """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
     pkg = os.path.join(ROOT, "phoenix-drone-simulation_amd")
