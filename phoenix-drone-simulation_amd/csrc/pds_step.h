@@ -906,8 +906,16 @@ __global__ __launch_bounds__(kBlock, PDS_MIN_WAVES) void step_kernel(const StepA
 // K env.step()s per launch for open-loop action sequences (pds_step_k): the env state stays in
 // registers, per step only the action (16 B) comes in and the observation row, reward, cost and flags
 // go out -- 4 D + 26 B per env-step instead of 4 D + 178 B, and one launch instead of K.
+// K-step kernel: the state of the env stays in registers across the loop, so the noise variants need more than the
+// 168 VGPRs of 3 blocks per CU (27-74 spilled registers inside the loop); at 2 blocks per CU they spill nothing.
+// Same box, 2^20 envs, K = 8, us per env-step, 3 vs 2: Hover noise + DR 86.1 vs 80.1, + PT1 102.2 vs 83.9, latency
+// ring 116.7 vs 88.7, Circle default 85.3 vs 77.1; TakeOff (hardly any resets) 49.2 vs 53.2 and the noise-free
+// variants 47.4 vs 46.5 / 49.0 vs 49.5 keep 3 (profiles/r02_variant_timings_stepk_minwaves.txt).
+#ifndef PDS_STEPK_MIN_WAVES
+#define PDS_STEPK_MIN_WAVES ((V::ON && V::TASK != PDS_TASK_TAKEOFF) ? 2 : 3)
+#endif
 template <class V>
-__global__ __launch_bounds__(kBlock, 3) void step_k_kernel(const StepArgs a) {
+__global__ __launch_bounds__(kBlock, PDS_STEPK_MIN_WAVES) void step_k_kernel(const StepArgs a) {
   constexpr int TR = kWave;
   constexpr int RM = merged_reset_variant<V>() ? RM_MERGED : RM_INLINE;
 #ifdef PDS_STAMPS

@@ -9,6 +9,7 @@ import phoenix_drone_simulation_amd as pds
 IDS = {"hover": "DroneHoverSimpleEnv-v0", "circle": "DroneCircleSimpleEnv-v0", "takeoff": "DroneTakeOffSimpleEnv-v0"}
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
 STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+K = int(sys.argv[3]) if len(sys.argv) > 3 else 8  # also time pds_step_k with K steps per launch (0: skip)
 OFF = dict(observation_noise=-1, domain_randomization=-1, motor_thrust_noise=0.0)
 CASES = [
     ("hover   lean", "hover", OFF),
@@ -39,5 +40,23 @@ for name, task, kw in CASES:
         torch.cuda.synchronize()
         best = min(best, (time.perf_counter() - t0) / STEPS)
     b = env.bytes_per_env_step
-    print(f"{name:40s} N={N:8d}  {best * 1e6:8.2f} us/step   {b:4d} B/env-step  {100 * b * N / best / 8e12:5.1f} % of 8 TB/s", flush=True)
+    line = f"{name:40s} N={N:8d}  {best * 1e6:8.2f} us/step   {b:4d} B/env-step  {100 * b * N / best / 8e12:5.1f} % of 8 TB/s"
+    if K > 0:
+        ak = torch.stack(acts[:K]) if K <= 8 else torch.stack([acts[j % 8] for j in range(K)])
+        try:
+            for _ in range(5):
+                env.step_k(ak)
+            torch.cuda.synchronize()
+            bk = 1e9
+            for rep in range(3):
+                t0 = time.perf_counter()
+                for _ in range(max(STEPS // K, 4)):
+                    env.step_k(ak)
+                torch.cuda.synchronize()
+                bk = min(bk, (time.perf_counter() - t0) / (max(STEPS // K, 4) * K))
+            kb = env.bytes_per_env_step_k(K)
+            line += f"   | step_k K={K}: {bk * 1e6:7.2f} us/env-step  {kb:4d} B  {100 * kb * N / bk / 8e12:5.1f} %"
+        except NotImplementedError as e:
+            line += f"   | step_k: {e}"
+    print(line, flush=True)
     env.close()
