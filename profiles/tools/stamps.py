@@ -35,6 +35,8 @@ def main():
     elif args.config == 4:
         task, n = "takeoff", 1 << 20
         kw.update(use_ground_effect=True)
+    elif args.config == 6:  # the reference's default env config
+        kw = dict(observation_noise=1, domain_randomization=0.10, motor_thrust_noise=0.05)
     if args.envs:
         n = args.envs
     env_id = {"hover": "DroneHoverSimpleEnv-v0", "circle": "DroneCircleSimpleEnv-v0", "takeoff": "DroneTakeOffSimpleEnv-v0"}[task]
