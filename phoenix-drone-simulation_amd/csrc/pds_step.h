@@ -953,7 +953,10 @@ __global__ __launch_bounds__(kBlock, PDS_STEPK_MIN_WAVES) void step_k_kernel(con
 template <class V>
 inline void launch_variant(int kind, bool half_tile, dim3 grid, hipStream_t s, const StepArgs &a) {
   if (kind == kLaunchReset) {
-    hipLaunchKernelGGL((reset_kernel<V>), grid, dim3(kBlock), 0, s, a);
+    // the reset kernel does not depend on GE / TN / CTRL / HOLD: the launch_* families fold those flags before
+    // they get here, so only the folded variants are instantiated (48 kernels instead of 472)
+    if constexpr (!V::GE && !V::TN && V::CTRL == 0 && !V::HOLD) hipLaunchKernelGGL((reset_kernel<V>), grid, dim3(kBlock), 0, s, a);
+    else abort();
   } else if (kind == kLaunchStepK) {
     // (the PID control modes have no K-step kernel: pds_step_k loops over pds_step for them)
     if constexpr (V::CTRL == 0) hipLaunchKernelGGL((step_k_kernel<V>), grid, dim3(kBlock), 0, s, a);
