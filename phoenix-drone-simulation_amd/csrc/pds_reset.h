@@ -514,6 +514,29 @@ PDS_DEV void reset_store(const StepArgs &a, const float2 *ref_lds, long long i, 
 constexpr int kLanesPerReset = 8;
 constexpr int kResetsPerPass = kWave / kLanesPerReset;
 
+// Philox blocks of up to kResetsPerPass queued envs (lane ids in bits 0..5 of entries[0..cnt)), computed L lanes
+// per env into `scratch` (LdsWords layout, slot s = entry s).  Wave-uniform control flow; the caller fences.
+template <class V>
+PDS_DEV void fill_reset_scratch(const StepArgs &a, const RngKey &rk, const uint32_t *entries, int cnt, int lane,
+                                long long wave_base, U4 *scratch) {
+  constexpr int NB = scratch_blocks_used<V>();
+  constexpr int L = NB <= 8 ? 8 : (NB <= 16 ? 16 : 32);  // lanes per env in a Philox round
+  constexpr int EPR = kWave / L;                           // envs per Philox round
+  const int g = lane / L, j = lane % L;
+  for (int sub = 0; sub < cnt; sub += EPR) {
+    const int slot = sub + g;  // env of the pass this lane computes a block for
+    const bool on = slot < cnt;
+    uint32_t ent = 0;
+    if (on) ent = entries[slot];
+    const uint32_t env_id = (uint32_t)(a.env_id_base + (unsigned long long)(wave_base + (long long)(ent & 63u)));
+    const DirectWords dw(env_id, rk);
+    bool need = false;
+#pragma unroll
+    for (int c = 0; c < NB; ++c) need = need || (c == j && block_needed<V>(c));
+    if (on && need) scratch[slot * kScratchBlocks + j] = dw.scratch_block(j);
+  }
+}
+
 template <class V>
 PDS_DEV void drain_reset_queue(const StepArgs &a, const RngKey &rk, const float2 *ref_lds, const uint32_t *queue,
                                int qcount, int lane, long long wave_base, float *tile) {
@@ -522,29 +545,14 @@ PDS_DEV void drain_reset_queue(const StepArgs &a, const RngKey &rk, const float2
   // reset (~2000 cycles) by the owner lanes.  So: up to 8 envs per pass share ONE reset evaluation, and their
   // Philox blocks are computed L lanes per env (8, 16 or 32 for the 9 / 15 / 22 blocks a variant can need),
   // i.e. in as few rounds as the number of queued envs allows (one round for up to 64 / L envs).
-  constexpr int NB = scratch_blocks_used<V>();
-  constexpr int L = NB <= 8 ? 8 : (NB <= 16 ? 16 : 32);  // lanes per env in a Philox round
-  constexpr int EPR = kWave / L;                           // envs per Philox round
   static_assert(kResetsPerPass * kScratchBlocks * 16 <= kHalfTileRows * V::D * 4, "scratch must fit in the wave's tile");
   U4 *scratch = reinterpret_cast<U4 *>(tile);
-  const int g = lane / L, j = lane % L;
   const int og = lane / kLanesPerReset;  // owner lanes: the first of every 8
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   for (int base = 0; base < qcount; base += kResetsPerPass) {
     const int cnt = min(kResetsPerPass, qcount - base);  // wave-uniform
-    for (int sub = 0; sub < cnt; sub += EPR) {
-      const int slot = sub + g;  // env of the pass this lane computes a block for
-      const bool on = slot < cnt;
-      uint32_t ent = 0;
-      if (on) ent = queue[base + slot];
-      const uint32_t env_id = (uint32_t)(a.env_id_base + (unsigned long long)(wave_base + (long long)(ent & 63u)));
-      const DirectWords dw(env_id, rk);
-      bool need = false;
-#pragma unroll
-      for (int c = 0; c < NB; ++c) need = need || (c == j && block_needed<V>(c));
-      if (on && need) scratch[slot * kScratchBlocks + j] = dw.scratch_block(j);
-    }
+    fill_reset_scratch<V>(a, rk, queue + base, cnt, lane, wave_base, scratch);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

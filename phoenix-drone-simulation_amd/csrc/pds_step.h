@@ -406,6 +406,13 @@ enum { RM_MERGED = 0, RM_DEFERRED = 1, RM_INLINE = 2 };
 // the pointers are formed where they are used so that the kernel arguments are not held in SGPRs
 // across the whole step).  Returns true for a lane whose env was reset in registers (RM_MERGED /
 // RM_INLINE).
+// Inline reset of the K-step kernel: cooperative Philox through an LDS scratch (see step_once), except TakeOff.
+template <class V>
+constexpr bool inline_coop_variant() { return V::TASK != PDS_TASK_TAKEOFF; }
+// envs per pass: the scratch of the noise-free latency variants has to leave room for 3 blocks per CU
+template <class V>
+constexpr int inline_envs_per_pass() { return V::ON ? kResetsPerPass : kResetsPerPass / 2; }
+
 template <class V, int TR, int RM, bool STORE>
 PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, int parity, const float2 *ref_lds,
                        float *tile, uint32_t *queue, U4 *scratch, int lane, long long wave_base, long long i, long long ii,
@@ -705,14 +712,17 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
     }
     if (RM != RM_DEFERRED && reset_mask != 0ull) {  // wave-uniform: the reset envs' rows become [o0, u0, o0', u0]
       if constexpr (RM == RM_INLINE) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();  // every final_obs row has left the tile
-        if (need_reset) {
+        // TakeOff ends episodes by truncation only, i.e. all 64 envs of a wave at once every 500 steps: there every
+        // lane computes its own Philox blocks (DirectWords) and the reset is evaluated once for the whole wave.
+        // Elsewhere 1-3 % of the envs finish per step: the Philox blocks of the finished envs (5-22 per env, ~650
+        // cycles each when one lane computes them in a row) are computed side by side by the whole wave into an
+        // LDS scratch, kInlineEnvs envs per pass like the drain; the reset itself is evaluated by the lanes that
+        // own the envs, so the fresh state stays in registers.
+        auto evaluate = [&](const auto &dw) {
           was_reset = true;
           const float stale_w[3] = {e.wx, e.wy, e.wz};
           const float bias[3] = {ns.bias[0], ns.bias[1], ns.bias[2]};
           ResetOut r;
-          const DirectWords dw(env_id, rk);
           reset_compute<V>(a, ref_lds, dw, ctr_pack(0u, 0u, (uint32_t)ref_offset), nullptr, stale_w, bias, r);
           e = r.e;
           S.ctr = r.ctr;
@@ -738,11 +748,34 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
 #pragma unroll
             for (int b = 0; b < kMaxLatSteps; ++b)
               if (b < k.lat_steps) {
-        // (by value: a conditional between the two lvalues would select a POINTER and push `r` into scratch memory)
-        float4 v = r.lat.r[b < kMaxLatSteps - 1 ? b : 0];
-        if (b == k.lat_steps - 1 || b == kMaxLatSteps - 1) v = r.u0;
-        a.st.lat[(long long)b * a.n + i] = v;
-      }
+                // (by value: a conditional between the two lvalues would select a POINTER and push `r` into scratch memory)
+                float4 v = r.lat.r[b < kMaxLatSteps - 1 ? b : 0];
+                if (b == k.lat_steps - 1 || b == kMaxLatSteps - 1) v = r.u0;
+                a.st.lat[(long long)b * a.n + i] = v;
+              }
+          }
+        };
+        if constexpr (!inline_coop_variant<V>()) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();  // every final_obs row has left the tile
+          if (need_reset) evaluate(DirectWords(env_id, rk));
+        } else {
+          constexpr int IE = inline_envs_per_pass<V>();
+          const int count = __popcll(reset_mask);
+          const int pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(reset_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)reset_mask, 0u));
+          if (need_reset) queue[pos] = (uint32_t)lane;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();  // every final_obs row has left the tile; the queue is complete
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          for (int base = 0; base < count; base += IE) {
+            const int cnt = min(IE, count - base);  // wave-uniform
+            fill_reset_scratch<V>(a, rk, queue + base, cnt, lane, wave_base, scratch);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (need_reset && pos >= base && pos < base + cnt) evaluate(LdsWords{scratch + (pos - base) * kScratchBlocks});
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();  // the scratch is refilled by the next pass
           }
         }
       } else {
@@ -835,8 +868,9 @@ PDS_DEV void prefetch_kernargs() {
   __shared__ __attribute__((aligned(16))) float tile_all[(kBlock / kWave) * TR * tile_stride<V::D>()]; \
   __shared__ float2 ref_lds[(V::TASK == PDS_TASK_CIRCLE) ? kRefPoints : 1];                           \
   __shared__ uint32_t queue_all[(kBlock / kWave) * kQueueCap];                                        \
-  __shared__ U4 scratch_all[(RM == RM_MERGED) ? (kBlock / kWave) * kMergedScratchU4 : 1];             \
-  U4 *scratch = scratch_all + ((RM == RM_MERGED) ? (threadIdx.x >> 6) * kMergedScratchU4 : 0);        \
+  constexpr int kScratchU4_ = (RM == RM_MERGED) ? kMergedScratchU4 : ((RM == RM_INLINE && inline_coop_variant<V>()) ? inline_envs_per_pass<V>() * kScratchBlocks : 0); \
+  __shared__ U4 scratch_all[kScratchU4_ > 0 ? (kBlock / kWave) * kScratchU4_ : 1];                     \
+  U4 *scratch = scratch_all + (threadIdx.x >> 6) * kScratchU4_;                                        \
   const int tid = threadIdx.x;                                                                         \
   const int lane = tid & (kWave - 1);                                                                  \
   const int wave = tid >> 6;                                                                           \
