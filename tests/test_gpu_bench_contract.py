@@ -50,3 +50,21 @@ def test_bench_multi_rank_code_path_on_one_gpu():
     assert d["n_gpus"] == 2 and len(d["per_rank_ms_per_step"]) == 2 and d["allgather_ms"] > 0
     assert "cpu_baseline" not in d and "p2p" in d["config"]["parallelism"]
     assert abs(d["value"] - 2 * 65536 * 20 / (d["ms_per_step"] * 20e-3)) < 1e-6 * d["value"]
+
+
+@pytest.mark.parametrize("mode,steps,warmup", [("graph", 128, 64), ("stepk", 64, 16)])
+def test_bench_diagnostic_modes(mode, steps, warmup):
+    """--mode graph (64 captured steps per replay) / stepk (K = 8 steps per launch): same env-steps, fewer
+    launches; the JSON line keeps its shape and says which mode produced it."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", str(warmup),
+                          "--envs-per-gpu", "65536", "--mode", mode, "--no-cpu-baseline", "--no-traffic"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][0])
+    assert d["steps"] == steps and d["n_gpus"] == 1 and d["roofline"]["mode"] == mode
+    assert abs(d["value"] - 65536 * steps / (d["ms_per_step"] * steps * 1e-3)) < 1e-6 * d["value"]
+    assert 0 < d["roofline"]["frac"] < 1
+    # a step count that the mode cannot time exactly is refused, not rounded
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "30", "--warmup", "5", "--envs-per-gpu", "65536",
+                          "--mode", mode, "--no-cpu-baseline", "--no-traffic"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert bad.returncode != 0 and "multiples" in (bad.stderr + bad.stdout)
