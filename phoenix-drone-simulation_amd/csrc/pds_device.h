@@ -117,8 +117,9 @@ PDS_DEV U4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32
 
 // Both variants in ONE instruction stream: lanes with `seven` keep the state after round 7, the others
 // after round 10.  (A wave whose lanes compute different blocks side by side would otherwise run the
-// 10-round and the 7-round code one after the other: the 32-bit multiplies are quarter rate, ~64 cycles of
-// the wave's VALU time per round whatever the number of active lanes.)
+// 10-round and the 7-round code one after the other: a round is ~14 vector instructions, ~60 cycles of the
+// wave's VALU time whatever the number of active lanes; v_mul_lo/hi_u32 issue at the v_fma_f32 rate on gfx950,
+// profiles/r02_valu_issue.txt.)
 PDS_DEV U4 philox4x32_10_or_7(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, bool seven) {
   U4 at7{0u, 0u, 0u, 0u};
 #pragma unroll

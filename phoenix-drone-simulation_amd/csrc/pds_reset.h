@@ -541,7 +541,7 @@ template <class V>
 PDS_DEV void drain_reset_queue(const StepArgs &a, const RngKey &rk, const float2 *ref_lds, const uint32_t *queue,
                                int qcount, int lane, long long wave_base, float *tile) {
   // Two costs per pass, both paid by the whole wave whatever the number of active lanes: one Philox (~650
-  // cycles: quarter-rate 32-bit multiplies) per round of block computations, and one evaluation of the
+  // cycles: 10 rounds x ~14 vector instructions) per round of block computations, and one evaluation of the
   // reset (~2000 cycles) by the owner lanes.  So: up to 8 envs per pass share ONE reset evaluation, and their
   // Philox blocks are computed L lanes per env (8, 16 or 32 for the 9 / 15 / 22 blocks a variant can need),
   // i.e. in as few rounds as the number of queued envs allows (one round for up to 64 / L envs).
@@ -604,7 +604,7 @@ PDS_DEV void reset_in_registers(const StepArgs &a, const RngKey &rk, const float
                                 int count, bool mine, int pos, int lane, long long wave_base, int ref_offset,
                                 U4 *scratch, EnvRegs &e, Quat &q, float4 &u0, float4 &mx, Params &par, uint32_t &ctr) {
   static_assert(!V::ON && !V::LAT, "observation-noise / latency variants use the deferred drain or the inline reset");
-  // One Philox4x32-10 block costs ~650 cycles of the wave's VALU time (40 quarter-rate 32-bit multiplies),
+  // One Philox4x32-10 block costs ~650 cycles of the wave's VALU time (10 rounds x ~14 vector instructions),
   // however many lanes compute one -- so all blocks of a pass are computed side by side: 8 envs x 8 blocks,
   // or, for the variants that need a ninth block (PT1 + DR), 4 envs x 8 blocks on lanes 0..31 and the ninth
   // blocks of those 4 envs on lanes 32, 40, 48, 56 (a second round if more than 4 envs finished); the reset
