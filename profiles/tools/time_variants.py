@@ -23,6 +23,14 @@ CASES = [
     ("takeoff ge on dr tn", "takeoff", dict(use_ground_effect=True)),
     ("hover   latency 0.02 on dr tn", "hover", dict(use_latency=True, latency=0.02)),
     ("hover   obs 50 Hz on dr tn", "hover", dict(observation_frequency=50)),
+    ("hover   AttitudeRate PID lean", "hover", dict(OFF, control_mode="AttitudeRate")),
+    ("hover   Attitude PID lean", "hover", dict(OFF, control_mode="Attitude")),
+    ("hover   Attitude PID on dr tn", "hover", dict(control_mode="Attitude")),
+    ("circle  AttitudeRate PID pt1 dr on tn", "circle", dict(control_mode="AttitudeRate", use_motor_dynamics=True)),
+    ("hover   latency 0.02 lean", "hover", dict(OFF, use_latency=True, latency=0.02)),
+    ("circle  latency 0.03 pt1 dr on tn", "circle", dict(use_latency=True, latency=0.03, use_motor_dynamics=True)),
+    ("hover   agg 2 lean", "hover", dict(OFF, aggregate_phy_steps=2)),
+    ("hover   agg 2 on dr tn", "hover", dict(aggregate_phy_steps=2)),
 ]
 g = torch.Generator(device="cuda").manual_seed(0)
 acts = [(-0.1 + 0.25 * torch.randn(N, 4, device="cuda", generator=g)).contiguous() for _ in range(8)]
