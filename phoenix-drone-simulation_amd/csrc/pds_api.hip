@@ -743,7 +743,7 @@ extern "C" int pds_step_with_variates(pds_handle *h, const float *d_actions, con
   // from the half tile: it wins up to 5 blocks per CU there, up to 8 for the others; profiles/r01_tile_rows.txt)
   const bool merged = !lf.on && !lf.lat && !(lf.motor && lf.dr) && h->cfg.task != PDS_TASK_TAKEOFF && h->cfg.auto_reset;
   const unsigned cus = (unsigned)h->num_cus;
-  lf.half_tile = grid.x > (unsigned)kFullTileBlocksPerCU * cus && grid.x <= (merged ? 5u : 8u) * cus;
+  lf.half_tile = grid.x > (unsigned)kFullTileBlocksPerCU * cus * (256 / kBlock) && grid.x <= (merged ? 5u : 8u) * cus * (256 / kBlock);
   if (h->force_tile) lf.half_tile = h->force_tile == 1;
   if (lf.on || lf.lat) lf.half_tile = false;  // (no half-tile instantiation)
   launch_family(h, kLaunchStep, lf, grid, (hipStream_t)stream, a);

@@ -910,7 +910,7 @@ PDS_DEV void prefetch_kernargs() {
 #endif
 
 template <class V, int TR>
-__global__ __launch_bounds__(kBlock, PDS_MIN_WAVES) void step_kernel(const StepArgs a) {
+__global__ __launch_bounds__(kBlock, (PDS_MIN_WAVES) * (256 / kBlock)) void step_kernel(const StepArgs a) {
   PDS_STAMP_DECL
   prefetch_kernargs();
   constexpr int RM = merged_reset_variant<V, TR>() ? RM_MERGED : RM_DEFERRED;
@@ -949,7 +949,7 @@ __global__ __launch_bounds__(kBlock, PDS_MIN_WAVES) void step_kernel(const StepA
 #define PDS_STEPK_MIN_WAVES ((V::ON && V::TASK != PDS_TASK_TAKEOFF) ? 2 : 3)
 #endif
 template <class V>
-__global__ __launch_bounds__(kBlock, PDS_STEPK_MIN_WAVES) void step_k_kernel(const StepArgs a) {
+__global__ __launch_bounds__(kBlock, (PDS_STEPK_MIN_WAVES) * (256 / kBlock)) void step_k_kernel(const StepArgs a) {
   constexpr int TR = kWave;
   constexpr int RM = merged_reset_variant<V>() ? RM_MERGED : RM_INLINE;
 #ifdef PDS_STAMPS
