@@ -506,11 +506,11 @@ PDS_DEV void reset_store(const StepArgs &a, const float2 *ref_lds, long long i, 
 // Pass over the envs a wave queued for auto-reset (queue entry = lane of the env in the wave's tile | ref_offset << 6).
 // Groups of 8 lanes serve one queued env: every lane computes one (or a few) of the env's Philox
 // blocks into an LDS scratch (the wave's observation tile, free after its flush), then the group's
-// first lane assembles the sample from the scratch and finishes the reset.  Without observation
-// noise the arithmetic touches no global memory, so it overlaps with the wave's outstanding stores;
-// those must have completed (s_waitcnt vmcnt(0)) before the same addresses are overwritten.  With
-// observation noise the reset needs the terminal body rates and the gyro bias the wave has just
-// stored, so the wait comes first.
+// first lane assembles the sample from the scratch and finishes the reset.  The arithmetic touches no
+// global memory, so it overlaps with the wave's outstanding stores; those must have completed
+// (s_waitcnt vmcnt(0)) before the same addresses are overwritten.  (With observation noise the reset
+// needs the terminal body rates and the gyro bias of the env: they come out of the registers of the
+// lane that stepped it, by ds_bpermute, not back from memory.)
 constexpr int kLanesPerReset = 8;
 constexpr int kResetsPerPass = kWave / kLanesPerReset;
 
@@ -539,7 +539,8 @@ PDS_DEV void fill_reset_scratch(const StepArgs &a, const RngKey &rk, const uint3
 
 template <class V>
 PDS_DEV void drain_reset_queue(const StepArgs &a, const RngKey &rk, const float2 *ref_lds, const uint32_t *queue,
-                               int qcount, int lane, long long wave_base, float *tile) {
+                               int qcount, int lane, long long wave_base, float *tile, const float (&own_w)[3],
+                               const float (&own_bias)[3]) {
   // Two costs per pass, both paid by the whole wave whatever the number of active lanes: one Philox (~650
   // cycles: 10 rounds x ~14 vector instructions) per round of block computations, and one evaluation of the
   // reset (~2000 cycles) by the owner lanes.  So: up to 8 envs per pass share ONE reset evaluation, and their
@@ -563,19 +564,19 @@ PDS_DEV void drain_reset_queue(const StepArgs &a, const RngKey &rk, const float2
     ResetOut r;
     float stale_w[3] = {0.f, 0.f, 0.f}, bias[3] = {0.f, 0.f, 0.f};
     if (V::ON) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (owner) {
-        const float4 q2 = a.st.s2[i];
-        const float4 nz = a.st.nz0[i];
-        stale_w[0] = q2.y; stale_w[1] = q2.z; stale_w[2] = q2.w;
-        bias[0] = nz.x; bias[1] = nz.y; bias[2] = nz.z;
-      }
+      // the gyro rates and the gyro bias the finished env had after this step (the reference re-initialises the
+      // low-pass with them): out of the registers of the lane that stepped it -- they are what that lane has
+      // just stored, and reading them back from memory would put a wait for the wave's stores and a load in
+      // front of the evaluation
+      const int src = (int)(ent & 63u);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { stale_w[j] = __shfl(own_w[j], src); bias[j] = __shfl(own_bias[j], src); }
     }
     if (owner) {
       const LdsWords lw{scratch + og * kScratchBlocks};
       reset_compute<V>(a, ref_lds, lw, ctr_pack(0u, 0u, ent >> 6), nullptr, stale_w, bias, r);
     }
-    if (!V::ON) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (owner) reset_store<V>(a, ref_lds, i, r);
     __builtin_amdgcn_wave_barrier();  // scratch is refilled by the next pass
   }

@@ -931,7 +931,10 @@ __global__ __launch_bounds__(kBlock, (PDS_MIN_WAVES) * (256 / kBlock)) void step
   unpack_state<V>(a.k, cur, parity, S);
   int qcount = 0;  // wave-uniform
   step_once<V, TR, RM, true>(a, 0ll, rk, parity, ref_lds, tile, queue, scratch, lane, wave_base, i, ii, active, cur.act, S, qcount PDS_STAMP_ARG);
-  if (RM == RM_DEFERRED && qcount > 0) drain_reset_queue<V>(a, rk, ref_lds, queue, qcount, lane, wave_base, tile);
+  if (RM == RM_DEFERRED && qcount > 0) {
+    const float own_w[3] = {S.e.wx, S.e.wy, S.e.wz};
+    drain_reset_queue<V>(a, rk, ref_lds, queue, qcount, lane, wave_base, tile, own_w, S.ns.bias);
+  }
   PDS_STAMP(6);
   advance_clock(a.st.clk, t, rk, parity ^ 1, 1u, lane);
   PDS_STAMP_FLUSH;
