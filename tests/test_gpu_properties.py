@@ -315,3 +315,36 @@ def test_device_philox_known_answers():
             o = (C.c_uint32 * 4)()
             L.po_philox4x32((C.c_uint32 * 4)(*[int(v) for v in ctr[j]]), (C.c_uint32 * 2)(*[int(v) for v in key[j]]), rounds, o)
             assert [int(v) for v in o] == [int(v) for v in out[j]]
+
+
+def test_fresh_outputs_are_not_overwritten():
+    """fresh_outputs=True: step() hands out newly allocated tensors like the reference's fresh arrays
+    (envs/base.py:311); the default alternates two env-owned buffer sets (an observation survives ONE further
+    step).  Same numbers either way, and a masked reset leaves the other envs' last observation in place."""
+    import phoenix_drone_simulation_amd as pds
+    N = 1000
+    kw = dict(num_envs=N, seed=3, observation_noise=-1, domain_randomization=-1, motor_thrust_noise=0.0)
+    a = pds.make("DroneHoverSimpleEnv-v0", **kw)
+    b = pds.make("DroneHoverSimpleEnv-v0", fresh_outputs=True, **kw)
+    oa, _ = a.reset()
+    ob, _ = b.reset()
+    assert torch.equal(oa, ob)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    kept_a, kept_b, kept_ref = [], [], []
+    for t in range(5):
+        act = (-0.1 + 0.2 * torch.randn(N, 4, device="cuda", generator=g))
+        ra, rb = a.step(act), b.step(act)
+        assert torch.equal(ra[0], rb[0]) and torch.equal(ra[1], rb[1]) and torch.equal(ra[2], rb[2])
+        done = ra[2] | ra[3]  # final_obs rows are defined where an env finished in this step
+        assert torch.equal(ra[4]["final_obs"][done], rb[4]["final_obs"][done])
+        kept_a.append(ra[0]); kept_b.append(rb[0]); kept_ref.append(ra[0].clone())
+    assert all(torch.equal(x, y) for x, y in zip(kept_b, kept_ref))          # fresh: every step's tensor is intact
+    assert kept_a[0].data_ptr() == kept_a[2].data_ptr() == kept_a[4].data_ptr()  # default: two alternating sets
+    assert len({x.data_ptr() for x in kept_b}) == 5
+    mask = torch.zeros(N, dtype=torch.uint8, device="cuda"); mask[::7] = 1
+    last = kept_b[-1].clone()
+    om, _ = b.reset(mask=mask)
+    keep = ~mask.bool()
+    assert torch.equal(om[keep], last[keep]) and not torch.equal(om[mask.bool()], last[mask.bool()])
+    assert torch.equal(kept_b[-1], last)  # ... and the tensor handed out earlier was not written to
+    a.close(); b.close()
