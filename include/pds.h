@@ -266,6 +266,15 @@ const char *pds_last_error(const pds_handle *h);
  * against the Random123 known-answer vectors.  Runs on the current device. */
 int pds_philox4x32(const uint32_t *d_ctr, const uint32_t *d_key, int rounds, int64_t n, uint32_t *d_out, void *stream);
 
+/* observation_history_size = H other than 2 (envs/base.py:44, 303-319, 417-431): advances the [N, H, half]
+ * history of every env by the step's new row `d_obs2` [N, 2 * half] (the pds_step output) in one launch.
+ * Running envs: hist' = [hist[1:], newest half].  Finished envs (auto_reset != 0): their final history
+ * [hist[1:], newest half of d_final_obs2] goes to d_final_hist (rows of other envs untouched; may be NULL) and
+ * hist' = [H - 1 copies of the reset row's first half, its second half].  d_hist_out must not alias d_hist_in. */
+int pds_history_advance(int64_t n, int half, int history, const float *d_obs2, const uint8_t *d_terminated,
+                        const uint8_t *d_truncated, const float *d_final_obs2, int auto_reset, const float *d_hist_in,
+                        float *d_hist_out, float *d_final_hist, void *stream);
+
 /* ---- caller-side helper: GAE over a lockstep rollout ----------------------
  * Replaces core.Buffer.finish_path / calculate_adv_and_value_targets (algs/core.py:461-533, one
  * scipy lfilter per finished path) for a [T, N] rollout: d_rew, d_val [T,N] f32; d_terminated,

@@ -167,6 +167,7 @@ class DroneVecEnv:
             self.obs_dim = self.observation_history_size * self._half
             self._hist = torch.zeros(self.num_envs, self.observation_history_size, self._half,
                                      dtype=torch.float32, device=self.device)
+        self._hist_sets = None
         self._auto_reset = bool(auto_reset)
         self.act_dim = 4
         o_lim = 1000 * np.ones((self.obs_dim,), dtype=np.float32)  # envs/base.py:147-150
@@ -280,21 +281,49 @@ class DroneVecEnv:
         return self._hist.reshape(self.num_envs, -1)
 
     def _advance_history(self, ret):
+        """One launch of pds_history_advance (csrc/pds_history.hip): shift the [N, H, half] history by the
+        step's newest half, write the final history of the envs that finished and restart theirs from the reset
+        row.  Like step()'s other outputs the returned tensors alternate between two env-owned sets (or are
+        newly allocated with fresh_outputs=True); info['final_obs'] rows are defined where an env finished
+        (without auto-reset it is the returned observation itself)."""
         obs2, reward, term, trunc, info = ret
-        half, N = self._half, self.num_envs
+        N, H, half = self.num_envs, self.observation_history_size, self._half
+        if self._fresh:
+            out = torch.empty_like(self._hist)
+            fin = torch.zeros_like(self._hist) if self._auto_reset else None
+        else:
+            if self._hist_sets is None:
+                self._hist_sets = [(torch.empty_like(self._hist), torch.zeros_like(self._hist) if self._auto_reset else None)
+                                   for _ in range(2)]
+                self._hist_flip = 0
+            self._hist_flip ^= 1
+            out, fin = self._hist_sets[self._hist_flip]
+            if out.data_ptr() == self._hist.data_ptr():  # (after a reset() replaced self._hist with one of the sets)
+                self._hist_flip ^= 1
+                out, fin = self._hist_sets[self._hist_flip]
+        rc = self.lib.pds_history_advance(N, half, H, obs2.data_ptr(), term.data_ptr(), trunc.data_ptr(),
+                                          info["final_obs"].data_ptr() if self._auto_reset else None,
+                                          int(self._auto_reset), self._hist.data_ptr(), out.data_ptr(),
+                                          fin.data_ptr() if fin is not None else None, self._raw_stream())
+        if rc != 0:
+            native.check(self._handle, rc, "pds_history_advance")
+        self._hist = out
+        flat = out.reshape(N, -1)
+        final = fin.reshape(N, -1) if fin is not None else flat
+        return (flat, reward, term, trunc, {"cost": info["cost"], "final_obs": final, "final_observation": final})
+
+    def _advance_history_torch(self, hist, ret):
+        """The same update written with torch ops (the pre-round-2 implementation; tests compare the kernel with it).
+        Returns (new history [N, H, half], final history [N, H, half])."""
+        obs2, reward, term, trunc, info = ret
+        half = self._half
         done = (term | trunc)[:, None]
         new = obs2[:, half:]
-        # newest half of the observation the reference returns for this step: the terminal one for an
-        # env that finished (the kernel has already reset it; its last observation is in final_obs)
         newest = torch.where(done, info["final_obs"][:, half:], new) if self._auto_reset else new
-        final_hist = torch.cat([self._hist[:, 1:], newest[:, None]], 1)
+        final_hist = torch.cat([hist[:, 1:], newest[:, None]], 1)
         if self._auto_reset:
-            self._hist = torch.where(done[:, :, None], self._reset_rows(obs2), final_hist)
-        else:
-            self._hist = final_hist
-        return (self._hist.reshape(N, -1), reward, term, trunc,
-                {"cost": info["cost"], "final_obs": final_hist.reshape(N, -1),
-                 "final_observation": final_hist.reshape(N, -1)})
+            return torch.where(done[:, :, None], self._reset_rows(obs2), final_hist), final_hist
+        return final_hist, final_hist
 
     def step(self, action, noise_variates=None):
         """env.step(action).  The returned tensors are OWNED by the env: two buffer sets alternate, so the

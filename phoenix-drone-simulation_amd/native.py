@@ -34,7 +34,7 @@ EXPORTS = ["pds_version", "pds_default_config", "pds_create", "pds_destroy", "pd
            "pds_field_width",
            "pds_get_state", "pds_set_state", "pds_tick", "pds_set_tick", "pds_sync_tick", "pds_count_nonfinite",
            "pds_bytes_per_env_step", "pds_bytes_per_env_step_k", "pds_last_error", "pds_step_k", "pds_set_latency",
-           "pds_latency_steps", "pds_philox4x32", "pds_gae",
+           "pds_latency_steps", "pds_philox4x32", "pds_gae", "pds_history_advance",
            "pds_mlp_param_count", "pds_mlp_workspace_floats", "pds_mlp_forward", "pds_ppo_policy_grad",
            "pds_value_grad", "pds_gaussian_sample", "pds_gaussian_sample_dev", "pds_counter_add", "pds_rollout_record",
            "pds_adam_step"]
@@ -114,6 +114,7 @@ def load():
     lib.pds_last_error.argtypes = [vp]
     lib.pds_last_error.restype = C.c_char_p
     lib.pds_gae.argtypes = [vp] * 6 + [C.c_float] * 4 + [i64, i64] + [vp] * 4
+    lib.pds_history_advance.argtypes = [i64, C.c_int, C.c_int] + [vp] * 4 + [C.c_int] + [vp] * 4
     mp = C.POINTER(Mlp)
     lib.pds_mlp_param_count.argtypes = [mp]
     lib.pds_mlp_workspace_floats.argtypes = [mp]

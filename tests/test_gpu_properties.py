@@ -348,3 +348,36 @@ def test_fresh_outputs_are_not_overwritten():
     assert torch.equal(om[keep], last[keep]) and not torch.equal(om[mask.bool()], last[mask.bool()])
     assert torch.equal(kept_b[-1], last)  # ... and the tensor handed out earlier was not written to
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("task,H,auto_reset,noise", [("hover", 1, True, False), ("hover", 4, True, False), ("circle", 3, True, False),
+                                                      ("takeoff", 8, True, False), ("hover", 6, False, False), ("hover", 4, True, True)])
+def test_history_kernel_equals_the_torch_composition(task, H, auto_reset, noise):
+    """observation_history_size != 2: pds_history_advance (one launch per step) against the same update written
+    with torch.cat / torch.where, bit for bit, over steps with auto-resets (ragged N, final histories on the
+    rows of the envs that finished)."""
+    import phoenix_drone_simulation_amd as pds
+    N = 1000
+    kw = dict(DET) if not noise else dict(observation_noise=1, domain_randomization=0.1, motor_thrust_noise=0.05)
+    env = pds.make(ENV_ID[task], num_envs=N, seed=11, observation_history_size=H, auto_reset=auto_reset,
+                   max_episode_steps=23, **kw)
+    obs, _ = env.reset()
+    half = env._half
+    assert obs.shape == (N, H * half)
+    hist = env._hist.clone()
+    finished = 0
+    for t in range(40):
+        act = _actions(N, env.device, 100 + t) + 0.3 * torch.randn(N, 4, device=env.device)
+        o, r, te, tr, info = env.step(act)
+        raw = env._bufs[env._flip]["_ret"]  # the kernel's own [o(k-1), u(k-2), o(k), u(k-1)] row of this step
+        want, want_final = env._advance_history_torch(hist, raw)
+        assert torch.equal(o, want.reshape(N, -1)), t
+        done = te | tr
+        if auto_reset:
+            assert torch.equal(info["final_obs"][done], want_final.reshape(N, -1)[done]), t
+            finished += int(done.sum())
+        else:
+            assert info["final_obs"].data_ptr() == o.data_ptr()
+        hist = want
+    assert (not auto_reset) or finished > N // 2
+    env.close()
