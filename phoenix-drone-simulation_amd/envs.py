@@ -17,6 +17,7 @@ Differences that follow from batching (documented in INTEGRATION.md):
 All computation happens in libpds_hip.so (HIP, gfx950); there is no CPU path here.
 """
 import ctypes as C
+import sys
 
 import numpy as np
 import torch
@@ -405,8 +406,12 @@ class DroneVecEnv:
             self._handle = C.c_void_p()
 
     def __del__(self):
+        # At interpreter shutdown the HIP runtime (and a profiler's tool library) may already be tearing down:
+        # freeing device memory from here was seen to hang a process under rocprofv3.  The driver reclaims the
+        # memory with the process; only a collected env of a live interpreter is destroyed here.
         try:
-            self.close()
+            if not sys.is_finalizing():
+                self.close()
         except Exception:
             pass
 
