@@ -81,6 +81,7 @@ def measure_traffic(argv_tail, timeout=90):
     import csv
     import glob
     import shutil
+    import signal
     import subprocess
     import tempfile
     rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
@@ -95,7 +96,21 @@ def measure_traffic(argv_tail, timeout=90):
         cmd = [rp, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
                "--steps", "30", "--warmup", "5", "--no-cpu-baseline", "--no-traffic"] + argv_tail
         try:
-            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=True)
+            # own session: a timeout must take down rocprofv3 AND the python grandchild that holds the GPU
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                                    start_new_session=True)
+            try:
+                _, err = proc.communicate(timeout=timeout)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                proc.wait()
+                return None, f"rocprofv3 --pmc {counter}: timed out after {timeout} s (process group killed)"
+            if proc.returncode != 0:
+                tail = (err or b"").decode("utf-8", "replace").strip().splitlines()[-3:]
+                return None, f"rocprofv3 --pmc {counter} exited with {proc.returncode}: {' | '.join(tail)[-300:]}"
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             vals = [float(r["Counter_Value"]) for f in files for r in csv.DictReader(open(f))
                     if r.get("Counter_Name") == counter and "step_kernel" in r.get("Kernel_Name", "")]
@@ -103,11 +118,25 @@ def measure_traffic(argv_tail, timeout=90):
                 return None, f"no {counter} rows for pds::step_kernel"
             total += sum(vals) / len(vals) * 1024.0 * scale
         except Exception as e:  # profiler unavailable / refused on this box: the caller falls back to the recorded value
-            return None, f"rocprofv3 --pmc {counter} failed: {type(e).__name__}"
+            return None, f"rocprofv3 --pmc {counter} failed: {type(e).__name__}: {e}"
         finally:
             shutil.rmtree(out, ignore_errors=True)
     return total, ("measured in this run: child passes `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` of the same command "
                    "(30 steps), FETCH_SIZE x2 (gfx950), KiB -> bytes, mean over the step_kernel dispatches")
+
+
+def self_launch(n):
+    import socket
+    import subprocess
+    with socket.socket() as sk:  # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL / HIP IPC across processes on this driver)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -137,6 +166,13 @@ def main():
                          "the numbers of such a run mean nothing")
     ap.add_argument("--no-auto-reset", action="store_true", help="diagnostic only: INVALID as a benchmark number")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # No launcher around us: start the N ranks ourselves (the role of the reference's mpi_fork,
+        # utils/mpi_tools.py:47-99) -- as a CHILD torch.distributed.run, before this process has imported
+        # anything that touches the GPU; never exec from here.  The child ranks print the JSON line; this
+        # process relays stdout and the exit code.
+        sys.exit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -196,13 +232,15 @@ def main():
     if gather_mode == "p2p":
         ctl = dist.new_group(backend="gloo")  # host-side hand-shake of the P2P gather (IPC handles, per-step barrier)
         p2p = pds.P2PObsGather(n, env.obs_dim, dev, sync_group=ctl)
-        gathered = p2p.out
 
     def do_gather(obs):
+        """-> the [world * n, D] observations of all ranks (valid until the next call)"""
         if gather_mode == "rccl":
             dist.all_gather_into_tensor(gathered, obs)
-        elif gather_mode == "p2p":
-            p2p.gather(obs)
+            return gathered
+        if gather_mode == "p2p":
+            return p2p.gather(obs)
+        return None
 
     def one_step(s):
         out = env.step(ring[s % T])
@@ -241,6 +279,8 @@ def main():
         torch.cuda.synchronize()
 
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # torch creates the HIP event at its first record(): do that outside the timed region
+    ev0.record(); ev1.record()
     sync()
     t0 = time.perf_counter()
     ev0.record()  # same stream pds_step launches on (torch's current stream)
@@ -260,6 +300,16 @@ def main():
         if gather_mode is not None:  # the exchange alone, same buffers, timed separately (not part of `value`)
             reps = max(4, min(50, args.steps // 4))
             last = env.step(ring[0])[0]
+            # the exchange is checked once, outside the timed region: this rank's rows and a peer's rows of
+            # the gathered buffer against what the owners computed (the peer's block over the control group)
+            full = do_gather(last)
+            peer = torch.empty_like(last)
+            blocks = [torch.empty_like(last, device=cdev) for _ in range(world)]
+            dist.all_gather(blocks, last.to(cdev))
+            nxt = (rank + 1) % world
+            peer.copy_(blocks[nxt])
+            if not (torch.equal(full[rank * n:(rank + 1) * n], last) and torch.equal(full[nxt * n:(nxt + 1) * n], peer)):
+                raise SystemExit(f"rank {rank}: gathered observations differ from the owners' blocks")
             sync()
             t1 = time.perf_counter()
             for _ in range(reps):

@@ -149,11 +149,14 @@ enum pds_field {
 
 /* Layout of one row of `d_variates` for pds_step_with_variates: the STANDARD variates (z ~ N(0,1),
  * u ~ U[0,1)) one env.step() consumes, in the reference's draw order restricted to the draws whose
- * value reaches the state or the observation (aggregate_phy_steps == 1):
+ * value reaches the state or the observation:
  *   OUNoise.noise (envs/utils.py:106) | first add_noise call (envs/base.py:464, only its gyro part
  *   survives at obs_rate 1) | second add_noise call (envs/base.py:468 -> compute_history) | the rest of the
  *   first call.  With obs_rate > 1 a call at an iteration that is not a multiple of obs_rate only draws the
- *   gyro part (add_noise_to_omega, envs/sensors.py:121-134); the unused entries are ignored. */
+ *   gyro part (add_noise_to_omega, envs/sensors.py:121-134); the unused entries are ignored.
+ * With aggregate_phy_steps = A > 1 (envs/base.py:457-465: A x {step_forward; compute_observation}) a row is
+ * A consecutive blocks of PDS_NOISE_FLOATS: block `sub` holds PDS_N_OU and the PDS_N_A_* entries of physics
+ * sub-step `sub`; the one observing call (PDS_N_OBS) is read from block 0. */
 #define PDS_NOISE_FLOATS 52
 #define PDS_N_OU 0        /* 4 z */
 #define PDS_N_A_BIAS 4    /* 3 z  gyro bias random walk   (envs/sensors.py:130) */
@@ -209,7 +212,7 @@ int pds_step(pds_handle *h, const float *d_actions, float *d_obs, float *d_rewar
              void *stream);
 
 /* pds_step with the noise variates supplied by the caller (parity injection for the stochastic
- * parts: OU thrust noise, SensorNoise): d_variates [N, PDS_NOISE_FLOATS].  The reference draws them
+ * parts: OU thrust noise, SensorNoise): d_variates [N, aggregate_phy_steps * PDS_NOISE_FLOATS].  The reference draws them
  * from the global numpy stream (envs/utils.py:106, envs/sensors.py:84-134). */
 int pds_step_with_variates(pds_handle *h, const float *d_actions, const float *d_variates, float *d_obs,
                            float *d_reward, uint8_t *d_terminated, uint8_t *d_truncated, float *d_cost,

@@ -265,6 +265,14 @@ def euler_from_quat(q, precision="f64"):
     return np.array(e)
 
 
+def bullet_readback_quat(q, precision="f64"):
+    """The quaternion getBasePositionAndOrientation returns for a stored `q` (btMatrix3x3 round trip)."""
+    real = C.c_double if precision == "f64" else C.c_float
+    out = (real * 4)()
+    getattr(lib(), "po_bullet_readback_quat_" + precision)(_arr(q, real), out)
+    return np.array(out)
+
+
 class OracleBatch:
     """N oracle envs stepped with OpenMP (the timed `cpu_baseline`, and the lockstep auto-reset
     semantics the HIP path is checked against)."""

@@ -190,6 +190,54 @@ void SUF(po_euler_from_quat)(const REAL q[4], REAL rpy[3]) {
   }
 }
 
+/* Bullet's pose read-back: bc.getBasePositionAndOrientation (agents.py:443) does not return the
+ * quaternion that resetBasePositionAndOrientation (hover.py:231-235, circle.py:259-263,
+ * takeoff.py:193-197) stored.  Bullet3 as published (third party, unpinned -- setup.py:32):
+ * PhysicsServerCommandProcessor.cpp processRequestActualStateCommand answers with
+ * `btTransform tr; tr.setRotation(mb->getWorldToBaseRot().inverse()); ... tr.getRotation()`, and
+ * btTransform keeps a 3x3 basis, i.e. btMatrix3x3::setRotation followed by btMatrix3x3::getRotation
+ * (LinearMath/btMatrix3x3.h; double precision in pybullet): trace > 0 -> w = sqrt(trace + 1) / 2 > 0,
+ * otherwise the component belonging to the largest diagonal element is the positive square root.
+ * pybullet.c pybullet_internalGetBasePositionAndOrientation copies the seven numbers unchanged. */
+void SUF(po_bullet_readback_quat)(const REAL qin[4], REAL q[4]) {
+  REAL m[3][3];
+  {
+    REAL R[9];
+    SUF(po_matrix_from_quat)(qin, R); /* btMatrix3x3::setRotation == the getMatrixFromQuaternion formula */
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) m[r][c] = R[3 * r + c];
+  }
+  REAL trace = m[0][0] + m[1][1] + m[2][2];
+  REAL temp[4];
+  if (trace > (REAL)0.0) {
+    REAL s = R_SQRT(trace + (REAL)1.0);
+    temp[3] = s * (REAL)0.5;
+    s = (REAL)0.5 / s;
+    temp[0] = (m[2][1] - m[1][2]) * s;
+    temp[1] = (m[0][2] - m[2][0]) * s;
+    temp[2] = (m[1][0] - m[0][1]) * s;
+  } else {
+    int i = m[0][0] < m[1][1] ? (m[1][1] < m[2][2] ? 2 : 1) : (m[0][0] < m[2][2] ? 2 : 0);
+    int j = (i + 1) % 3, k = (i + 2) % 3;
+    REAL s = R_SQRT(m[i][i] - m[j][j] - m[k][k] + (REAL)1.0);
+    temp[i] = s * (REAL)0.5;
+    s = (REAL)0.5 / s;
+    temp[3] = (m[k][j] - m[j][k]) * s;
+    temp[j] = (m[j][i] + m[i][j]) * s;
+    temp[k] = (m[k][i] + m[i][k]) * s;
+  }
+#ifdef PO_F64
+  for (int i = 0; i < 4; ++i) q[i] = temp[i];
+#else
+  /* f32 build (the stand-in for what the f32 HIP kernel may do): a float matrix round trip adds ~3e-7 of
+   * rounding that the reference's double-precision round trip (~1e-16) does not have, so only the SIGN the
+   * extraction produces is applied to the input quaternion -- csrc/pds_reset.h reset_env does the same. */
+  {
+    REAL dot = temp[0] * qin[0] + temp[1] * qin[1] + temp[2] * qin[2] + temp[3] * qin[3];
+    for (int i = 0; i < 4; ++i) q[i] = dot < 0 ? -qin[i] : qin[i];
+  }
+#endif
+}
+
 /* ------------------------------------------------------------------------------------------------
  * variate source
  * ---------------------------------------------------------------------------------------------- */
@@ -725,10 +773,11 @@ void SUF(po_reset)(const po_config *c, ENV *e, const po_reset_sample *s, po_rng 
 
   /* ---- drone.update_information(): agents.py:434-453 ---- */
   for (int i = 0; i < 3; ++i) e->xyz[i] = pos[i];
-  for (int i = 0; i < 4; ++i) e->quat[i] = quat[i];
-  SUF(po_euler_from_quat)(quat, e->rpy);                           /* :446 */
+  SUF(po_bullet_readback_quat)(quat, e->quat);                     /* :443 the quaternion as Bullet returns it */
+  SUF(po_euler_from_quat)(e->quat, e->rpy);                        /* :446 */
   for (int i = 0; i < 3; ++i) e->xyz_dot[i] = vel[i];
-  for (int i = 0; i < 3; ++i) e->rpy_dot[i] = R[0 + i] * w_world[0] + R[3 + i] * w_world[1] + R[6 + i] * w_world[2]; /* :452-453 */
+  SUF(po_matrix_from_quat)(e->quat, R);                            /* :452 */
+  for (int i = 0; i < 3; ++i) e->rpy_dot[i] = R[0 + i] * w_world[0] + R[3 + i] * w_world[1] + R[6 + i] * w_world[2]; /* :453 */
 
   /* ---- history fill: base.py:417-431 ---- */
   REAL o[PO_MAX_OBS];

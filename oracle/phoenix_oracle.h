@@ -108,6 +108,7 @@ typedef struct po_rng {
   void po_quat_from_euler##SUF(const REAL rpy[3], REAL q[4]);                                       \
   void po_matrix_from_quat##SUF(const REAL q[4], REAL R[9]);                                        \
   void po_euler_from_quat##SUF(const REAL q[4], REAL rpy[3]);                                       \
+  void po_bullet_readback_quat##SUF(const REAL qin[4], REAL q[4]);                                  \
   void po_env_init##SUF(const po_config *c, po_env##SUF *e);                                        \
   void po_apply_action##SUF(const po_config *c, po_env##SUF *e, const REAL a[4], po_rng *rng,      \
                             REAL forces[4], REAL *z_torque);                                        \

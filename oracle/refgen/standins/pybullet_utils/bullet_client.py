@@ -2,9 +2,51 @@
 
 On the SimplePhysics path the Bullet world is only a mirror of the Python state
 (reference envs/physics.py:190-200) plus a pose/velocity round trip at reset
-(envs/agents.py:434-453), so a dict of base pose/velocity per body is sufficient.
+(envs/agents.py:434-453), so a dict of base pose/velocity per body is sufficient -- with ONE
+piece of Bullet arithmetic restated: the base orientation is read back through btTransform's
+3x3 basis (see getBasePositionAndOrientation), which canonicalises the quaternion's sign.
 """
+import math as _math
+
 import pybullet as _pb
+
+
+def _bt_set_rotation(q):
+    """btMatrix3x3::setRotation(const btQuaternion&) (LinearMath/btMatrix3x3.h), scalar path."""
+    x, y, z, w = q
+    d = x * x + y * y + z * z + w * w
+    s = 2.0 / d
+    xs, ys, zs = x * s, y * s, z * s
+    wx, wy, wz = w * xs, w * ys, w * zs
+    xx, xy, xz = x * xs, x * ys, x * zs
+    yy, yz, zz = y * ys, y * zs, z * zs
+    return ((1.0 - (yy + zz), xy - wz, xz + wy),
+            (xy + wz, 1.0 - (xx + zz), yz - wx),
+            (xz - wy, yz + wx, 1.0 - (xx + yy)))
+
+
+def _bt_get_rotation(m):
+    """btMatrix3x3::getRotation(btQuaternion&) (LinearMath/btMatrix3x3.h), scalar path."""
+    trace = m[0][0] + m[1][1] + m[2][2]
+    temp = [0.0, 0.0, 0.0, 0.0]
+    if trace > 0.0:
+        s = _math.sqrt(trace + 1.0)
+        temp[3] = s * 0.5
+        s = 0.5 / s
+        temp[0] = (m[2][1] - m[1][2]) * s
+        temp[1] = (m[0][2] - m[2][0]) * s
+        temp[2] = (m[1][0] - m[0][1]) * s
+    else:
+        i = (2 if m[1][1] < m[2][2] else 1) if m[0][0] < m[1][1] else (2 if m[0][0] < m[2][2] else 0)
+        j = (i + 1) % 3
+        k = (i + 2) % 3
+        s = _math.sqrt(m[i][i] - m[j][j] - m[k][k] + 1.0)
+        temp[i] = s * 0.5
+        s = 0.5 / s
+        temp[3] = (m[k][j] - m[j][k]) * s
+        temp[j] = (m[j][i] + m[i][j]) * s
+        temp[k] = (m[k][i] + m[i][k]) * s
+    return tuple(temp)
 
 
 class BulletClient:
@@ -38,7 +80,25 @@ class BulletClient:
         self._pose[bid] = (tuple(float(v) for v in posObj), tuple(float(v) for v in ornObj))
 
     def getBasePositionAndOrientation(self, bid):
-        return self._pose[bid]
+        """Bullet does NOT hand the quaternion back verbatim.  Published Bullet3 code path
+        (pybullet is unpinned in the reference's setup.py:32; files of bullet3 master / 3.2x):
+          * examples/pybullet/pybullet.c `pybullet_internalGetBasePositionAndOrientation` copies
+            `actualStateQ[0..6]` of the CMD_REQUEST_ACTUAL_STATE status, nothing else;
+          * examples/SharedMemory/PhysicsServerCommandProcessor.cpp
+            `processRequestActualStateCommand` fills them for a btMultiBody base (loadURDF's
+            default) with `btTransform tr; tr.setOrigin(mb->getBasePos());
+            tr.setRotation(mb->getWorldToBaseRot().inverse());` ... `tr.getRotation()[i]`
+            (the root inertial frame of cf21x_sys_eq.urdf:14-18 is the identity);
+            `processInitPoseCommand` had stored `setWorldToBaseRot(q.inverse())` -- conjugation
+            twice is exact;
+          * src/LinearMath/btTransform.h `setRotation` / `getRotation` go through the 3x3 basis:
+            btMatrix3x3::setRotation(q) then btMatrix3x3::getRotation(q) (btMatrix3x3.h), in
+            double precision (pybullet is built with BT_USE_DOUBLE_PRECISION).
+        So the quaternion that comes back is the matrix->quaternion extraction: w > 0 when the
+        trace is positive, else the component of the largest diagonal element positive; the
+        position is returned as stored."""
+        pos, orn = self._pose[bid]
+        return pos, _bt_get_rotation(_bt_set_rotation(orn))
 
     def resetBaseVelocity(self, bid, linearVelocity=None, angularVelocity=None):
         lin, ang = self._vel[bid]

@@ -409,6 +409,7 @@ static int ensure_latency_buffer(pds_handle *h) {
   hipError_t e = hipMalloc((void **)&h->lat_buf, bytes);
   if (e == hipSuccess) e = hipMemset(h->lat_buf, 0, bytes);
   if (e != hipSuccess) {
+    if (h->lat_buf) (void)hipFree(h->lat_buf);
     h->lat_buf = nullptr;
     return fail(h, e == hipErrorOutOfMemory ? PDS_ENOMEM : PDS_EHIP, "latency buffer (%zu bytes): %s", bytes, hipGetErrorString(e));
   }
@@ -602,17 +603,20 @@ extern "C" int pds_set_latency(pds_handle *h, double latency) {
     if (steps < 1) return fail(h, PDS_EINVAL, "latency %g: buf_size 0 (the reference asserts buf_size > 0)", latency);
     if (steps > kMaxLatSteps) return fail(h, PDS_EUNSUPPORTED, "latency %g s = %d steps (limit %d)", latency, steps, kMaxLatSteps);
   }
+  // every check and the allocation come BEFORE the handle is touched: a refused call leaves it as it was
+  if (steps > 0 && h->flags.hold) return fail(h, PDS_EUNSUPPORTED, "latency with obs_rate > 1 is not built");
   DeviceGuard guard(h->cfg.device);
   PDS_HIP(h, guard.err);
   PDS_HIP(h, hipDeviceSynchronize());
+  if (steps > 0) {
+    const int rc = ensure_latency_buffer(h);
+    if (rc != PDS_OK) return rc;
+  }
   h->cfg.latency = latency;
   h->cfg.use_latency = steps > 0;
   h->flags.lat = steps > 0;
   set_latency_consts(h->k, steps, h->cfg.aggregate_phy_steps);
-  if (steps > 0 && h->flags.hold) return fail(h, PDS_EUNSUPPORTED, "latency with obs_rate > 1 is not built");
   if (steps > 0) {
-    const int rc = ensure_latency_buffer(h);
-    if (rc != PDS_OK) return rc;
     const long long n = h->cfg.num_envs;
     hipLaunchKernelGGL(latency_clear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, h->st, n, kMaxLatSteps);
     PDS_HIP(h, hipGetLastError());
@@ -724,8 +728,6 @@ extern "C" int pds_step_with_variates(pds_handle *h, const float *d_actions, con
                                       uint8_t *d_truncated, float *d_cost, float *d_final_obs, void *stream) {
   if (!h) return PDS_EINVAL;
   if (const int rc = check_step_pointers(h, d_actions, d_obs, d_reward, d_terminated, d_truncated, d_cost)) return rc;
-  if (d_variates && h->cfg.aggregate_phy_steps != 1)
-    return fail(h, PDS_EUNSUPPORTED, "injected noise variates need aggregate_phy_steps == 1");
   DeviceGuard guard(h->cfg.device);  // (no hipSetDevice when the caller is already on the device)
   PDS_HIP(h, guard.err);
   StepArgs a;

@@ -368,6 +368,21 @@ PDS_DEV void reset_env(const Consts &k, const float2 *ref_lds, const Sample &s, 
   q = quat_from_euler(r0, r1, r2);
   float R[9];
   matrix_from_quat(q, R);
+  // update_information reads the pose back from Bullet (envs/agents.py:443): the quaternion comes back
+  // through btTransform's 3x3 basis (btMatrix3x3::setRotation / getRotation, see oracle/phoenix_oracle.c
+  // po_bullet_readback_quat), i.e. as +-Q(sampled rpy) with the sign Bullet's extraction gives it:
+  // w > 0 when the trace is positive, else the component of the largest diagonal element positive.
+  // Only the sign is taken from that rule (the f32 value of Q is closer to the reference's f64 quaternion
+  // than an f32 matrix round trip would be).
+  uint32_t sign;
+  {
+    // on the unit quaternion itself: trace = 4 w^2 - 1, and diag_i - diag_j = 2 (q_i^2 - q_j^2)
+    const float xx = q.x * q.x, yy = q.y * q.y, zz = q.z * q.z;
+    float lead = q.w;
+    if (!(4.f * q.w * q.w > 1.f)) lead = xx < yy ? (yy < zz ? q.z : q.y) : (xx < zz ? q.z : q.x);
+    sign = lead < 0.f ? 1u : 0u;
+    if (sign) { q.x = -q.x; q.y = -q.y; q.z = -q.z; q.w = -q.w; }
+  }
   // bc.resetBaseVelocity(R^T w) then update_information: R^T (R^T w)
   const float a0 = R[0] * w0 + R[3] * w1 + R[6] * w2;
   const float a1 = R[1] * w0 + R[4] * w1 + R[7] * w2;
@@ -376,18 +391,17 @@ PDS_DEV void reset_env(const Consts &k, const float2 *ref_lds, const Sample &s, 
   e.wy = R[1] * a0 + R[4] * a1 + R[7] * a2;
   e.wz = R[2] * a0 + R[5] * a1 + R[8] * a2;
   e.px = px; e.py = py; e.pz = pz; e.vx = vx; e.vy = vy; e.vz = vz;
-  // rpy = Euler(quat) (envs/agents.py:446).  The quaternion keeps the sign of Q(sampled rpy) until
-  // the first step while the state stores the wrapped Euler angles, so remember whether Q(wrapped)
-  // has the opposite sign.
-  uint32_t sign;
+  // rpy = Euler(quat) (envs/agents.py:446).  The state stores the wrapped Euler angles and every later
+  // quaternion is Q(rpy) (envs/physics.py:179); until the first step the observation carries the
+  // read-back quaternion, so remember whether Q(wrapped rpy) has the opposite sign.
   if (fabsf(r0) < 1.55f && fabsf(r1) < 1.55f) {
     // every sampled attitude lands here: roll/pitch inside the principal range, so
-    // Euler(Q(r,p,y)) == (r, p, y - 2 pi k) and Q flips sign once per 2 pi of yaw
+    // Euler(+-Q(r,p,y)) == (r, p, y - 2 pi k) and Q flips sign once per 2 pi of yaw
     const float kk = rintf(r2 * 0.15915494309189533577f);
     float yw = fmaf(-kk, 6.2831854820251465f, r2);
     yw = fmaf(kk, 1.7484555e-7f, yw);
     e.roll = r0; e.pitch = r1; e.yaw = yw;
-    sign = ((int)kk) & 1;
+    sign ^= ((uint32_t)(int)kk) & 1u;
   } else {  // init_rpy overrides near / beyond gimbal lock: the general pybullet formulas
     euler_from_quat(q, e.roll, e.pitch, e.yaw);
     const Quat qw = quat_from_euler(e.roll, e.pitch, e.yaw);

@@ -317,8 +317,8 @@ struct SubNoise {
 
 template <class V>
 PDS_DEV void sub_noise(const StepArgs &a, const RngKey &rk, uint32_t env_id, long long ii, int sub, SubNoise &n) {
-  if (a.noise != nullptr) {  // injected (parity tests; aggregate_phy_steps == 1)
-    const float *p = a.noise + ii * PDS_NOISE_FLOATS;
+  if (a.noise != nullptr) {  // injected (parity tests): one PDS_NOISE_FLOATS block per physics sub-step
+    const float *p = a.noise + (ii * a.k.agg + sub) * PDS_NOISE_FLOATS;
 #pragma unroll
     for (int j = 0; j < 4; ++j) n.ou[j] = p[PDS_N_OU + j];
 #pragma unroll
@@ -624,7 +624,7 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
   // ---- o(k+1) and u(k-1) -> second half of the row (envs/base.py:303-319) --------------------
   if (V::ON) {
     ObsNoise n;
-    if (a.noise != nullptr) obs_noise_load(a.noise + ii * PDS_NOISE_FLOATS + PDS_N_OBS, n);
+    if (a.noise != nullptr) obs_noise_load(a.noise + ii * k.agg * PDS_NOISE_FLOATS + PDS_N_OBS, n);  // (block of sub-step 0)
     else obs_noise_philox(env_id, rk, kBlkObsNoise, n);
     sensor_observe(k, e, n, ns, S.oh);
     if (V::HOLD) {  // per env: fresh observation or the held one + the fresh gyro

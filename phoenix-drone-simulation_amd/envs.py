@@ -16,6 +16,7 @@ Differences that follow from batching (documented in INTEGRATION.md):
     stream keyed by (seed, global env id, tick) -- the reference draws from the global numpy stream.
 All computation happens in libpds_hip.so (HIP, gfx950); there is no CPU path here.
 """
+import contextlib
 import ctypes as C
 import sys
 
@@ -23,6 +24,8 @@ import numpy as np
 import torch
 
 from . import native
+
+_NULL_CTX = contextlib.nullcontext()
 
 try:  # gymnasium is optional (absent in the build image); spaces are duck-typed otherwise
     from gymnasium.spaces import Box as _GymBox
@@ -302,10 +305,12 @@ class DroneVecEnv:
             if out.data_ptr() == self._hist.data_ptr():  # (after a reset() replaced self._hist with one of the sets)
                 self._hist_flip ^= 1
                 out, fin = self._hist_sets[self._hist_flip]
-        rc = self.lib.pds_history_advance(N, half, H, obs2.data_ptr(), term.data_ptr(), trunc.data_ptr(),
-                                          info["final_obs"].data_ptr() if self._auto_reset else None,
-                                          int(self._auto_reset), self._hist.data_ptr(), out.data_ptr(),
-                                          fin.data_ptr() if fin is not None else None, self._raw_stream())
+        # pds_history_advance has no handle argument: it launches on the CURRENT device, which must be the env's
+        with (_NULL_CTX if self.device.index == torch.cuda.current_device() else torch.cuda.device(self.device)):
+            rc = self.lib.pds_history_advance(N, half, H, obs2.data_ptr(), term.data_ptr(), trunc.data_ptr(),
+                                              info["final_obs"].data_ptr() if self._auto_reset else None,
+                                              int(self._auto_reset), self._hist.data_ptr(), out.data_ptr(),
+                                              fin.data_ptr() if fin is not None else None, self._raw_stream())
         if rc != 0:
             native.check(self._handle, rc, "pds_history_advance")
         self._hist = out
@@ -330,7 +335,7 @@ class DroneVecEnv:
         """env.step(action).  The returned tensors are OWNED by the env: two buffer sets alternate, so the
         result of a step stays valid during the next one (`o` and `next_o` of a rollout loop) and is
         overwritten by the one after -- clone() what must live longer (the reference returns fresh arrays,
-        envs/base.py:311).  `noise_variates` [N, 52] (native.STEP_NOISE_LAYOUT) replaces the in-kernel
+        envs/base.py:311).  `noise_variates` [N, aggregate_phy_steps * 52] (native.STEP_NOISE_LAYOUT per physics sub-step) replaces the in-kernel
         Philox draws of the OU thrust noise / SensorNoise with caller-supplied standard variates
         (parity tests replay the reference's numpy draws this way)."""
         a = action
@@ -344,7 +349,7 @@ class DroneVecEnv:
         nv = None
         if noise_variates is not None:
             nv = torch.as_tensor(noise_variates, dtype=torch.float32).to(self.device).contiguous()
-            assert nv.shape == (self.num_envs, native.NOISE_FLOATS)
+            assert nv.shape == (self.num_envs, native.NOISE_FLOATS * self.aggregate_phy_steps)  # one block per physics sub-step
             nv = C.c_void_p(nv.data_ptr())
         rc = self.lib.pds_step_with_variates(self._handle, a.data_ptr(), nv, *b["_args"],
                                              self._raw_stream())
@@ -389,6 +394,10 @@ class DroneVecEnv:
     def set_latency(self, new_latency):
         """CrazyFlieAgent.set_latency (envs/agents.py:388-404): below one time step the delay is switched
         off, otherwise buf_size = int(latency / time_step); the action buffer of every env is zeroed."""
+        if self._hist is not None and float(new_latency) >= float(self.cfg.time_step):
+            # the aliased action-history entries of the first two steps after a reset (agents.py:386, base.py:425-426)
+            # are resolved in-kernel for observation_history_size == 2 only -- same refusal as the constructor's
+            raise NotImplementedError("set_latency >= one time step with observation_history_size != 2 is not built")
         rc = self.lib.pds_set_latency(self._handle, float(new_latency))
         native.check(self._handle, rc, "pds_set_latency")
 

@@ -75,7 +75,7 @@ def all_gather_obs(obs, out=None, group=None):
 
 class P2PObsGather:
     """All-gather of the observation shards by direct peer-to-peer STORES: every rank owns
-    a full-size [sum n_r, D] buffer that its peers have opened through the HIP IPC handle of its
+    full-size [sum n_r, D] buffers that its peers have opened through the HIP IPC handle of the
     allocation; after a step each rank copies its [n_r, D] block straight into the matching rows of every
     peer's buffer -- G-1 independent transfers that use all xGMI links of the GPU at once (the fabric is
     point to point: 7 links per MI355X), where a ring all-gather moves the same bytes over one link per
@@ -83,15 +83,27 @@ class P2PObsGather:
     (utils/mpi_tools.py:117-187 only averages gradients and statistics); this is the optional layout in
     which ONE policy consumes the whole batch.
 
-    Synchronisation (no device-wide sync on the host): the copies run on a side stream behind the
-    producer's step; each rank then records an inter-process event; a host barrier on `sync_group`
-    (a gloo group: microseconds on one node) guarantees that every record is enqueued before any rank
-    enqueues `wait_event` on its peers' events; the consumer's stream waits for them on the GPU.  The
-    buffers are coarse-grained device memory, coherent across devices at kernel boundaries, which is
-    what the event wait provides.
+    Synchronisation (no device-wide sync on the host), call number s, j = s & 1:
+      * TWO buffers alternate (`out[j]`), so the blocks of step s land in a buffer nobody reads: the
+        consumer of step s-1 works on `out[j ^ 1]`.
+      * write-after-read across ranks: at the entry of call s this rank records the inter-process event
+        `consumed[j ^ 1]` on its current stream -- every read of the buffer returned by call s-1 has been
+        enqueued by then -- and a producer waits (on its copy stream, on the GPU) for the `consumed[j]`
+        events its peers recorded during call s-1 before it overwrites their `out[j]`.
+      * read-after-write: the copies run on a side stream behind the producer's step and are followed by
+        the inter-process event `produced[j]`; the consumer's stream waits for its peers' events.
+      * ONE host barrier per call on `sync_group` (a gloo group: microseconds on one node) orders the
+        ENQUEUES: an event wait refers to the last record enqueued before it, so every rank's records of
+        call s (and s-1) must be enqueued before any rank enqueues a wait on them.
+    The buffers are coarse-grained device memory, coherent across devices at kernel boundaries, which is
+    what the event waits provide.
+
+    Validity of the result: `gather()` returns `out[j]`; it may be read by work enqueued on the current
+    stream (or on streams that wait for it) until the NEXT `gather()` call on this rank -- clone what must
+    live longer.
 
     On CPU tensors (the world-2 gloo tests) the peer buffers are files under /dev/shm mapped by both
-    processes and the events degenerate to the barrier: same slicing and hand-shake logic, no HIP.
+    processes and the events degenerate to the barrier: same slicing, double buffering and hand-shake, no HIP.
     """
 
     def __init__(self, rows, width, device, dtype=torch.float32, group=None, sync_group=None, tag="pds_p2p"):
@@ -106,65 +118,89 @@ class P2PObsGather:
         self._step = 0
         self._files = []
         if self.device.type == "cuda":
-            self.out = torch.empty(self.total, self.width, dtype=dtype, device=self.device)
-            handle = self.out.untyped_storage()._share_cuda_()
+            # one allocation, two halves: ONE IPC handle per rank
+            self._both = torch.empty(2, self.total, self.width, dtype=dtype, device=self.device)
+            self.bufs = [self._both[0], self._both[1]]
+            handle = self._both.untyped_storage()._share_cuda_()
             handles = [None] * self.world
             dist.all_gather_object(handles, handle, group=self.sync_group)
-            self.peers = []
+            self.peers = []  # peers[r][j]: rank r's buffer j
             for r, h in enumerate(handles):
                 if r == self.rank:
-                    self.peers.append(self.out)
+                    self.peers.append(self.bufs)
                     continue
                 st = torch.UntypedStorage._new_shared_cuda(*h)
-                self.peers.append(torch.empty(0, dtype=dtype, device=st.device).set_(st, 0, (self.total, self.width)))
+                both = torch.empty(0, dtype=dtype, device=st.device).set_(st, 0, (2, self.total, self.width))
+                self.peers.append([both[0], both[1]])
             self.copy_stream = torch.cuda.Stream(self.device)
-            self.events = [torch.cuda.Event(interprocess=True) for _ in range(2)]
+            self.produced = [torch.cuda.Event(interprocess=True) for _ in range(2)]
+            self.consumed = [torch.cuda.Event(interprocess=True) for _ in range(2)]
             ev_handles = [None] * self.world
-            dist.all_gather_object(ev_handles, (self.device.index, [e.ipc_handle() for e in self.events]),
-                                   group=self.sync_group)
+            dist.all_gather_object(ev_handles, (self.device.index, [e.ipc_handle() for e in self.produced],
+                                                [e.ipc_handle() for e in self.consumed]), group=self.sync_group)
+
             # (an IPC event is re-opened on the device it was created on: the producer's)
-            self.peer_events = [None if r == self.rank else
-                                [torch.cuda.Event.from_ipc_handle(torch.device("cuda", ev_handles[r][0]), hh)
-                                 for hh in ev_handles[r][1]]
-                                for r in range(self.world)]
+            def _open(r, hs):
+                return [torch.cuda.Event.from_ipc_handle(torch.device("cuda", ev_handles[r][0]), hh) for hh in hs]
+            self.peer_produced = [None if r == self.rank else _open(r, ev_handles[r][1]) for r in range(self.world)]
+            self.peer_consumed = [None if r == self.rank else _open(r, ev_handles[r][2]) for r in range(self.world)]
         else:
             import os
             import tempfile
-            nbytes = self.total * self.width
+            nbytes = 2 * self.total * self.width
             base = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir(), f"{tag}_{os.getppid()}")
             mine = f"{base}_{self.rank}"
-            self.out = torch.from_file(mine, shared=True, size=nbytes, dtype=dtype).view(self.total, self.width)
+            both = torch.from_file(mine, shared=True, size=nbytes, dtype=dtype).view(2, self.total, self.width)
+            self.bufs = [both[0], both[1]]
             self._files.append(mine)
             dist.barrier(group=self.sync_group)  # every file exists
-            self.peers = [self.out if r == self.rank else
-                          torch.from_file(f"{base}_{r}", shared=True, size=nbytes, dtype=dtype).view(self.total, self.width)
-                          for r in range(self.world)]
+            self.peers = []
+            for r in range(self.world):
+                if r == self.rank:
+                    self.peers.append(self.bufs)
+                else:
+                    pb = torch.from_file(f"{base}_{r}", shared=True, size=nbytes, dtype=dtype).view(2, self.total, self.width)
+                    self.peers.append([pb[0], pb[1]])
+
+    @property
+    def out(self):
+        """The buffer the last `gather()` returned (buffer 0 before the first call)."""
+        return self.bufs[(self._step - 1) & 1] if self._step else self.bufs[0]
 
     def gather(self, obs):
-        """Store `obs` [n_r, width] into rows [offset_r, offset_r + n_r) of every rank's buffer and return
-        this rank's full [total, width] buffer once all peers' blocks have arrived (stream-ordered on GPUs)."""
+        """Store `obs` [n_r, width] into rows [offset_r, offset_r + n_r) of every rank's buffer `j = call & 1`
+        and return this rank's full [total, width] buffer j once all peers' blocks have arrived
+        (stream-ordered on GPUs).  The result stays valid until the next `gather()` call."""
         lo, n = self.offsets[self.rank], self.sizes[self.rank]
         assert obs.shape == (n, self.width), (tuple(obs.shape), n, self.width)
+        s, j = self._step, self._step & 1
         if self.device.type == "cuda":
             cur = torch.cuda.current_stream(self.device)
-            j = self._step & 1
-            self.copy_stream.wait_stream(cur)  # the step that produced `obs`
+            if s >= 1:
+                self.consumed[j ^ 1].record(cur)  # all reads of the previous result are enqueued before this point
+            self.copy_stream.wait_stream(cur)  # the step that produced `obs` (and this rank's own reads of out[j])
             with torch.cuda.stream(self.copy_stream):
+                if s >= 2:  # the peers' consumers of call s-2 (records enqueued before the barrier of call s-1)
+                    for r in range(self.world):
+                        if r != self.rank:
+                            self.copy_stream.wait_event(self.peer_consumed[r][j])
                 for k in range(self.world):  # start with the next rank so that the G ranks do not all hit one target
                     r = (self.rank + k) % self.world
-                    self.peers[r][lo:lo + n].copy_(obs, non_blocking=True)
-                self.events[j].record(self.copy_stream)
-            dist.barrier(group=self.sync_group)  # every rank has ENQUEUED its record (host only, no device sync)
-            cur.wait_event(self.events[j])
+                    self.peers[r][j][lo:lo + n].copy_(obs, non_blocking=True)
+                self.produced[j].record(self.copy_stream)
+            dist.barrier(group=self.sync_group)  # every rank has ENQUEUED its records (host only, no device sync)
+            cur.wait_event(self.produced[j])
             for r in range(self.world):
                 if r != self.rank:
-                    cur.wait_event(self.peer_events[r][j])
+                    cur.wait_event(self.peer_produced[r][j])
         else:
+            # host copies are synchronous: a peer writes my out[j] in ITS call s, i.e. after the barrier of call
+            # s-1, which I only pass once I am done with the result of call s-2 (the same buffer)
             for r in range(self.world):
-                self.peers[r][lo:lo + n].copy_(obs)
+                self.peers[r][j][lo:lo + n].copy_(obs)
             dist.barrier(group=self.sync_group)
         self._step += 1
-        return self.out
+        return self.bufs[j]
 
     def release(self):
         """Call on every rank before the buffers go away: no peer may still be writing into them."""

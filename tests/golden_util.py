@@ -129,47 +129,56 @@ def obs_rate(g):
     return int(100 // int(g.kwargs.get("observation_frequency", 100)))
 
 
+def _agg(g):
+    return int(g.kwargs.get("aggregate_phy_steps", 1))
+
+
 def _stream_offsets(g, t):
-    """(z, u) offsets of env.step() number t (aggregate_phy_steps == 1) inside the episode's recorded streams,
-    and which of its two add_noise calls are full ones: a call at an iteration that is not a multiple of
-    obs_rate only draws the 9 gyro normals (envs/hover.py:134-156)."""
-    R = obs_rate(g)
+    """(z, u) offsets of env.step() number t inside the episode's recorded streams.  One env.step() draws, per
+    physics sub-step (envs/base.py:457-465), OUNoise's randn(4) and one add_noise call at iteration
+    t * A + sub, then the observing call at iteration (t + 1) * A (base.py:468); a call at an iteration that
+    is not a multiple of obs_rate only draws the 9 gyro normals (envs/hover.py:134-156)."""
+    R, A = obs_rate(g), _agg(g)
     zs, us = 2 * Z_CALL, 2 * U_CALL  # reset(): two full calls at iteration 0
     for k in range(t):
-        for it in (k, k + 1):
+        for it in list(range(k * A, (k + 1) * A)) + [(k + 1) * A]:
             full = (it % R) == 0
             zs += Z_CALL if full else 9
             us += U_CALL if full else 0
-        zs += 4  # OUNoise
-    return zs, us, (t % R) == 0, ((t + 1) % R) == 0
+        zs += 4 * A  # OUNoise, once per sub-step
+    return zs, us
 
 
 def step_noise_variates(g, ep, t):
-    """[52]: OU z4 | gyro part of the first call (bias3 rw3 to3) | the observing call (24) | position /
-    velocity / angle draws of the first call (pos_z3 pos_u3 vel_z3 th_z3 th_u3; they matter when obs_rate > 1)."""
+    """[A * 52], A = aggregate_phy_steps: per physics sub-step a block of OU z4 | gyro part of that sub-step's
+    (discarded) add_noise call (bias3 rw3 to3) | [block 0 only: the observing call (24)] | position / velocity /
+    angle draws of the discarded call (pos_z3 pos_u3 vel_z3 th_z3 th_u3; they matter when obs_rate > 1)."""
     z, u = episode_streams(g, ep)
-    out = np.zeros(52)
+    R, A = obs_rate(g), _agg(g)
+    out = np.zeros((A, 52))
     if noisy(g):
-        assert int(g.kwargs.get("aggregate_phy_steps", 1)) == 1
-        zs, us, full_a, full_b = _stream_offsets(g, t)
-        out[0:4] = z[zs:zs + 4]
-        zs += 4
-        if full_a:
-            za, ua = z[zs:zs + Z_CALL], u[us:us + U_CALL]
-            out[4:13] = za[6:15]
-            out[37:40], out[40:43], out[43:46] = za[0:3], ua[0:3], za[3:6]
-            out[46:49], out[49:52] = za[15:18], ua[6:9]
-            zs += Z_CALL; us += U_CALL
+        zs, us = _stream_offsets(g, t)
+        for sub in range(A):
+            o = out[sub]
+            o[0:4] = z[zs:zs + 4]
+            zs += 4
+            if ((t * A + sub) % R) == 0:
+                za, ua = z[zs:zs + Z_CALL], u[us:us + U_CALL]
+                o[4:13] = za[6:15]
+                o[37:40], o[40:43], o[43:46] = za[0:3], ua[0:3], za[3:6]
+                o[46:49], o[49:52] = za[15:18], ua[6:9]
+                zs += Z_CALL; us += U_CALL
+            else:
+                o[4:13] = z[zs:zs + 9]
+                zs += 9
+        if (((t + 1) * A) % R) == 0:
+            out[0, 13:37] = _obs_call_variates(z[zs:zs + Z_CALL], u[us:us + U_CALL])
         else:
-            out[4:13] = z[zs:zs + 9]
-            zs += 9
-        if full_b:
-            out[13:37] = _obs_call_variates(z[zs:zs + Z_CALL], u[us:us + U_CALL])
-        else:
-            out[13 + 9:13 + 18] = z[zs:zs + 9]  # bias, random walk, turn-on of add_noise_to_omega
+            out[0, 13 + 9:13 + 18] = z[zs:zs + 9]  # bias, random walk, turn-on of add_noise_to_omega
     else:
-        out[0:4] = z[4 * t:4 * t + 4]
-    return out
+        for sub in range(A):
+            out[sub, 0:4] = z[4 * (A * t + sub):4 * (A * t + sub) + 4]
+    return out.reshape(-1)
 
 
 def tolerances(name):

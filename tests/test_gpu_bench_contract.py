@@ -52,6 +52,24 @@ def test_bench_multi_rank_code_path_on_one_gpu():
     assert abs(d["value"] - 2 * 65536 * 20 / (d["ms_per_step"] * 20e-3)) < 1e-6 * d["value"]
 
 
+def test_bench_gpus_n_without_a_launcher_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (no torch.distributed.run around it): bench.py starts
+    the two ranks itself as a child launcher (the role of the reference's mpi_fork, utils/mpi_tools.py:47-99),
+    relays the one JSON line and the exit code."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "4",
+           "--envs-per-gpu", "65536", "--same-device", "--allgather-obs", "p2p"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and len(d["per_rank_ms_per_step"]) == 2 and d["allgather_ms"] > 0
+    # a failing rank's exit code comes back through the launcher
+    bad = subprocess.run(cmd[:-2] + ["--allgather-obs", "rccl"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert bad.returncode != 0
+
+
 @pytest.mark.parametrize("mode,steps,warmup", [("graph", 128, 64), ("stepk", 64, 16)])
 def test_bench_diagnostic_modes(mode, steps, warmup):
     """--mode graph (64 captured steps per replay) / stepk (K = 8 steps per launch): same env-steps, fewer

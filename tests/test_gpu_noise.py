@@ -19,8 +19,8 @@ def _is_noisy(n):
     return gu.noisy(gu.Golden(n)) and "det" not in n
 
 
-# every scenario with observation noise; the injected-variate interface covers aggregate_phy_steps == 1
-NOISE_SCENARIOS = [n for n in gu.scenario_names() if _is_noisy(n) and int(gu.Golden(n).kwargs.get("aggregate_phy_steps", 1)) == 1]
+# every scenario with observation noise, aggregate_phy_steps > 1 included (one variate block per physics sub-step)
+NOISE_SCENARIOS = [n for n in gu.scenario_names() if _is_noisy(n)]
 
 
 def _inject_noise_state(env, ou, bias, lpf, noisy_obs10):
@@ -118,19 +118,26 @@ def test_philox_noise_lockstep_vs_f32_oracle(task, kw):
     oobs = orc.reset(seed, 0)
     gu.assert_close(obs.cpu().numpy(), oobs, 1e-5, 1e-5, "reset obs")
     rs = np.random.RandomState(1)
-    bad = 0
+    synced = np.ones(N, dtype=bool)  # an env whose termination flag ever differed has its own episode phase from then on
+    finished = 0
     for t in range(T):
         a = (-0.1 + 0.3 * rs.standard_normal((N, 4))).astype(np.float32)
         tick = env.tick
         o, r, term, trunc, info = env.step(torch.tensor(a))
         oo, orr, oterm, otrunc, ocost = orc.step(a, seed=seed, tick=tick, auto_reset=True)
-        same = (term.cpu().numpy() == oterm.astype(bool))
-        bad += int((~same).sum())
-        gu.assert_close(o.cpu().numpy()[same], oo[same], 1e-4, 1e-4, f"t{t} obs")
-        gu.assert_close(r.cpu().numpy()[same], orr[same], 1e-4, 1e-3, f"t{t} reward")
-        if bad:
-            break
-    assert bad <= 1
+        te, tr = term.cpu().numpy(), trunc.cpu().numpy()
+        synced &= (te == oterm.astype(bool)) & (tr == otrunc.astype(bool))
+        gu.assert_close(o.cpu().numpy()[synced], oo[synced], 1e-4, 1e-4, f"t{t} obs")  # (post-reset rows of finished envs included)
+        gu.assert_close(r.cpu().numpy()[synced], orr[synced], 1e-4, 1e-3, f"t{t} reward")
+        assert np.array_equal(info["cost"].cpu().numpy()[synced], ocost[synced])
+        done = (te | tr) & synced
+        finished += int(done.sum())
+        if done.any():
+            fo = info["final_obs"].cpu().numpy()
+            gu.assert_close(fo[done], orc.final_obs[done], 1e-4, 1e-4, f"t{t} final_obs")
+    # all T steps ran; a threshold flipped by f32 rounding may desynchronise at most 0.1 % of the envs
+    assert (~synced).sum() <= max(1, N // 1000), (~synced).sum()
+    assert finished >= 3 * N, finished
     env.close()
 
 

@@ -184,11 +184,20 @@ assert full.shape == (total, D) and torch.equal(full, want), rank
 full2 = pds.all_gather_obs(obs)  # shard sizes come from the cache now: no size exchange on the second call
 assert torch.equal(full2, want)
 # the peer-to-peer STORE variant (SURVEY 8e): same result, ordered by global env id, over several steps
+# NO barrier between the calls: the result of call s is valid until this rank's call s+1 (two buffers
+# alternate, a peer writes buffer j again only after the barrier inside my NEXT call); rank 1 is a slow
+# consumer, rank 0 runs ahead as far as the protocol lets it
+import time
 gat = pds.P2PObsGather(b - a, D, "cpu")
-for step in range(3):
+prev = None
+for step in range(7):
     got = gat.gather(obs + step)
+    assert prev is None or prev.data_ptr() != got.data_ptr()
+    if rank == 1:
+        time.sleep(0.05)
     assert got.shape == (total, D) and torch.equal(got, want + step), (rank, step)
-    dist.barrier()  # (the test re-reads `got` above before the peers overwrite it in the next step)
+    assert gat.out.data_ptr() == got.data_ptr()
+    prev = got
 gat.release()
 from phoenix_drone_simulation_amd.sharding import max_over_ranks
 assert max_over_ranks(float(rank + 1), torch.device("cpu")) == float(world)

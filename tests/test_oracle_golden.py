@@ -73,6 +73,60 @@ def test_quaternion_convention():
         np.testing.assert_allclose(qo, qs, rtol=0, atol=1e-15)
 
 
+def test_bullet_pose_readback_canonicalises_the_quaternion():
+    """Row a17: getBasePositionAndOrientation answers through btTransform's 3x3 basis
+    (btMatrix3x3::setRotation -> getRotation), so the quaternion update_information reads
+    (envs/agents.py:443) is +-Q(sampled rpy) with Bullet's sign: w > 0 when the trace is positive
+    (|w| > 1/2), otherwise the component of the largest diagonal element (largest of x^2, y^2, z^2) > 0."""
+    from scipy.spatial.transform import Rotation
+    rs = np.random.RandomState(3)
+    n_flip = n_else = 0
+    for i in range(4000):
+        if i % 2:  # the Hover reset distribution: yaw in (-2 pi, 2 pi) (envs/hover.py:207-209)
+            rpy = np.array([rs.uniform(-np.pi / 6, np.pi / 6), rs.uniform(-np.pi / 6, np.pi / 6), rs.uniform(-2 * np.pi, 2 * np.pi)])
+            q = po.quat_from_euler(rpy)
+        else:
+            q = rs.standard_normal(4); q /= np.linalg.norm(q)
+        r = po.bullet_readback_quat(q)
+        same = np.dot(r, q) > 0
+        np.testing.assert_allclose(r, q if same else -q, rtol=0, atol=2e-15)
+        n_flip += not same
+        # same rotation, and the sign rule stated on the quaternion itself
+        np.testing.assert_allclose(po.matrix_from_quat(r), Rotation.from_quat(q).as_matrix(), rtol=0, atol=1e-15)
+        if q[3] * q[3] > 0.25 + 1e-12:
+            assert r[3] > 0
+        elif q[3] * q[3] < 0.25 - 1e-12:
+            n_else += 1
+            assert r[int(np.argmax(np.abs(q[:3])))] > 0
+        # idempotent up to rounding: what Bullet returns is what it would return again
+        np.testing.assert_allclose(po.bullet_readback_quat(r), r, rtol=0, atol=2e-15)
+        # f32 build: same branch, f32 accuracy
+        np.testing.assert_allclose(po.bullet_readback_quat(q, "f32"), r, rtol=0, atol=3e-7)
+    assert n_flip > 1000 and n_else > 1000
+
+
+@pytest.mark.parametrize("name", ["hover_det", "hover_motor_dr", "takeoff_det", "takeoff_motor_dr", "circle_det"])
+def test_golden_reset_quaternions_carry_bullets_sign(name):
+    """The fixtures were generated through the read-back above: every recorded post-reset quaternion is the
+    canonical one, and for Hover / TakeOff (yaw beyond +-2 pi / 3) a good part of them is -Q(wrapped rpy)."""
+    g = gu.Golden(name)
+    neg = 0
+    for ep in range(g.E):
+        q, rpy = g["reset_quat"][ep], g["reset_rpy"][ep]
+        np.testing.assert_allclose(po.bullet_readback_quat(q), q, rtol=0, atol=2e-15)
+        qw = po.quat_from_euler(rpy)  # what step_forward will write next (envs/physics.py:179)
+        assert abs(abs(np.dot(qw, q)) - 1) < 1e-12
+        neg += np.dot(qw, q) < 0
+        if abs(rpy[2]) < 2 * np.pi / 3 - 0.2:
+            assert np.dot(qw, q) > 0
+        # the first observation carries it (noise-free scenarios: o = [p3, quat4, ...])
+        np.testing.assert_array_equal(g["reset_obs"][ep][3:7], q)
+    if name.startswith("circle"):
+        assert neg == 0  # |yaw| <= 0.1 pi (envs/circle.py:234)
+    elif g.E >= 8:
+        assert neg > 0
+
+
 def test_ground_effect_formula():
     """G7: BasePhysics.calculate_ground_effect (envs/physics.py:27-58)."""
     d = np.load(os.path.join(gu.GOLDEN, "ground_effect.npz"))
