@@ -367,6 +367,11 @@ static void fill_consts(const pds_config &c, Consts &k) {
   k.agg = c.aggregate_phy_steps; k.max_steps = c.max_episode_steps;
   k.reset_dist = c.enable_reset_distribution ? 1 : 0;
   k.ref_points = (c.task == PDS_TASK_CIRCLE) ? 3 * c.observation_frequency : kRefPoints;  // envs/circle.py:47-49
+  {
+    const double dth = 2.0 * M_PI / (double)k.ref_points;
+    k.ref_dth_hi = (float)dth;
+    k.ref_dth_lo = (float)(dth - (double)k.ref_dth_hi);
+  }
   k.obs_rate = 1;
   if (c.observation_noise > 0) {  // obs_rate = sim_freq // observation_frequency, envs/base.py:108
     const int r = (int)llround(1.0 / c.time_step) / c.observation_frequency;

@@ -676,11 +676,7 @@ PDS_DEV void advance_clock(WaveClock *clk, long long tile, const RngKey &rk, int
 // Explicit reset (pds_reset / pds_reset_from_samples): not a hot path.
 template <class V>
 __global__ __launch_bounds__(kBlock) void reset_kernel(const StepArgs a) {
-  __shared__ float2 ref_lds[(V::TASK == PDS_TASK_CIRCLE) ? kRefPoints : 1];
-  if (V::TASK == PDS_TASK_CIRCLE) {
-    for (int t = threadIdx.x; t < a.k.ref_points; t += kBlock) ref_lds[t] = a.st.circle_ref[t];
-    __syncthreads();
-  }
+  const float2 *ref_lds = nullptr;  // (unused: target_at evaluates the reference circle)
   const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
   const long long tile = i / kWave;  // wave-uniform
   if (tile * kWave >= a.n) return;

@@ -31,6 +31,13 @@ constexpr int tile_stride() {
   return (D % 8 == 0) ? D + 4 : D;
 }
 
+// Row stride of the half tile's parking area (first row halves of lanes 32-63): float4 rows want an odd multiple of
+// 16 B (20 floats: yes; 24: padded to 28), scalar rows an odd number of floats (21: yes).
+template <int HW>
+constexpr int park_stride() {
+  return (HW % 4 == 0) ? ((HW / 4) % 2 == 1 ? HW : HW + 4) : (HW % 2 == 1 ? HW : HW + 1);
+}
+
 template <int N>
 PDS_DEV void lds_store_row(float *dst, const float *src) {  // dst 16-byte aligned
   static_assert(N % 4 == 0, "float4 rows");
@@ -50,10 +57,11 @@ PDS_DEV void flush_tile(const float *tile, float *gdst, int rows, int lane) {
       constexpr int NV = TR * D / 4;  // float4 count (D is even, 32*D divisible by 4)
       const float4 *src = reinterpret_cast<const float4 *>(tile);
       float4 *dst = reinterpret_cast<float4 *>(gdst);
+      const uint32_t ln = fresh<1>((uint32_t)lane);
 #pragma unroll
       for (int it = 0; it < (NV + kWave - 1) / kWave; ++it) {
         const int idx = it * kWave + lane;
-        if (idx < NV) nt_store4(dst + idx, src[idx]);
+        if (idx < NV) nt_store4(lane_ptr(dst + it * kWave, ln), src[idx]);  // (uniform base + constant, lane offset)
       }
       return;
     }
@@ -64,10 +72,10 @@ PDS_DEV void flush_tile(const float *tile, float *gdst, int rows, int lane) {
       constexpr int Q = D / 4, RP = kWave / Q, NP = (TR + RP - 1) / RP;
       const int r0 = lane / Q, c = lane - r0 * Q;
       const float4 *src = reinterpret_cast<const float4 *>(tile + r0 * TS + 4 * c);
-      float4 *dst = reinterpret_cast<float4 *>(gdst) + r0 * Q + c;
+      float4 *dst = lane_ptr(reinterpret_cast<float4 *>(gdst), fresh<2>((uint32_t)(r0 * Q + c)));
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        if (r0 < RP && p * RP + r0 < TR) nt_store4(dst + p * RP * Q, src[p * RP * (TS / 4)]);
+        if (r0 < RP && p * RP + r0 < TR) nt_store4(dst + p * RP * Q, src[p * RP * (TS / 4)]);  // (+ compile-time constant: the instruction offset)
       }
       return;
     }
@@ -102,31 +110,31 @@ struct Loaded {
 // u(k-1) is decided by the parity bit of the wave's clock word, which arrives with the same batch of
 // loads -- no load address depends on another load.
 template <class V>
-PDS_DEV void load_env(const StepArgs &a, long long ii, long long tile, Loaded &L) {
+PDS_DEV void load_env(const StepArgs &a, const EnvIdx ix, long long tile, Loaded &L) {
   constexpr int kOrder = PDS_ACT_LOAD_ORDER;
-  if (kOrder == 0 || kOrder == 2) L.act = nt_load4(a.actions + ii);  // read once per step: keep it out of the caches
+  if (kOrder == 0 || kOrder == 2) L.act = nt_load4(at(a.actions, ix));  // read once per step: keep it out of the caches
   if (kOrder == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  L.q0 = st_load4(a.st.s0 + ii);
-  L.q1 = st_load4(a.st.s1 + ii);
-  L.q2 = st_load4(a.st.s2 + ii);
-  L.hA = st_load4(a.st.hist[0] + ii);
-  L.hB = st_load4(a.st.hist[1] + ii);
-  L.ctr = a.st.ctr[ii];
+  L.q0 = st_load4(at(a.st.s0, ix));
+  L.q1 = st_load4(at(a.st.s1, ix));
+  L.q2 = st_load4(at(a.st.s2, ix));
+  L.hA = st_load4(at(a.st.hist[0], ix));
+  L.hB = st_load4(at(a.st.hist[1], ix));
+  L.ctr = *at(a.st.ctr, ix);
   L.clk = a.st.clk[tile];
-  if (V::MOTOR) L.mx = a.st.mx[ii];
+  if (V::MOTOR) L.mx = *at(a.st.mx, ix);
   if (V::DR) {
-    L.p0 = a.st.par0[ii];
-    L.p1 = a.st.par1[ii];
-    if (V::MOTOR) { L.mA = a.st.mA[ii]; L.mK = a.st.mK[ii]; }
+    L.p0 = *at(a.st.par0, ix);
+    L.p1 = *at(a.st.par1, ix);
+    if (V::MOTOR) { L.mA = *at(a.st.mA, ix); L.mK = *at(a.st.mK, ix); }
   }
-  if (V::TN) L.ou = a.st.ou[ii];
-  if (V::CTRL >= 1) { L.pid0 = a.st.pid0[ii]; L.pid1 = a.st.pid1[ii]; }
-  if (V::CTRL == 2) { L.pid2 = a.st.pid2[ii]; L.pid3 = a.st.pid3[ii]; }
+  if (V::TN) L.ou = *at(a.st.ou, ix);
+  if (V::CTRL >= 1) { L.pid0 = *at(a.st.pid0, ix); L.pid1 = *at(a.st.pid1, ix); }
+  if (V::CTRL == 2) { L.pid2 = *at(a.st.pid2, ix); L.pid3 = *at(a.st.pid3, ix); }
   if (V::ON) {
-    L.nz0 = a.st.nz0[ii]; L.nz1 = a.st.nz1[ii];
-    L.oh0 = a.st.oh0[ii]; L.oh1 = a.st.oh1[ii]; L.oh2 = a.st.oh2[ii];
+    L.nz0 = *at(a.st.nz0, ix); L.nz1 = *at(a.st.nz1, ix);
+    L.oh0 = *at(a.st.oh0, ix); L.oh1 = *at(a.st.oh1, ix); L.oh2 = *at(a.st.oh2, ix);
   }
-  if (kOrder == 1) L.act = nt_load4(a.actions + ii);
+  if (kOrder == 1) L.act = nt_load4(at(a.actions, ix));
 }
 
 // Everything one env carries from step to step, in registers (members a variant does not use are
@@ -188,38 +196,40 @@ PDS_DEV void unpack_state(const Consts &k, const Loaded &cur, int parity, EnvSta
 // alone (it already holds S.h2) unless the env was reset in registers (`both`); the K-step kernel
 // rewrites both slots and the randomised parameters.
 template <class V>
-PDS_DEV void store_state(const StepArgs &a, long long i, int new_parity, const EnvState &S, bool both) {
+PDS_DEV void store_state(const StepArgs &a, const EnvIdx i_, int new_parity, const EnvState &S, bool both) {
   const EnvRegs &e = S.e;
-  st_store4(a.st.s0 + i, make_float4(e.px, e.py, e.pz, e.vx));
-  st_store4(a.st.s1 + i, make_float4(e.vy, e.vz, e.roll, e.pitch));
-  st_store4(a.st.s2 + i, make_float4(e.yaw, e.wx, e.wy, e.wz));
-  st_store4(a.st.hist[new_parity] + i, S.h1);
-  a.st.ctr[i] = S.ctr;
-  if (V::MOTOR) a.st.mx[i] = make_float4(S.xm[0], S.xm[1], S.xm[2], S.xm[3]);
-  if (V::TN) a.st.ou[i] = make_float4(S.ns.ou[0], S.ns.ou[1], S.ns.ou[2], S.ns.ou[3]);
+  EnvIdx i = fresh<3>(i_);
+  st_store4(at(a.st.s0, i), make_float4(e.px, e.py, e.pz, e.vx));
+  st_store4(at(a.st.s1, i), make_float4(e.vy, e.vz, e.roll, e.pitch));
+  st_store4(at(a.st.s2, i), make_float4(e.yaw, e.wx, e.wy, e.wz));
+  st_store4(at(a.st.hist[new_parity], i), S.h1);
+  *at(a.st.ctr, i) = S.ctr;
+  if (V::MOTOR) *at(a.st.mx, i) = make_float4(S.xm[0], S.xm[1], S.xm[2], S.xm[3]);
+  if (V::TN) *at(a.st.ou, i) = make_float4(S.ns.ou[0], S.ns.ou[1], S.ns.ou[2], S.ns.ou[3]);
   if (V::CTRL >= 1) {
-    a.st.pid0[i] = make_float4(S.ps.rate_int[0], S.ps.rate_int[1], S.ps.rate_int[2], S.ps.rate_err[0]);
-    a.st.pid1[i] = make_float2(S.ps.rate_err[1], S.ps.rate_err[2]);
+    *at(a.st.pid0, i) = make_float4(S.ps.rate_int[0], S.ps.rate_int[1], S.ps.rate_int[2], S.ps.rate_err[0]);
+    *at(a.st.pid1, i) = make_float2(S.ps.rate_err[1], S.ps.rate_err[2]);
   }
   if (V::CTRL == 2) {
-    a.st.pid2[i] = make_float4(S.ps.att_int[0], S.ps.att_int[1], S.ps.att_int[2], S.ps.att_err[0]);
-    a.st.pid3[i] = make_float2(S.ps.att_err[1], S.ps.att_err[2]);
+    *at(a.st.pid2, i) = make_float4(S.ps.att_int[0], S.ps.att_int[1], S.ps.att_int[2], S.ps.att_err[0]);
+    *at(a.st.pid3, i) = make_float2(S.ps.att_err[1], S.ps.att_err[2]);
   }
   if (V::ON) {
-    a.st.nz0[i] = make_float4(S.ns.bias[0], S.ns.bias[1], S.ns.bias[2], S.ns.lpf[0]);
-    a.st.nz1[i] = make_float2(S.ns.lpf[1], S.ns.lpf[2]);
-    a.st.oh0[i] = make_float4(S.oh.x, S.oh.y, S.oh.z, S.oh.qx);
-    a.st.oh1[i] = make_float4(S.oh.qy, S.oh.qz, S.oh.qw, S.oh.vx);
-    a.st.oh2[i] = make_float2(S.oh.vy, S.oh.vz);
+    *at(a.st.nz0, i) = make_float4(S.ns.bias[0], S.ns.bias[1], S.ns.bias[2], S.ns.lpf[0]);
+    *at(a.st.nz1, i) = make_float2(S.ns.lpf[1], S.ns.lpf[2]);
+    *at(a.st.oh0, i) = make_float4(S.oh.x, S.oh.y, S.oh.z, S.oh.qx);
+    *at(a.st.oh1, i) = make_float4(S.oh.qy, S.oh.qz, S.oh.qw, S.oh.vx);
+    *at(a.st.oh2, i) = make_float2(S.oh.vy, S.oh.vz);
   }
   if (both) {  // written only by resets (no write-after-write with this step's stores)
-    a.st.hist[new_parity ^ 1][i] = S.h2;
+    i = fresh<4>(i_);
+    *at(a.st.hist[new_parity ^ 1], i) = S.h2;
     if (V::DR) {
-      a.st.par0[i] = make_float4(S.par.dt, S.par.m, S.par.Jx, S.par.Jy);
-      a.st.par1[i] = make_float2(S.par.Jz, S.par.ftf1);
+      *at(a.st.par0, i) = make_float4(S.par.dt, S.par.m, S.par.Jx, S.par.Jy);
+      *at(a.st.par1, i) = make_float2(S.par.Jz, S.par.ftf1);
       if (V::MOTOR) {
-        a.st.mA[i] = make_float4(S.par.A[0], S.par.A[1], S.par.A[2], S.par.A[3]);
-        a.st.mK[i] = make_float4(S.par.K[0], S.par.K[1], S.par.K[2], S.par.K[3]);
+        *at(a.st.mA, i) = make_float4(S.par.A[0], S.par.A[1], S.par.A[2], S.par.A[3]);
+        *at(a.st.mK, i) = make_float4(S.par.K[0], S.par.K[1], S.par.K[2], S.par.K[3]);
       }
     }
   }
@@ -316,9 +326,9 @@ struct SubNoise {
 };
 
 template <class V>
-PDS_DEV void sub_noise(const StepArgs &a, const RngKey &rk, uint32_t env_id, long long ii, int sub, SubNoise &n) {
+PDS_DEV void sub_noise(const StepArgs &a, const RngKey &rk, uint32_t env_id, const EnvIdx ix, int sub, SubNoise &n) {
   if (a.noise != nullptr) {  // injected (parity tests): one PDS_NOISE_FLOATS block per physics sub-step
-    const float *p = a.noise + (ii * a.k.agg + sub) * PDS_NOISE_FLOATS;
+    const float *p = a.noise + (ix.global() * a.k.agg + sub) * PDS_NOISE_FLOATS;
 #pragma unroll
     for (int j = 0; j < 4; ++j) n.ou[j] = p[PDS_N_OU + j];
 #pragma unroll
@@ -375,6 +385,10 @@ PDS_DEV void sub_noise(const StepArgs &a, const RngKey &rk, uint32_t env_id, lon
   }
 }
 
+// Variants whose kernel arguments do not fit the SGPR file for the whole step: they re-read them (reload_args).
+template <class V>
+constexpr bool heavy_variant() { return V::MOTOR || V::DR || V::TN || V::ON || V::CTRL != 0 || V::LAT; }
+
 // How an env that finished is reset inside the step (all three produce the same bits):
 //  RM_MERGED   before the wave stores, 8 lanes per finished env, results through ds_bpermute
 //              (reset_in_registers): state and observation leave through the ordinary coalesced stores;
@@ -415,7 +429,7 @@ constexpr int inline_envs_per_pass() { return V::ON ? kResetsPerPass : kResetsPe
 
 template <class V, int TR, int RM, bool STORE>
 PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, int parity, const float2 *ref_lds,
-                       float *tile, uint32_t *queue, U4 *scratch, int lane, long long wave_base, long long i, long long ii,
+                       float *tile, float *park, uint32_t *queue, U4 *scratch, int lane, long long wave_base, const EnvIdx ix,
                        bool active, const float4 act, EnvState &S, int &qcount
 #ifdef PDS_STAMPS
                        , unsigned long long *stamp_
@@ -430,10 +444,18 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
   static_assert(RM != RM_INLINE || TR == kWave, "inline reset: full tile only");
   static_assert(RM != RM_DEFERRED || STORE, "deferred drain: the state must be in HBM before it");
   const Consts &k = a.k;
-  // full tile: the row is built in place in LDS; half tile: in registers, staged pass by pass
-  float rowbuf[(TR == kWave) ? 1 : D];
-  float *row = (TR == kWave) ? tile + lane * TS : rowbuf;
-  const uint32_t env_id = (uint32_t)(a.env_id_base + (unsigned long long)ii);
+  // Full tile: the row is built in place in LDS.  Half tile (the wave stages and flushes its 64 rows in two passes
+  // of 32): the FIRST half of the row -- o(k), known before the physics -- goes straight to LDS as well, into the
+  // tile for lanes 0-31 and into a parking area for lanes 32-63, so that only the second half (o(k+1), written last)
+  // waits in registers for its pass: 20-24 VGPRs instead of a whole 40-48 float row held across the step.  That is
+  // what lets the PT1 + DR variants reset in registers on the half tile (round 2: 61 spilled VGPRs, deferred drain).
+  constexpr int HW = O + 4;           // floats per row half (D == 2 HW)
+  constexpr int PS = park_stride<HW>();
+  constexpr bool VEC1 = (TR == kWave) ? VEC : (TS != D);  // first half as float4 (rows 16-byte aligned in both places)
+  float rowbuf[(TR == kWave) ? 1 : HW];
+  float *row = (TR == kWave) ? tile + lane * TS : (lane < TR ? tile + lane * TS : park + (lane - TR) * PS);
+  float *row2 = (TR == kWave) ? row + HW : rowbuf;
+  const uint32_t env_id = (uint32_t)(a.env_id_base + (unsigned long long)ix.wb) + ix.lc;  // (uniform part in SGPRs)
   const float4 h1 = S.h1, h2 = S.h2;
   const uint32_t ctr = S.ctr;
   EnvRegs &e = S.e;
@@ -469,11 +491,11 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
     float tx, ty, tz;
     target_at<TASK>(k, ref_lds, target_index<TASK>(step, k.agg, phase), tx, ty, tz);
     if (V::ON) {
-      put_noisy_half<TASK, O + 4, VEC>(row, S.oh, ns.lpf, h1, tx, ty, tz, pa1);
+      put_noisy_half<TASK, O + 4, VEC1>(row, S.oh, ns.lpf, h1, tx, ty, tz, pa1);
     } else {
       Quat qk = q;
       if (ctr_sign(ctr)) { qk.x = -q.x; qk.y = -q.y; qk.z = -q.z; qk.w = -q.w; }
-      put_obs_half<TASK, O + 4, VEC>(row, e, qk, h1, tx, ty, tz, pa1);
+      put_obs_half<TASK, O + 4, VEC1>(row, e, qk, h1, tx, ty, tz, pa1);
     }
   }
 
@@ -485,11 +507,11 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
   const float inv_m = fast_rcp(par.m), inv_Jx = fast_rcp(par.Jx), inv_Jy = fast_rcp(par.Jy), inv_Jz = fast_rcp(par.Jz);
   for (int sub = 0; sub < k.agg; ++sub) {
     SubNoise sn;
-    if (V::TN || V::ON) sub_noise<V>(a, rk, env_id, ii, sub, sn);
+    if (V::TN || V::ON) sub_noise<V>(a, rk, env_id, ix, sub, sn);
     // CrazyFlieAgent.apply_action, envs/agents.py:259-298 (+ PWM.act envs/control.py:94-100)
     float av[4] = {act.x, act.y, act.z, act.w};
     if (V::LAT) {  // agents.py:267-276: the controller sees the action of buf_size physics steps ago
-      float4 *slot = a.st.lat + (long long)lat_idx * a.n + ii;
+      float4 *slot = a.st.lat + (long long)lat_idx * a.n + ix.global();  // (the ring index is per env)
       const float4 d = *slot;
       if (active) *slot = act;
       lat_idx = (lat_idx + 1u == (uint32_t)k.lat_steps) ? 0u : lat_idx + 1u;
@@ -624,7 +646,7 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
   // ---- o(k+1) and u(k-1) -> second half of the row (envs/base.py:303-319) --------------------
   if (V::ON) {
     ObsNoise n;
-    if (a.noise != nullptr) obs_noise_load(a.noise + ii * k.agg * PDS_NOISE_FLOATS + PDS_N_OBS, n);  // (block of sub-step 0)
+    if (a.noise != nullptr) obs_noise_load(a.noise + ix.global() * k.agg * PDS_NOISE_FLOATS + PDS_N_OBS, n);  // (block of sub-step 0)
     else obs_noise_philox(env_id, rk, kBlkObsNoise, n);
     sensor_observe(k, e, n, ns, S.oh);
     if (V::HOLD) {  // per env: fresh observation or the held one + the fresh gyro
@@ -634,9 +656,9 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
       S.oh.qw = fresh ? S.oh.qw : held.qw;
       S.oh.vx = fresh ? S.oh.vx : held.vx; S.oh.vy = fresh ? S.oh.vy : held.vy; S.oh.vz = fresh ? S.oh.vz : held.vz;
     }
-    put_noisy_half<TASK, O + 4, VEC>(row + O + 4, S.oh, ns.lpf, act, tx, ty, tz, pa2);
+    put_noisy_half<TASK, O + 4, VEC>(row2, S.oh, ns.lpf, act, tx, ty, tz, pa2);
   } else {
-    put_obs_half<TASK, O + 4, VEC>(row + O + 4, e, q, act, tx, ty, tz, pa2);
+    put_obs_half<TASK, O + 4, VEC>(row2, e, q, act, tx, ty, tz, pa2);
   }
 
   S.ctr = ctr_pack((uint32_t)(step + 1), 0u, (uint32_t)phase1, lat_idx);
@@ -655,6 +677,7 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
       qcount = __popcll(reset_mask);
       if (need_reset) queue[pos] = (uint32_t)lane | ((uint32_t)ref_offset << 6);
     } else if constexpr (RM == RM_MERGED) {
+      const StepArgs &a = reload_args<101, heavy_variant<V>()>((int)o1);  // (shadows the parameter: see "coalesced stores" below)
       const int count = __popcll(reset_mask);
       if (need_reset) queue[pos] = (uint32_t)lane;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -674,12 +697,20 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
   }
 
   // ---- coalesced stores ----------------------------------------------------------------------
+  // From here on the kernel arguments are read through a second, opaque view (reload_args): the pointers and
+  // constants of the first half do not stay live in SGPRs across the step.
+  const StepArgs &a_early = a;
+  (void)a_early;
+  {
+  const StepArgs &a = reload_args<102, heavy_variant<V>()>((int)o1);  // (o1: renewed per iteration of the K-step loop)
+  const Consts &k = a.k;
   if (active) {
-    if constexpr (STORE) store_state<V>(a, i, parity ^ 1, S, was_reset);
-    nt_store(a.reward + o1 + i, reward);
-    nt_store(a.cost + o1 + i, cost);
-    nt_store(a.term + o1 + i, (uint8_t)(done ? 1 : 0));
-    nt_store(a.trunc + o1 + i, (uint8_t)(trunc ? 1 : 0));
+    if constexpr (STORE) store_state<V>(a, ix, parity ^ 1, S, was_reset);
+    const EnvIdx jx = fresh<5>(ix);
+    nt_store(at(a.reward + o1, jx), reward);
+    nt_store(at(a.cost + o1, jx), cost);
+    nt_store(at(a.term + o1, jx), (uint8_t)(done ? 1 : 0));
+    nt_store(at(a.trunc + o1, jx), (uint8_t)(trunc ? 1 : 0));
   }
   PDS_STAMP(4);
   // LDS rows of this wave were written by its own lanes only: wave-synchronous, no block barrier
@@ -689,11 +720,21 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
     if (TR != kWave) {
       if ((lane / TR) == pass) {
         float *dst = tile + (lane % TR) * TS;
+        if (pass == 1) {  // the parked first half of lanes 32-63 moves into the (flushed) tile
+          const float *src = park + (lane - TR) * PS;
+          if constexpr (TS != D) {
+#pragma unroll
+            for (int j = 0; j < HW / 4; ++j) reinterpret_cast<float4 *>(dst)[j] = reinterpret_cast<const float4 *>(src)[j];
+          } else {
+#pragma unroll
+            for (int j = 0; j < HW; ++j) dst[j] = src[j];
+          }
+        }
         if constexpr (TS != D) {
-          lds_store_row<D>(dst, rowbuf);
+          lds_store_row<HW>(dst + HW, rowbuf);
         } else {
 #pragma unroll
-          for (int j = 0; j < D; ++j) dst[j] = rowbuf[j];
+          for (int j = 0; j < HW; ++j) dst[HW + j] = rowbuf[j];
         }
       }
     }
@@ -708,7 +749,7 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
       const int src_lane = __builtin_ctzll(m);
       m &= m - 1ull;
       // non-temporal like the other streamed outputs (same box: 57.7 vs 58.4 us on Hover 2^20)
-      if (lane < D) nt_store(a.final_obs + (o1 + wave_base + src_lane) * D + lane, tile[(src_lane % TR) * TS + lane]);
+      if (lane < D) nt_store(lane_ptr(a.final_obs + (o1 + wave_base + src_lane) * D, fresh<6>((uint32_t)lane)), tile[(src_lane % TR) * TS + lane]);
     }
     if (RM != RM_DEFERRED && reset_mask != 0ull) {  // wave-uniform: the reset envs' rows become [o0, u0, o0', u0]
       if constexpr (RM == RM_INLINE) {
@@ -751,7 +792,7 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
                 // (by value: a conditional between the two lvalues would select a POINTER and push `r` into scratch memory)
                 float4 v = r.lat.r[b < kMaxLatSteps - 1 ? b : 0];
                 if (b == k.lat_steps - 1 || b == kMaxLatSteps - 1) v = r.u0;
-                a.st.lat[(long long)b * a.n + i] = v;
+                *at(a.st.lat + (long long)b * a.n, ix) = v;
               }
           }
         };
@@ -798,6 +839,7 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
     __builtin_amdgcn_wave_barrier();  // the tile is rewritten by the next pass / the reset drain / the next step
   }
   PDS_STAMP(5);
+  }
   return was_reset;
 }
 
@@ -823,10 +865,13 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
 // PT1 + DR at 2^20 82.9 vs 78.6 us (181 VGPRs => 2 waves/SIMD), TakeOff (resets only by the 500-step
 // truncation) 61.4 vs 60.7 us, and under the half tile's 128-VGPR cap it spills (Circle 262 144: 39
 // vs 21 us) -- so those keep the deferred drain.
+#ifndef PDS_MERGED_HALF_PT1DR
+#define PDS_MERGED_HALF_PT1DR 1  // round 3: fits since the half tile parks the first row half in LDS (A/B: 0 = deferred drain)
+#endif
 template <class V, int TR = kWave>
 constexpr bool merged_reset_variant() {
   // (the half tile keeps the whole observation row in registers: PT1 + DR would spill 61 VGPRs there)
-  return PDS_MERGED_RESET && !V::ON && !V::LAT && V::TASK != PDS_TASK_TAKEOFF && (TR == kWave || !(V::MOTOR && V::DR));
+  return PDS_MERGED_RESET && !V::ON && !V::LAT && V::TASK != PDS_TASK_TAKEOFF && (TR == kWave || !(V::MOTOR && V::DR) || (PDS_MERGED_HALF_PT1DR && V::CTRL == 0 && !V::TN));  // (PID / thrust-noise + PT1 + DR: 6-22 spilled VGPRs under the half tile's cap)
 }
 
 // The kernel arguments (StepArgs, ~10 cache lines) are read with scalar loads that the compiler
@@ -864,22 +909,24 @@ PDS_DEV void prefetch_kernargs() {
 #ifndef PDS_XCD_REMAP
 #define PDS_XCD_REMAP 1
 #endif
-#define PDS_WAVE_SETUP(V, TR, RM)                                                                      \
+#define PDS_WAVE_LDS(V, TR, RM)                                                                        \
   __shared__ __attribute__((aligned(16))) float tile_all[(kBlock / kWave) * TR * tile_stride<V::D>()]; \
-  __shared__ float2 ref_lds[(V::TASK == PDS_TASK_CIRCLE) ? kRefPoints : 1];                           \
+  constexpr int kParkFloats_ = (TR == kWave) ? 0 : (kWave - TR) * park_stride<V::O + 4>();             \
+  __shared__ __attribute__((aligned(16))) float park_all[kParkFloats_ > 0 ? (kBlock / kWave) * kParkFloats_ : 4]; \
+  const float2 *ref_lds = nullptr; /* (the Circle table of rounds 1-2: the reference point is evaluated now) */ \
   __shared__ uint32_t queue_all[(kBlock / kWave) * kQueueCap];                                        \
   constexpr int kScratchU4_ = (RM == RM_MERGED) ? kMergedScratchU4 : ((RM == RM_INLINE && inline_coop_variant<V>()) ? inline_envs_per_pass<V>() * kScratchBlocks : 0); \
   __shared__ U4 scratch_all[kScratchU4_ > 0 ? (kBlock / kWave) * kScratchU4_ : 1];                     \
-  U4 *scratch = scratch_all + (threadIdx.x >> 6) * kScratchU4_;                                        \
   const int tid = threadIdx.x;                                                                         \
   const int lane = tid & (kWave - 1);                                                                  \
-  const int wave = tid >> 6;                                                                           \
-  if (V::TASK == PDS_TASK_CIRCLE) {                                                                    \
-    for (int t_ = tid; t_ < a.k.ref_points; t_ += kBlock) ref_lds[t_] = a.st.circle_ref[t_];          \
-    __syncthreads();                                                                                   \
-  }                                                                                                    \
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); /* wave-uniform: everything derived from it lives in SGPRs */ \
+  U4 *scratch = scratch_all + wave * kScratchU4_;                                                      \
   uint32_t *queue = queue_all + wave * kQueueCap;                                                      \
   float *tile = tile_all + wave * (TR * tile_stride<V::D>());                                          \
+  float *park = park_all + wave * kParkFloats_;
+
+#define PDS_WAVE_SETUP(V, TR, RM)                                                                      \
+  PDS_WAVE_LDS(V, TR, RM)                                                                              \
   const long long ntiles = (a.n + kWave - 1) / kWave;                                                  \
   long long blk_ = blockIdx.x;                                                                         \
   if (PDS_XCD_REMAP) { /* blocks b, b + 8, ... (one XCD) take consecutive tiles */                     \
@@ -889,9 +936,10 @@ PDS_DEV void prefetch_kernargs() {
   const long long t = blk_ * (kBlock / kWave) + wave;                                                  \
   if (t >= ntiles) return; /* wave-uniform */                                                          \
   const long long wave_base = t * kWave;                                                               \
-  const long long i = wave_base + lane;                                                                \
-  const bool active = i < a.n;                                                                         \
-  const long long ii = active ? i : (a.n - 1); /* tail lanes recompute the last env, stores masked */
+  const long long rem_ = a.n - wave_base; /* envs of this tile and beyond: > 0, wave-uniform */         \
+  const bool active = rem_ >= kWave || lane < (int)rem_;                                               \
+  /* tail lanes recompute the last env, stores masked */                                               \
+  const EnvIdx ix{wave_base, active ? (uint32_t)lane : (uint32_t)rem_ - 1u};
 
 #ifdef PDS_STAMPS
 #define PDS_STAMP_ARG , stamp_
@@ -909,6 +957,15 @@ PDS_DEV void prefetch_kernargs() {
 #define PDS_STAMP_FLUSH do { } while (0)
 #endif
 
+// One 64-env tile per wave, one block per 4 tiles, no tile loop.  Round 3 re-tried persistent waves (at most the
+// resident number of blocks, each wave walking over several tiles with a static XCD-aware schedule; the kernel
+// arguments re-read per tile through reload_args(), so the loop no longer costs SGPR spills as it did in rounds 1-2):
+// Hover 2^20 64.0 us against 55.6 us for this form, 62.6 us with the next tile's loads software-pipelined in front
+// of the current tile's stores (gfx9 counts loads and stores on one in-order vmcnt, so a load issued behind a
+// tile's stores waits for their acknowledgement), config 6 99.6 / 122 (spills) vs 88.9, 2^21 114.7 vs 104.3
+// (profiles/r03_ab_persistent.txt).  Waves that all start together run their load / compute / store phases in
+// lockstep across the chip; the dispatcher's staggered block starts are what overlaps one block's memory phases
+// with another's arithmetic.
 template <class V, int TR>
 __global__ __launch_bounds__(kBlock, (PDS_MIN_WAVES) * (256 / kBlock)) void step_kernel(const StepArgs a) {
   PDS_STAMP_DECL
@@ -918,7 +975,7 @@ __global__ __launch_bounds__(kBlock, (PDS_MIN_WAVES) * (256 / kBlock)) void step
   // The loads are issued before anything else so that the scalar preamble of the kernel
   // (kernel-argument loads, uniform constants) overlaps with their latency.
   Loaded cur;
-  load_env<V>(a, ii, t, cur);
+  load_env<V>(a, ix, t, cur);
   __builtin_amdgcn_sched_barrier(0);
   PDS_STAMP(1);
   PDS_STAMP_WAIT(2);
@@ -930,13 +987,13 @@ __global__ __launch_bounds__(kBlock, (PDS_MIN_WAVES) * (256 / kBlock)) void step
   EnvState S;
   unpack_state<V>(a.k, cur, parity, S);
   int qcount = 0;  // wave-uniform
-  step_once<V, TR, RM, true>(a, 0ll, rk, parity, ref_lds, tile, queue, scratch, lane, wave_base, i, ii, active, cur.act, S, qcount PDS_STAMP_ARG);
+  step_once<V, TR, RM, true>(a, 0ll, rk, parity, ref_lds, tile, park, queue, scratch, lane, wave_base, ix, active, cur.act, S, qcount PDS_STAMP_ARG);
   if (RM == RM_DEFERRED && qcount > 0) {
     const float own_w[3] = {S.e.wx, S.e.wy, S.e.wz};
-    drain_reset_queue<V>(a, rk, ref_lds, queue, qcount, lane, wave_base, tile, own_w, S.ns.bias);
+    drain_reset_queue<V>(reload_args<104, heavy_variant<V>()>(), rk, ref_lds, queue, qcount, lane, wave_base, tile, own_w, S.ns.bias);
   }
   PDS_STAMP(6);
-  advance_clock(a.st.clk, t, rk, parity ^ 1, 1u, lane);
+  advance_clock(reload_args<105, heavy_variant<V>()>().st.clk, t, rk, parity ^ 1, 1u, lane);
   PDS_STAMP_FLUSH;
 }
 
@@ -961,7 +1018,7 @@ __global__ __launch_bounds__(kBlock, (PDS_STEPK_MIN_WAVES) * (256 / kBlock)) voi
   prefetch_kernargs();
   PDS_WAVE_SETUP(V, TR, RM)
   Loaded cur;
-  load_env<V>(a, ii, t, cur);
+  load_env<V>(a, ix, t, cur);
   RngKey rk{a.seed_lo, a.seed_hi, 0u, 0u};
   int parity;
   rk.tick_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.clk.x);
@@ -974,16 +1031,20 @@ __global__ __launch_bounds__(kBlock, (PDS_STEPK_MIN_WAVES) * (256 / kBlock)) voi
   float4 act = cur.act;  // actions[0]
   int qcount = 0;
   for (int s = 0; s < K; ++s) {
+    // a fresh view of the kernel arguments per iteration: what the loop body needs is re-read (scalar-cache
+    // hits) instead of being hoisted out of the loop into SGPRs that do not exist (41-79 spills in round 2)
+    const StepArgs &al = reload_args<106, heavy_variant<V>()>(s);
     float4 act_next = act;
-    if (s + 1 < K) act_next = nt_load4(a.actions + (long long)(s + 1) * a.n + ii);  // in flight during step s
-    step_once<V, TR, RM, false>(a, (long long)s * a.n, rk, parity, ref_lds, tile, queue, scratch, lane, wave_base, i, ii, active, act, S, qcount PDS_STAMP_ARG);
+    if (s + 1 < K) act_next = nt_load4(at(al.actions + (long long)(s + 1) * al.n, ix));  // in flight during step s
+    step_once<V, TR, RM, false>(al, (long long)s * al.n, rk, parity, ref_lds, tile, park, queue, scratch, lane, wave_base, ix, active, act, S, qcount PDS_STAMP_ARG);
     act = act_next;
     parity ^= 1;
     rk.tick_lo += 1u;
     if (rk.tick_lo == 0u) rk.tick_hi += 1u;
   }
-  if (active) store_state<V>(a, i, parity, S, true);
-  advance_clock(a.st.clk, t, rk0, parity, (uint32_t)K, lane);
+  const StepArgs &az = reload_args<107, heavy_variant<V>()>();
+  if (active) store_state<V>(az, ix, parity, S, true);
+  advance_clock(az.st.clk, t, rk0, parity, (uint32_t)K, lane);
 }
 
 // ---- host-side dispatch: runtime flags -> template instantiation ----------------------------------

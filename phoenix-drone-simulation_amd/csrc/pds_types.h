@@ -50,6 +50,45 @@ PDS_DEV uint32_t circle_ref_offset(uint32_t c, int ref_points) {  // not on the 
   return (uint32_t)(d < 0 ? d + ref_points : d);
 }
 
+// ---- addressing of the per-env streams -------------------------------------------------------------
+// One wave owns the 64 consecutive envs of a tile, so every per-env access of the step is
+//   (wave-uniform 64-bit base: array + first env of the tile, in SGPRs)  +  (32-bit per-lane byte offset)
+// which is the SADDR form of the global instructions (global_load_dwordx4 v, v_off, s[base:base+1]): ONE
+// offset VGPR per element size is shared by all arrays, and no 64-bit vector address (2 VGPRs + a
+// v_lshl_add_u64 each) is formed per stream.  `lc` is the lane, clamped to the last env of the batch for the
+// lanes past the end (they recompute that env; their stores are masked).
+struct EnvIdx {
+  long long wb;  // first env of the tile (wave-uniform)
+  uint32_t lc;   // lane within the tile, clamped
+  PDS_DEV long long global() const { return wb + (long long)lc; }
+};
+template <class T>
+PDS_DEV T *lane_ptr(T *uniform_base, uint32_t index) {  // uniform_base + index, with a 32-bit byte offset
+  return reinterpret_cast<T *>(reinterpret_cast<char *>(uniform_base) + index * (uint32_t)sizeof(T));
+}
+template <class T>
+PDS_DEV const T *lane_ptr(const T *uniform_base, uint32_t index) {
+  return reinterpret_cast<const T *>(reinterpret_cast<const char *>(uniform_base) + index * (uint32_t)sizeof(T));
+}
+template <class T>
+PDS_DEV T *at(T *array, const EnvIdx x) { return lane_ptr(array + x.wb, x.lc); }
+// The instruction selector matches the SADDR form per BASIC BLOCK: it has to see the zero-extension of the
+// 32-bit offset next to the access.  An offset that was extended in an earlier block (common subexpression
+// with the loads at kernel entry) arrives as a 64-bit register and the access falls back to a 64-bit vector
+// address.  `fresh()` makes the lane index opaque (no instruction) at the top of a block of stores.
+// NOT volatile (an asm with unmodelled side effects is a barrier for the scheduler's memory operations): each
+// call site passes its own ID as an unused immediate operand instead, so that two sites are never merged.
+template <int ID>
+PDS_DEV uint32_t fresh(uint32_t lane_index) {
+  asm("" : "+v"(lane_index) : "n"(ID));
+  return lane_index;
+}
+template <int ID>
+PDS_DEV EnvIdx fresh(EnvIdx x) {
+  x.lc = fresh<ID>(x.lc);
+  return x;
+}
+
 // ---- per-wave clock word (device memory) ----------------------------------------------------------
 // x, y: tick (counts pds_reset* / pds_step calls; words 1 and 2 of the Philox counter), z: parity of
 // the action ring.  One word per 64-env tile, read by the wave that owns the tile when it starts
@@ -101,6 +140,7 @@ struct Consts {
   int lat_steps;   // buf_size of the latency ring (0: use_latency False)
   int lat_own1, lat_own2;  // step whose action action_buffer[-1] holds after env.step 1 / 2 (0: still the reset row)
   int ref_points;  // Circle: circle_time * observation_frequency (envs/circle.py:49), <= kRefPoints
+  float ref_dth_hi, ref_dth_lo;  // 2 pi / ref_points split in two floats (the angle of reference point t is t x that)
   int obs_rate;    // sim_freq // observation_frequency (envs/base.py:108); > 1: Kalman-hold branch of compute_observation
 };
 
@@ -124,6 +164,28 @@ struct StepArgs {
   int k_steps;                // step_k_kernel: number of env.step()s per launch
   unsigned long long *stamps;  // diagnostic builds (-DPDS_STAMPS): s_memtime stamps per wave
 };
+
+// A second view of the kernel arguments, for the LATE phases of a kernel.  The kernarg segment is read with
+// scalar loads that the compiler places where a value is first used -- and then keeps: a pointer that is used by
+// the loads at kernel entry and by the stores at the end occupies two SGPRs for the whole kernel, and with ~25
+// arrays + ~60 constants the 102 SGPRs overflow into v_writelane / v_readlane spills (up to 114 per kernel in
+// round 2).  Reading the late phases' arguments through an OPAQUE copy of the kernarg pointer makes those
+// values new loads (scalar-cache hits: the segment was prefetched at entry) instead of live ranges.
+// (Kernels only: the calling kernel's first parameter must be the StepArgs struct.)
+#ifndef PDS_RELOAD_ARGS
+#define PDS_RELOAD_ARGS 1
+#endif
+// ID: one per call site (the asm is not volatile, see fresh(); equal calls would be merged); `tag`: a loop
+// counter when the view has to be renewed per iteration (otherwise the asm is loop-invariant and hoisted).
+// ENABLE = false: the lean variants (no PT1 / DR / noise / PID / latency) fit the SGPR file as they are, and on
+// a latency-bound launch (65 536 envs: one wave per SIMD) every extra scalar-load round trip shows: 7.2 vs 7.0 us.
+template <int ID, bool ENABLE = true>
+PDS_DEV const StepArgs &reload_args(int tag = 0) {
+  auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+  if (!ENABLE || !PDS_RELOAD_ARGS) return *(const StepArgs *)kp;  // the compiler sees the same pointer and keeps the early loads' values
+  asm("" : "+s"(kp) : "n"(ID), "s"(tag));
+  return *(const StepArgs *)kp;  // (C cast: address space 4 -> generic; the loads are inferred back to scalar loads)
+}
 
 // tick + seed of the current call: words of the Philox counter / key
 struct RngKey {
@@ -194,13 +256,19 @@ PDS_DEV void default_params(const Consts &k, Params &p) {
   for (int i = 0; i < 4; ++i) { p.A[i] = k.A; p.K[i] = k.K; }
 }
 
-// Reference trajectories: envs/circle.py:45-56 (table staged per block in LDS),
-// envs/takeoff.py:43-47 (z = k/300).
+// Reference trajectories: envs/circle.py:45-56, envs/takeoff.py:43-47 (z = k/300).  The circle
+// (0.25 (1 - cos th_t), 0.25 sin th_t, 1), th_t = 2 pi t / P, is evaluated, not looked up (round 3): the table of rounds
+// 1-2 cost every block a global-memory round trip and a barrier before its first instruction of the step, and
+// 2.4 KB of LDS; ~27 vector instructions per point with the step's own sincos (abs error 1e-7 x 0.25; the angle
+// from a two-float 2 pi / P so that t x it is exact to 1e-8 rad).  `ref_lds` is unused.
 template <int TASK>
 PDS_DEV void target_at(const Consts &k, const float2 *ref_lds, int t, float &tx, float &ty, float &tz) {
   if (TASK == PDS_TASK_CIRCLE) {
-    const float2 r = ref_lds[t];
-    tx = r.x; ty = r.y; tz = 1.0f;
+    const float tf = (float)t;
+    const float th = fmaf(tf, k.ref_dth_lo, tf * k.ref_dth_hi);
+    float sn, cs;
+    fast_sincos(th, sn, cs);
+    tx = 0.25f * (1.0f - cs); ty = 0.25f * sn; tz = 1.0f;
   } else if (TASK == PDS_TASK_TAKEOFF) {
     tx = 0.f; ty = 0.f; tz = (float)t / 300.0f;
   } else {
