@@ -22,6 +22,16 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+def physical_cores():
+    """Physical cores of the host as `lscpu` counts them (unique core/socket pairs); None if lscpu is absent."""
+    import subprocess
+    try:
+        out = subprocess.run(["lscpu", "-p=CORE,SOCKET"], capture_output=True, text=True, timeout=10).stdout
+        return len({l for l in out.splitlines() if l and not l.startswith("#")}) or None
+    except Exception:
+        return None
+
+
 def cpu_baseline(task, kw, n_cpu, target_seconds=12.0):
     """Time the CPU oracle (C restatement, float32, OpenMP over envs) on a bounded sample of the
     same workload: the SAME number of envs as the GPU run, same action recipe, auto-reset on,
@@ -56,8 +66,11 @@ def cpu_baseline(task, kw, n_cpu, target_seconds=12.0):
         one_t.step(a1[k1 % 8], seed=0, tick=2 + k1)
         k1 += 1
     dt1 = time.perf_counter() - t0
+    phys = physical_cores()
     out = {"value": n_cpu * steps / dt, "unit": "env-steps/s", "cores": int(threads), "kind": "port",
-           "sample": f"oracle/phoenix_oracle.c (C restatement of the reference, float32) + OpenMP on {threads} host threads, "
+           "physical_cores": phys,
+           "sample": f"oracle/phoenix_oracle.c (C restatement of the reference, float32) + OpenMP on {threads} host threads "
+                     f"(`cores`; lscpu: {phys} physical cores), env structs first-touched by the thread that steps them, "
                      f"{n_cpu} envs (= the GPU run's N) x {steps} steps ({dt:.1f} s), same config and action recipe, "
                      f"auto-reset on; value_1_thread: {n1} envs on 1 thread for 3 s",
            "value_1_thread": n1 * k1 / dt1}

@@ -299,6 +299,24 @@ typedef struct pds_mlp {
   const float *w1, *b1, *w2, *b2, *w3, *b3;
 } pds_mlp;
 
+/* ONE launch per rollout (csrc/pds_rollout.h): the T closed-loop steps of the caller's roll_out
+ * (algs/iwpg/iwpg.py:350-385; ActorCritic.step algs/core.py:370-393) --
+ *   V(o) -> d_val_buf[t];  a = mu(o) + exp(log_std) z, log p -> d_act_buf[t], d_logp_buf[t] (the draws of
+ *   pds_gaussian_sample with call = *d_call_base + call_offset + t + 1);  env.step(a) (bitwise pds_step) ->
+ *   d_rew_buf[t], d_term_buf[t], d_trunc_buf[t], d_cost_buf[t], next observation -> d_obs_buf[t + 1];
+ *   V(final observation) of the envs that finished -> d_fval_buf[t] (other entries are left alone: pds_gae never
+ *   reads them);  episode return / length bookkeeping of pds_rollout_record -> d_ep_ret, d_ep_len, d_stats[3]
+ * -- and V(o(T)) -> d_last_val.  d_obs_buf is [T + 1, N, D]: row 0 holds o(0) on entry, rows 1..T are written.
+ * Networks: actor d_in = D, d_out = 4; critic d_in = D, d_out = 1; hidden <= 64; inputs standardised with
+ * d_mean / d_std / eps when given (OnlineMeanStd.forward).  All other buffers are [T, N] ([T, N, 4] actions).
+ * PDS_EUNSUPPORTED for env configurations the kernel is not built for (the caller falls back to the per-step
+ * entry points, which give the same bits). */
+int pds_rollout(pds_handle *h, int T, const pds_mlp *pi, const pds_mlp *vf, const float *d_mean, const float *d_std, float eps,
+                const float *d_log_std, uint64_t seed, const uint64_t *d_call_base, uint64_t call_offset, int deterministic,
+                float *d_obs_buf, float *d_act_buf, float *d_logp_buf, float *d_val_buf, float *d_rew_buf,
+                uint8_t *d_term_buf, uint8_t *d_trunc_buf, float *d_cost_buf, float *d_fval_buf, float *d_last_val,
+                float *d_ep_ret, float *d_ep_len, float *d_stats, void *stream);
+
 /* number of parameters; flat gradient layout = [W1, b1, W2, b2, W3, b3] (torch parameter order) */
 int pds_mlp_param_count(const pds_mlp *m);
 /* floats of scratch the *_grad entry points need (per-wave partial sums) */

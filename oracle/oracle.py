@@ -285,10 +285,13 @@ class OracleBatch:
         self.cfg = task if isinstance(task, Config) else default_config(task, **kwargs)
         self.n = int(n)
         Env = EnvF64 if precision == "f64" else EnvF32
-        self.envs = (Env * self.n)()
-        getattr(self.L, "po_env_init_batch" + self.suf)(C.byref(self.cfg), self.envs, C.c_int64(self.n))
-        self.obs_dim = getattr(self.L, "po_obs_dim" + self.suf)(C.byref(self.cfg))
         self.nthreads = nthreads or self.L.po_max_threads()
+        # untouched memory (a ctypes array would be zero-filled by THIS thread): po_env_init_batch_mt touches every
+        # struct from the OpenMP thread that later steps it (same static schedule) -> first-touch NUMA placement
+        self._env_mem = np.empty(self.n * C.sizeof(Env), np.uint8)
+        self.envs = (Env * self.n).from_buffer(self._env_mem)
+        getattr(self.L, "po_env_init_batch_mt" + self.suf)(C.byref(self.cfg), self.envs, C.c_int64(self.n), C.c_int(self.nthreads))
+        self.obs_dim = getattr(self.L, "po_obs_dim" + self.suf)(C.byref(self.cfg))
         self.obs = np.zeros((self.n, self.obs_dim), self.np_real)
         self.final_obs = np.zeros((self.n, self.obs_dim), self.np_real)
         self.reward = np.zeros(self.n, self.np_real)

@@ -1059,8 +1059,12 @@ void SUF(po_step_batch)(const po_config *c, ENV *envs, int64_t n, const REAL *ac
   (void)nthreads;
 }
 
-void SUF(po_env_init_batch)(const po_config *c, ENV *envs, int64_t n) {
+/* Same static schedule as po_step_batch / po_reset_batch: the thread that will step an env is the one that
+ * touches its struct first (first-touch NUMA placement; the caller passes untouched memory). */
+void SUF(po_env_init_batch_mt)(const po_config *c, ENV *envs, int64_t n, int nthreads) {
+#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(static)
   for (int64_t i = 0; i < n; ++i) SUF(po_env_init)(c, &envs[i]);
 }
+void SUF(po_env_init_batch)(const po_config *c, ENV *envs, int64_t n) { SUF(po_env_init_batch_mt)(c, envs, n, 1); }
 
 int SUF(po_sizeof_env)(void) { return (int)sizeof(ENV); }

@@ -134,7 +134,8 @@ typedef struct po_rng {
   void po_reset_batch##SUF(const po_config *c, po_env##SUF *envs, int64_t n, REAL *obs,             \
                            uint64_t seed, uint64_t tick, int nthreads);                             \
   void po_ctor_noise_batch##SUF(const po_config *c, po_env##SUF *envs, int64_t n, uint64_t seed);           \
-  void po_env_init_batch##SUF(const po_config *c, po_env##SUF *envs, int64_t n);
+  void po_env_init_batch##SUF(const po_config *c, po_env##SUF *envs, int64_t n);                  \
+  void po_env_init_batch_mt##SUF(const po_config *c, po_env##SUF *envs, int64_t n, int nthreads);
 
 PO_DECL(_f64, double)
 PO_DECL(_f32, float)

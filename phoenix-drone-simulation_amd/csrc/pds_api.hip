@@ -815,6 +815,56 @@ extern "C" int pds_field_width(int field) {
 }
 
 // number of envs whose dynamic state holds a NaN or an Inf (diagnostic, see pds_count_nonfinite)
+// One launch per rollout: csrc/pds_rollout.h (the caller's roll_out, algs/iwpg/iwpg.py:350-385).
+extern "C" int pds_rollout(pds_handle *h, int T, const pds_mlp *pi, const pds_mlp *vf, const float *d_mean, const float *d_std,
+                           float eps, const float *d_log_std, uint64_t seed, const uint64_t *d_call_base, uint64_t call_offset,
+                           int deterministic, float *d_obs_buf, float *d_act_buf, float *d_logp_buf, float *d_val_buf,
+                           float *d_rew_buf, uint8_t *d_term_buf, uint8_t *d_trunc_buf, float *d_cost_buf, float *d_fval_buf,
+                           float *d_last_val, float *d_ep_ret, float *d_ep_len, float *d_stats, void *stream) {
+  if (!h) return PDS_EINVAL;
+  if (T < 1) return fail(h, PDS_EINVAL, "pds_rollout: T %d", T);
+  if (!pi || !vf || !d_log_std || !d_obs_buf || !d_act_buf || !d_logp_buf || !d_val_buf || !d_rew_buf || !d_term_buf ||
+      !d_trunc_buf || !d_cost_buf || !d_fval_buf || !d_last_val || !d_ep_ret || !d_ep_len || !d_stats)
+    return fail(h, PDS_EINVAL, "pds_rollout: NULL pointer");
+  if ((d_mean == nullptr) != (d_std == nullptr)) return fail(h, PDS_EINVAL, "pds_rollout: mean and std come together");
+  if (!h->was_reset) return fail(h, PDS_EINVAL, "pds_rollout before pds_reset");
+  const int D = h->obs_dim;
+  for (const pds_mlp *m : {pi, vf})
+    if (m->d_in != D || m->h1 < 1 || m->h1 > 64 || m->h2 < 1 || m->h2 > 64 || (m->activation != 0 && m->activation != 1) ||
+        !m->w1 || !m->b1 || !m->w2 || !m->b2 || !m->w3 || !m->b3)
+      return fail(h, PDS_EINVAL, "pds_rollout: network shape (d_in must be the observation width %d, hidden <= 64)", D);
+  if (pi->d_out != 4 || vf->d_out != 1) return fail(h, PDS_EINVAL, "pds_rollout: actor d_out 4, critic d_out 1");
+  if ((((uintptr_t)d_act_buf) & 15u) || (((uintptr_t)d_obs_buf) & 3u)) return fail(h, PDS_EINVAL, "pds_rollout: alignment");
+  DeviceGuard guard(h->cfg.device);
+  PDS_HIP(h, guard.err);
+  RolloutArgs ra;
+  memset(&ra, 0, sizeof(ra));
+  base_args(h, ra.s);
+  const long long n = h->cfg.num_envs;
+  ra.s.actions = reinterpret_cast<const float4 *>(d_act_buf);  // (load_env's action slot: valid memory, value unused)
+  ra.s.obs = d_obs_buf + n * D;                                 // step t writes o(t + 1) into row t + 1
+  ra.s.reward = d_rew_buf; ra.s.term = d_term_buf; ra.s.trunc = d_trunc_buf; ra.s.cost = d_cost_buf;
+  ra.s.final_obs = nullptr;                                     // (the finished rows stay in LDS)
+  ra.s.k_steps = T;
+  ra.pi = *pi; ra.vf = *vf;
+  ra.mean = d_mean; ra.stdv = d_std; ra.eps = eps; ra.log_std = d_log_std;
+  ra.seed = seed; ra.call_base = reinterpret_cast<const unsigned long long *>(d_call_base); ra.call_offset = call_offset;
+  ra.deterministic = deterministic; ra.T = T;
+  ra.obs0 = d_obs_buf;
+  ra.act_buf = d_act_buf; ra.logp_buf = d_logp_buf; ra.val_buf = d_val_buf; ra.fval_buf = d_fval_buf; ra.last_val = d_last_val;
+  ra.ep_ret = d_ep_ret; ra.ep_len = d_ep_len; ra.stats = d_stats;
+  const dim3 grid((unsigned)((n + kWave - 1) / kWave));
+  bool ok;
+  if (h->cfg.task == PDS_TASK_HOVER) ok = launch_rollout_hover(h->flags, grid, (hipStream_t)stream, ra);
+  else if (h->cfg.task == PDS_TASK_CIRCLE) ok = launch_rollout_circle(h->flags, grid, (hipStream_t)stream, ra);
+  else ok = launch_rollout_takeoff(h->flags, grid, (hipStream_t)stream, ra);
+  if (!ok) return fail(h, PDS_EUNSUPPORTED, "pds_rollout: built for control_mode PWM without latency / hold / ground effect, "
+                                            "with {no, all of} domain randomisation + thrust noise + observation noise");
+  PDS_HIP(h, hipGetLastError());
+  h->tick += (uint64_t)T;
+  return PDS_OK;
+}
+
 __global__ __launch_bounds__(256) void nonfinite_kernel(DevState st, long long n, unsigned long long *count) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   bool bad = false;

@@ -427,10 +427,18 @@ constexpr bool inline_coop_variant() { return V::TASK != PDS_TASK_TAKEOFF; }
 template <class V>
 constexpr int inline_envs_per_pass() { return V::ON ? kResetsPerPass : kResetsPerPass / 2; }
 
+// What a caller that goes on with the step's results in registers gets back (csrc/pds_rollout.h).
+struct StepOut {
+  float reward;
+  bool done, trunc;
+};
+
+// `fin_lds` (optional): [64][D] LDS image that receives the last observation row of every env that finished (the
+// rows that go to final_obs); `so` (optional): reward / flags of this lane's env.
 template <class V, int TR, int RM, bool STORE>
 PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, int parity, const float2 *ref_lds,
                        float *tile, float *park, uint32_t *queue, U4 *scratch, int lane, long long wave_base, const EnvIdx ix,
-                       bool active, const float4 act, EnvState &S, int &qcount
+                       bool active, const float4 act, EnvState &S, int &qcount, float *fin_lds, StepOut *so
 #ifdef PDS_STAMPS
                        , unsigned long long *stamp_
 #endif
@@ -669,7 +677,8 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
   // LDS tile); the reset itself: see RM_* above.
   const bool need_reset = a.auto_reset && (done || trunc) && active;
   const unsigned long long reset_mask = __ballot(need_reset);  // wave-uniform
-  const unsigned long long done_mask = (a.final_obs != nullptr) ? reset_mask : 0ull;  // -> final_obs
+  const unsigned long long done_mask = (a.final_obs != nullptr || fin_lds != nullptr) ? reset_mask : 0ull;  // -> final_obs
+  if (so != nullptr) { so->reward = reward; so->done = done; so->trunc = trunc; }
   bool was_reset = false;
   if (reset_mask != 0ull) {  // wave-uniform
     const int pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(reset_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)reset_mask, 0u));
@@ -749,7 +758,11 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
       const int src_lane = __builtin_ctzll(m);
       m &= m - 1ull;
       // non-temporal like the other streamed outputs (same box: 57.7 vs 58.4 us on Hover 2^20)
-      if (lane < D) nt_store(lane_ptr(a.final_obs + (o1 + wave_base + src_lane) * D, fresh<6>((uint32_t)lane)), tile[(src_lane % TR) * TS + lane]);
+      if (lane < D) {
+        const float v = tile[(src_lane % TR) * TS + lane];
+        if (a.final_obs != nullptr) nt_store(lane_ptr(a.final_obs + (o1 + wave_base + src_lane) * D, fresh<6>((uint32_t)lane)), v);
+        if (fin_lds != nullptr) fin_lds[src_lane * D + lane] = v;
+      }
     }
     if (RM != RM_DEFERRED && reset_mask != 0ull) {  // wave-uniform: the reset envs' rows become [o0, u0, o0', u0]
       if constexpr (RM == RM_INLINE) {
@@ -987,7 +1000,7 @@ __global__ __launch_bounds__(kBlock, (PDS_MIN_WAVES) * (256 / kBlock)) void step
   EnvState S;
   unpack_state<V>(a.k, cur, parity, S);
   int qcount = 0;  // wave-uniform
-  step_once<V, TR, RM, true>(a, 0ll, rk, parity, ref_lds, tile, park, queue, scratch, lane, wave_base, ix, active, cur.act, S, qcount PDS_STAMP_ARG);
+  step_once<V, TR, RM, true>(a, 0ll, rk, parity, ref_lds, tile, park, queue, scratch, lane, wave_base, ix, active, cur.act, S, qcount, nullptr, nullptr PDS_STAMP_ARG);
   if (RM == RM_DEFERRED && qcount > 0) {
     const float own_w[3] = {S.e.wx, S.e.wy, S.e.wz};
     drain_reset_queue<V>(reload_args<104, heavy_variant<V>()>(), rk, ref_lds, queue, qcount, lane, wave_base, tile, own_w, S.ns.bias);
@@ -1036,7 +1049,7 @@ __global__ __launch_bounds__(kBlock, (PDS_STEPK_MIN_WAVES) * (256 / kBlock)) voi
     const StepArgs &al = reload_args<106, heavy_variant<V>()>(s);
     float4 act_next = act;
     if (s + 1 < K) act_next = nt_load4(at(al.actions + (long long)(s + 1) * al.n, ix));  // in flight during step s
-    step_once<V, TR, RM, false>(al, (long long)s * al.n, rk, parity, ref_lds, tile, park, queue, scratch, lane, wave_base, ix, active, act, S, qcount PDS_STAMP_ARG);
+    step_once<V, TR, RM, false>(al, (long long)s * al.n, rk, parity, ref_lds, tile, park, queue, scratch, lane, wave_base, ix, active, act, S, qcount, nullptr, nullptr PDS_STAMP_ARG);
     act = act_next;
     parity ^= 1;
     rk.tick_lo += 1u;

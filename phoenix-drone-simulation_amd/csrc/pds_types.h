@@ -293,6 +293,26 @@ struct LaunchFlags {
 };
 enum LaunchKind { kLaunchStep = 0, kLaunchStepK = 1, kLaunchReset = 2 };
 // one translation unit per (task, family) keeps the build parallel: pds_task_*.hip
+// Arguments of the fused rollout (csrc/pds_rollout.h).
+struct RolloutArgs {
+  StepArgs s;  // FIRST member (reload_args reads the kernarg segment as a StepArgs); reward / term / trunc / cost point
+               // at the [T, N] rollout buffers, obs at obs_buf + N D (step t writes o(t + 1) into row t + 1)
+  pds_mlp pi, vf;
+  const float *mean, *stdv;  // optional standardisation of the network inputs (both or none)
+  float eps;
+  const float *log_std;      // [d_out]
+  unsigned long long seed;   // Philox key of the action noise (pds_gaussian_sample)
+  const unsigned long long *call_base;  // device word added to call_offset (hipGraph replays), or nullptr
+  unsigned long long call_offset;       // step t samples with call = *call_base + call_offset + t + 1
+  int deterministic, T;
+  const float *obs0;         // [N, D] o(0) (= obs_buf row 0)
+  float *act_buf, *logp_buf, *val_buf, *fval_buf, *last_val;
+  float *ep_ret, *ep_len, *stats;
+};
+
+bool launch_rollout_hover(const LaunchFlags &f, dim3 grid, hipStream_t s, const RolloutArgs &ra);
+bool launch_rollout_circle(const LaunchFlags &f, dim3 grid, hipStream_t s, const RolloutArgs &ra);
+bool launch_rollout_takeoff(const LaunchFlags &f, dim3 grid, hipStream_t s, const RolloutArgs &ra);
 void launch_hover(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
 void launch_circle(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
 void launch_takeoff(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);

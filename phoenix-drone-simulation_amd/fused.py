@@ -139,6 +139,22 @@ def counter_add(counter, inc):
         raise RuntimeError(f"pds_counter_add -> {rc}")
 
 
+def fused_rollout(env, fm_pi, fm_v, T, mean, std, eps, log_std, seed, call_offset, deterministic, obs_buf, act_buf, logp_buf,
+                  val_buf, rew_buf, term_buf, trunc_buf, cost_buf, fval_buf, last_val, ep_ret, ep_len, stats, call_base=None):
+    """ONE launch for the T closed-loop steps of a rollout (include/pds.h pds_rollout, csrc/pds_rollout.h): obs_buf is
+    [T + 1, N, D] with o(0) in row 0.  Raises NotImplementedError for env configurations the kernel is not built
+    for (the per-step path gives the same bits)."""
+    fm_pi._bind(); fm_v._bind()
+    with _on(obs_buf):
+        rc = env.lib.pds_rollout(env._handle, int(T), C.byref(fm_pi.m), C.byref(fm_v.m), _ptr(mean), _ptr(std), float(eps),
+                                 _ptr(log_std), int(seed), _ptr(call_base), int(call_offset), int(bool(deterministic)),
+                                 _ptr(obs_buf), _ptr(act_buf), _ptr(logp_buf), _ptr(val_buf), _ptr(rew_buf), _ptr(term_buf),
+                                 _ptr(trunc_buf), _ptr(cost_buf), _ptr(fval_buf), _ptr(last_val), _ptr(ep_ret), _ptr(ep_len),
+                                 _ptr(stats), FusedMLP._stream(obs_buf))
+    if rc != native.OK:
+        native.check(env._handle, rc, "pds_rollout")
+
+
 def gaussian_sample(mu, log_std, act_out, logp_out, seed, call, id_base=0, deterministic=False, call_base=None):
     """act_out[n, d] = mu + exp(log_std) * z, logp_out[n] = log N(act | mu, sigma) summed over d.  The Philox
     call counter is `call` (+ the int64 device word `call_base` when given: hipGraph-capturable form)."""

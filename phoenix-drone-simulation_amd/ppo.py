@@ -216,7 +216,7 @@ class PPOTrainer:
                  train_v_iterations=5, num_mini_batches=16, target_kl=0.01, use_kl_early_stopping=False,
                  use_linear_lr_decay=True, use_exploration_noise_anneal=True, use_reward_scaling=True,
                  use_standardized_obs=True, use_max_grad_norm=False, max_grad_norm=0.5, ac_kwargs=None,
-                 seed=0, fused=None, graph_rollout=None):
+                 seed=0, fused=None, graph_rollout=None, fused_rollout=None):
         self.env, self.T, self.N = env, int(rollout_len), env.num_envs
         self.epochs, self.gamma, self.lam, self.clip_ratio = epochs, gamma, lam, clip_ratio
         self.entropy_coef = entropy_coef if use_entropy else 0.0
@@ -249,6 +249,14 @@ class PPOTrainer:
             graph_rollout = env.num_envs <= 262144 and getattr(env, "observation_history_size", 2) == 2
         self.graph_rollout = bool(graph_rollout) and self.fused and (rollout_len % 2 == 0)
         self._graph, self._graph_stats, self._call_base = None, None, None
+        # ONE launch per rollout (csrc/pds_rollout.h: networks + sampling + env step + bookkeeping for all T steps,
+        # the env state in registers, the observation tile in LDS); None = use it when the env configuration has an
+        # instantiation (found out at the first rollout), False = the per-step kernels (same bits)
+        if fused_rollout is None and env.num_envs > 262144:
+            # one 64-env tile per 256-thread block, one block per CU: from ~2^19 envs the per-step kernels (all CUs
+            # streaming, 3-4 blocks per CU) win -- 2^20 x 8: 9.1 vs 6.3 ms; 65 536 x 32: 2.2 vs 3.0; 8 192 x 64: 1.1 vs 4.1
+            fused_rollout = False
+        self.fused_rollout = fused_rollout
         if self.fused:
             from .fused import FusedMLP
             self.fm_pi = FusedMLP(self.ac.pi.net, kw["pi"]["activation"])
@@ -257,7 +265,10 @@ class PPOTrainer:
             self.pi_opt._opt_called = True
         T, N, D = self.T, self.N, env.obs_dim
         f = dict(device=dev, dtype=torch.float32)
-        self.obs_buf = torch.zeros(T, N, D, **f)
+        self._obs_buf = torch.zeros(T + 1, N, D, **f)  # row T: o(T), written by the fused rollout
+        self.obs_buf = self._obs_buf[:T]
+        self.cost_buf = torch.zeros(T, N, **f)
+        self._last_val_buf = torch.zeros(N, **f)
         self.act_buf = torch.zeros(T, N, 4, **f)
         self.rew_buf, self.val_buf, self.logp_buf, self.fval_buf = (torch.zeros(T, N, **f) for _ in range(4))
         self.term_buf = torch.zeros(T, N, device=dev, dtype=torch.uint8)
@@ -271,9 +282,34 @@ class PPOTrainer:
     def roll_out(self):
         """algs/iwpg/iwpg.py:350-385 over all envs at once.  Returns per-epoch episode statistics."""
         self.ac.train()
+        if self.fused and self.fused_rollout is not False and getattr(self.env, "observation_history_size", 2) == 2:
+            try:
+                return self._roll_out_fused()
+            except NotImplementedError:
+                if self.fused_rollout:  # asked for explicitly
+                    raise
+                self.fused_rollout = False
         if self.graph_rollout:
             return self._roll_out_graph()
         return self._roll_out_eager()
+
+    @torch.no_grad()
+    def _roll_out_fused(self):
+        """The whole rollout in one launch (pds_rollout).  Same draws as the per-step path: step t samples with
+        call counter `_sample_calls + t + 1`."""
+        from .fused import fused_rollout
+        mean, std, eps = self._oms()
+        stats = torch.zeros(3, device=self.obs.device)
+        self._obs_buf[0].copy_(self.obs)
+        fused_rollout(self.env, self.fm_pi, self.fm_v, self.T, mean, std, eps, self.ac.pi.log_std, self._sample_seed,
+                      self._sample_calls, not self.ac.training, self._obs_buf, self.act_buf, self.logp_buf, self.val_buf,
+                      self.rew_buf, self.term_buf, self.trunc_buf, self.cost_buf, self.fval_buf, self._last_val_buf,
+                      self.ep_ret, self.ep_len, stats)
+        self._sample_calls += self.T
+        self.fused_rollout = True
+        self.obs = self._obs_buf[self.T]  # (a view: copied into row 0 before the next launch overwrites it)
+        self.last_val = self._last_val_buf
+        return stats
 
     def _roll_out_graph(self):
         """The same launches, captured once (7 per step x T) and replayed per epoch: one host call per rollout."""

@@ -300,3 +300,61 @@ def test_graph_captured_rollout_equals_eager_rollout_bitwise():
     assert a._sample_calls == b._sample_calls == 64
     assert a.env.sync_tick() == b.env.tick
     a.env.close(); b.env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("task,kw,n", [
+    ("DroneHoverSimpleEnv-v0", dict(observation_noise=-1, domain_randomization=-1, motor_thrust_noise=0), 512),
+    ("DroneHoverSimpleEnv-v0", dict(), 1000),                                   # reference defaults, ragged last tile
+    ("DroneCircleSimpleEnv-v0", dict(use_motor_dynamics=True), 256),            # PT1 + DR + noise
+    ("DroneTakeOffSimpleEnv-v0", dict(), 192),
+])
+def test_fused_rollout_equals_per_step_rollout_bitwise(task, kw, n):
+    """pds_rollout (ONE launch for the T closed-loop steps: both networks on the matrix cores, Gaussian sampling, env
+    step with the state in registers, V(final_obs), episode bookkeeping; csrc/pds_rollout.h) against the per-step
+    kernels of round 2 (7 launches per step): every rollout buffer bit for bit, over two consecutive rollouts with an
+    update of the running statistics in between, short episodes so that resets and TimeLimit truncations occur."""
+    import phoenix_drone_simulation_amd as pds
+    from phoenix_drone_simulation_amd.ppo import PPOTrainer
+    T = 12
+    tr = []
+    for fused_rollout in (True, False):
+        env = pds.make(task, num_envs=n, seed=3, max_episode_steps=9, **kw)
+        tr.append(PPOTrainer(env, rollout_len=T, epochs=4, seed=5, fused=True, graph_rollout=False, fused_rollout=fused_rollout))
+    a, b = tr
+    for rnd in range(2):
+        sa, sb = a.roll_out(), b.roll_out()
+        torch.cuda.synchronize()
+        assert a.fused_rollout is True and b.fused_rollout is False
+        for name in ("obs_buf", "act_buf", "logp_buf", "val_buf", "rew_buf", "term_buf", "trunc_buf", "ep_ret", "ep_len", "last_val"):
+            x, y = getattr(a, name), getattr(b, name)
+            assert torch.equal(x, y), (rnd, name, (x != y).nonzero()[:4])
+        assert torch.equal(a.obs, b.obs)
+        done = (a.term_buf | a.trunc_buf).bool()
+        assert int(done.sum()) >= n  # max_episode_steps = 9 < T
+        assert torch.equal(a.fval_buf[done], b.fval_buf[done])
+        torch.testing.assert_close(sa, sb, rtol=1e-5, atol=1e-3)  # (sums over all envs: atomics, order differs)
+        for f in ("pos", "vel", "rpy", "omega", "last_action", "step_count"):
+            assert torch.equal(a.env.get_state(f), b.env.get_state(f)), f
+        assert a.env.tick == b.env.tick and a._sample_calls == b._sample_calls
+        # move the running statistics / weights identically on both before the second rollout
+        for t_ in tr:
+            t_.ac.obs_oms.update(t_.obs_buf.reshape(-1, t_.obs_buf.shape[-1])) if t_.ac.obs_oms is not None else None
+            with torch.no_grad():
+                for p_ in t_.ac.parameters():
+                    p_.mul_(1.01)
+    for t_ in tr:
+        t_.env.close()
+
+
+@pytest.mark.gpu
+def test_fused_rollout_refuses_what_it_is_not_built_for_and_the_trainer_falls_back():
+    import phoenix_drone_simulation_amd as pds
+    from phoenix_drone_simulation_amd.ppo import PPOTrainer
+    env = pds.make("DroneHoverSimpleEnv-v0", num_envs=128, seed=3, control_mode="AttitudeRate")
+    tr = PPOTrainer(env, rollout_len=4, epochs=2, seed=5, fused=True)
+    tr.roll_out()
+    assert tr.fused_rollout is False  # PDS_EUNSUPPORTED -> per-step kernels
+    with pytest.raises(NotImplementedError):
+        PPOTrainer(env, rollout_len=4, epochs=2, seed=5, fused=True, fused_rollout=True).roll_out()
+    env.close()
