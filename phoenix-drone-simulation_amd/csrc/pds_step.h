@@ -425,7 +425,11 @@ template <class V>
 constexpr bool inline_coop_variant() { return V::TASK != PDS_TASK_TAKEOFF; }
 // envs per pass: the scratch of the noise-free latency variants has to leave room for 3 blocks per CU
 template <class V>
-constexpr int inline_envs_per_pass() { return V::ON ? kResetsPerPass : kResetsPerPass / 2; }
+constexpr int inline_envs_per_pass() {
+  // 8 where the LDS budget of 3 blocks per CU allows it (Hover's 34-float noisy rows), 4 for the padded 40-float rows
+  // of Circle (8 cost it the third block per CU: 104.7 vs 91.8 us) and for the 22-block latency variants
+  return (V::ON && !V::LAT && tile_stride<V::D>() == V::D) ? kResetsPerPass : kResetsPerPass / 2;
+}
 
 // What a caller that goes on with the step's results in registers gets back (csrc/pds_rollout.h).
 struct StepOut {
@@ -714,7 +718,12 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
   const StepArgs &a = reload_args<102, heavy_variant<V>()>((int)o1);  // (o1: renewed per iteration of the K-step loop)
   const Consts &k = a.k;
   if (active) {
-    if constexpr (STORE) store_state<V>(a, ix, parity ^ 1, S, was_reset);
+    // (RM_INLINE: a finished env's lane stores the FRESH state from inside the reset below, nothing here: no
+    //  write-after-write between the two, hence no wait for these stores)
+    if constexpr (STORE && RM != RM_INLINE) store_state<V>(a, ix, parity ^ 1, S, was_reset);
+    if constexpr (STORE && RM == RM_INLINE) {
+      if (!need_reset) store_state<V>(a, ix, parity ^ 1, S, false);
+    }
     const EnvIdx jx = fresh<5>(ix);
     nt_store(at(a.reward + o1, jx), reward);
     nt_store(at(a.cost + o1, jx), cost);
@@ -778,20 +787,42 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
           const float bias[3] = {ns.bias[0], ns.bias[1], ns.bias[2]};
           ResetOut r;
           reset_compute<V>(a, ref_lds, dw, ctr_pack(0u, 0u, (uint32_t)ref_offset), nullptr, stale_w, bias, r);
-          e = r.e;
-          S.ctr = r.ctr;
-          S.h1 = r.u0; S.h2 = r.u0;
-          xm[0] = r.mx.x; xm[1] = r.mx.y; xm[2] = r.mx.z; xm[3] = r.mx.w;
-          if (V::DR) par = r.par;
+          if constexpr (STORE) {
+            // single-step kernel: the finished env's lane has not stored its (terminal) state -- see "coalesced
+            // stores" -- and stores the fresh one here, straight out of the reset's result: the step's own state
+            // registers are dead by now, so the result does not have to be merged into them (the K-step kernel's
+            // form below costs 9-88 spilled VGPRs under the single-step kernel's 168-register cap)
+            EnvState F;
+            F.e = r.e; F.ctr = r.ctr; F.h1 = r.u0; F.h2 = r.u0;
+            F.xm[0] = r.mx.x; F.xm[1] = r.mx.y; F.xm[2] = r.mx.z; F.xm[3] = r.mx.w;
+            F.par = r.par;
 #pragma unroll
-          for (int j = 0; j < 3; ++j) { ps.rate_int[j] = ps.rate_err[j] = ps.att_int[j] = ps.att_err[j] = 0.f; }
+            for (int j = 0; j < 4; ++j) F.ns.ou[j] = ns.ou[j];  // the OU state is never reset (envs/agents.py:377-386)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+              F.ns.bias[j] = r.ns.bias[j]; F.ns.lpf[j] = r.ns.lpf[j];
+              F.ps.rate_int[j] = F.ps.rate_err[j] = F.ps.att_int[j] = F.ps.att_err[j] = 0.f;
+            }
+            F.oh = r.ob;
+            store_state<V>(a, ix, parity ^ 1, F, true);
+          } else {
+            e = r.e;
+            S.ctr = r.ctr;
+            S.h1 = r.u0; S.h2 = r.u0;
+            xm[0] = r.mx.x; xm[1] = r.mx.y; xm[2] = r.mx.z; xm[3] = r.mx.w;
+            if (V::DR) par = r.par;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { ps.rate_int[j] = ps.rate_err[j] = ps.att_int[j] = ps.att_err[j] = 0.f; }
+          }
           float tx0, ty0, tz0;
           target_at<TASK>(k, ref_lds, target_index<TASK>(0, k.agg, (int)ctr_off(r.ctr)), tx0, ty0, tz0);
           float *dst = tile + lane * TS;
           if (V::ON) {
+            if constexpr (!STORE) {
 #pragma unroll
-            for (int j = 0; j < 3; ++j) { ns.bias[j] = r.ns.bias[j]; ns.lpf[j] = r.ns.lpf[j]; }
-            S.oh = r.ob;
+              for (int j = 0; j < 3; ++j) { ns.bias[j] = r.ns.bias[j]; ns.lpf[j] = r.ns.lpf[j]; }
+              S.oh = r.ob;
+            }
             put_noisy_half<TASK, O + 4, (TS != D)>(dst, r.oa, r.lpf_a, r.u0, tx0, ty0, tz0, r.u0);
             put_noisy_half<TASK, O + 4, (TS != D)>(dst + O + 4, r.ob, r.ns.lpf, r.u0, tx0, ty0, tz0, r.u0);
           } else {
@@ -878,6 +909,21 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
 // PT1 + DR at 2^20 82.9 vs 78.6 us (181 VGPRs => 2 waves/SIMD), TakeOff (resets only by the 500-step
 // truncation) 61.4 vs 60.7 us, and under the half tile's 128-VGPR cap it spills (Circle 262 144: 39
 // vs 21 us) -- so those keep the deferred drain.
+// Round 3: the observation-noise and latency variants (no merged form) reset in registers too in the single-step
+// kernel -- the inline reset of the K-step kernel, with the state stored AFTER it -- instead of the deferred drain,
+// whose `s_waitcnt vmcnt(0)` put a full store round trip, a second evaluation pass and ~25 scattered stores behind
+// the wave's own stores on more than half of the waves.  (TakeOff, whose envs only finish by the 500-step
+// truncation, keeps the drain.)
+#ifndef PDS_INLINE_SINGLE_STEP
+#define PDS_INLINE_SINGLE_STEP 1  // A/B: 0 = deferred drain
+#endif
+template <class V, int TR>
+constexpr bool inline_reset_single_step() {
+  // (Circle with the latency ring or a PID mode measured 3-7 % slower than its drain: 2-10 spilled VGPRs)
+  return PDS_INLINE_SINGLE_STEP && TR == kWave && (V::ON || V::LAT) && V::TASK != PDS_TASK_TAKEOFF &&
+         !(V::TASK == PDS_TASK_CIRCLE && (V::LAT || V::CTRL != 0));
+}
+
 #ifndef PDS_MERGED_HALF_PT1DR
 #define PDS_MERGED_HALF_PT1DR 1  // round 3: fits since the half tile parks the first row half in LDS (A/B: 0 = deferred drain)
 #endif
@@ -983,7 +1029,7 @@ template <class V, int TR>
 __global__ __launch_bounds__(kBlock, (PDS_MIN_WAVES) * (256 / kBlock)) void step_kernel(const StepArgs a) {
   PDS_STAMP_DECL
   prefetch_kernargs();
-  constexpr int RM = merged_reset_variant<V, TR>() ? RM_MERGED : RM_DEFERRED;
+  constexpr int RM = merged_reset_variant<V, TR>() ? RM_MERGED : (inline_reset_single_step<V, TR>() ? RM_INLINE : RM_DEFERRED);
   PDS_WAVE_SETUP(V, TR, RM)
   // The loads are issued before anything else so that the scalar preamble of the kernel
   // (kernel-argument loads, uniform constants) overlaps with their latency.
