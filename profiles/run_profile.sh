@@ -10,7 +10,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="$REPO/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-traffic ${BENCH_ARGS:-}"
+ARGS="$REPO/bench.py --steps ${PROFILE_STEPS:-500} --warmup ${PROFILE_WARMUP:-50} --no-cpu-baseline --no-traffic ${BENCH_ARGS:-}"  # (the default bench window, so that the profiled average is the one bench.py times)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $ARGS > "$OUT/bench_trace.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 $ARGS > "$OUT/bench_pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 $ARGS > "$OUT/bench_pmc_write.log" 2>&1

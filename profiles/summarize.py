@@ -36,7 +36,7 @@ def main(out):
     print(f"# rocprofv3 summary ({os.path.basename(out)})\n")
     stats = find(os.path.join(out, "trace"), "kernel_stats.csv")
     if stats:
-        print("## --kernel-trace --stats (python3 bench.py --steps 100 --warmup 10)\n")
+        print("## --kernel-trace --stats (python3 bench.py --steps 500 --warmup 50: the default bench window)\n")
         print("| kernel | calls | total ns | avg ns | min ns | max ns | % |")
         print("|---|---|---|---|---|---|---|")
         for r in csv.DictReader(open(stats)):
