@@ -21,6 +21,9 @@
 
 namespace pds {
 
+#ifndef PDS_ROLLOUT_SKIP
+#define PDS_ROLLOUT_SKIP 0  // profiling builds only: 1 = no network passes, 2 = no env step, 4 = no V(final_obs)
+#endif
 constexpr int kRolloutThreads = 256;
 
 // network input of this lane: features 16 kt + 4 g + q of row `r` of an LDS image with row stride `stride`
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void rollout_kernel(const Rollo
     const RolloutArgs &rl = *reinterpret_cast<const RolloutArgs *>(&reload_args<201, true>(s));
     const long long o1 = (long long)s * rl.s.n;
     // ---- networks on o(s): 16 samples per wave --------------------------------------------------------
-    {
+    if (!(PDS_ROLLOUT_SKIP & 1)) {
       f32x4 xin[NIN];
       gather_input<NIN>(tile, TS, r16, D, mus, iss, g, xin);
       const f32x4 v = (rl.vf.activation == 0) ? forward16<0, NIN>(wvf, xin, n16, g) : forward16<1, NIN>(wvf, xin, n16, g);
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void rollout_kernel(const Rollo
     }
     __syncthreads();  // actions in LDS; every wave is done reading the tile
     // ---- env.step by wave 0 (state in registers) --------------------------------------------------------
-    if (wave == 0) {
+    if (wave == 0 && !(PDS_ROLLOUT_SKIP & 2)) {
       const float4 act = act_lds[lane];
       StepOut so;
       step_once<V, kWave, RM, false>(rl.s, o1, rk, parity, nullptr, tile, nullptr, queue, scratch_all, lane, wave_base, ix, active, act,
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void rollout_kernel(const Rollo
     }
     __syncthreads();  // o(s + 1) in the tile, the finished envs' last rows in `fin`
     // ---- V(final_obs) where an env finished (the other rows of fval_buf are never read: pds_gae) -----
-    {
+    if (!(PDS_ROLLOUT_SKIP & 4)) {
       const bool dn = done_lds[r16] != 0u;
       if (__ballot(dn) != 0ull) {  // wave-uniform: one of this wave's 16 envs finished
         f32x4 xin[NIN];
