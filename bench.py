@@ -32,10 +32,10 @@ def physical_cores():
         return None
 
 
-def cpu_baseline(task, kw, n_cpu, target_seconds=12.0):
+def cpu_baseline(task, kw, n_cpu, target_seconds=8.0):
     """Time the CPU oracle (C restatement, float32, OpenMP over envs) on a bounded sample of the
     same workload: the SAME number of envs as the GPU run, same action recipe, auto-reset on,
-    as many steps as fit in ~12 s.  Reported baseline only."""
+    as many steps as fit in ~8 s by the pilot timing (10-30 s in practice).  Reported baseline only."""
     import numpy as np
     from oracle import oracle as po
     threads = po.lib().po_max_threads()
