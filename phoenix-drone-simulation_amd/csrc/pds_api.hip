@@ -450,13 +450,14 @@ extern "C" int pds_create(const pds_config *cfg, pds_handle **out) {
   }
   if (cfg->observation_noise > 0) {
     const int obs_rate = (int)llround(1.0 / cfg->time_step) / cfg->observation_frequency;
-    if (obs_rate != 1 && (cfg->control_mode != PDS_CTRL_PWM || cfg->use_latency || cfg->use_ground_effect))
+    if (obs_rate != 1 && (cfg->control_mode != PDS_CTRL_PWM || cfg->use_latency))
       PDS_CREATE_FAIL(PDS_EUNSUPPORTED, "observation noise with obs_rate %d > 1 (Kalman-hold branch) is built for control_mode PWM "
-                      "without latency / ground effect", obs_rate);
+                      "without latency", obs_rate);
   }
   const int lat_steps = cfg->use_latency ? latency_steps_ctor(cfg->latency, cfg->time_step) : 0;
   if (lat_steps > kMaxLatSteps) PDS_CREATE_FAIL(PDS_EUNSUPPORTED, "latency %g s = %d steps (limit %d)", cfg->latency, lat_steps, kMaxLatSteps);
-  if (cfg->use_latency && cfg->use_ground_effect) PDS_CREATE_FAIL(PDS_EUNSUPPORTED, "use_latency with the ground-effect extension is not built");
+  // (use_latency + the ground-effect extension: built for control_mode PWM since round 3; the PID modes have no
+  //  ground-effect instantiation at all, refused above)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device >= ndev)
     PDS_CREATE_FAIL(PDS_ENODEVICE, "no HIP device %d (found %d); there is no CPU fallback", cfg->device, ndev);
@@ -601,7 +602,7 @@ extern "C" int pds_set_tick(pds_handle *h, uint64_t tick) {
 // CrazyFlieAgent.set_latency, envs/agents.py:388-404
 extern "C" int pds_set_latency(pds_handle *h, double latency) {
   if (!h) return PDS_EINVAL;
-  if (h->flags.ge) return fail(h, PDS_EUNSUPPORTED, "use_latency with the ground-effect extension is not built");
+  if (h->flags.ge && h->flags.ctrl != 0) return fail(h, PDS_EUNSUPPORTED, "use_latency with the ground-effect extension: control_mode PWM only");
   int steps = 0;
   if (!(latency < h->cfg.time_step)) {
     steps = (int)(latency / h->cfg.time_step);  // int(self.latency / self.TIME_STEP)

@@ -1150,7 +1150,7 @@ struct VariantDispatch {
 // Families (one translation unit each, see pds_task_*.hip):
 //  base: control_mode PWM, no latency: motor x DR x GE x TN x ON  (32 step variants, half + full tile)
 //  pid:  AttitudeRate / Attitude, no ground effect, no latency     (2 x 16)
-//  lat:  use_latency, any control mode, no ground effect            (3 x 16; TakeOff: PWM only)
+//  lat:  use_latency, any control mode; ground effect with PWM only  (32 + 2 x 16; TakeOff: PWM only)
 // The reset kernel does not depend on GE / TN / CTRL: those flags are folded to false / 0 for it.
 template <int TASK>
 inline void launch_base(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a) {
@@ -1165,28 +1165,25 @@ inline void launch_pid(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s,
 template <int TASK>
 inline void launch_lat(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a) {
   if (kind == kLaunchReset) { VariantDispatch<TASK, 0, true, false>::run(kind, false, grid, s, a, f.motor, f.dr, false, false, f.on); return; }
-  if (TASK == PDS_TASK_TAKEOFF || f.ctrl == 0) VariantDispatch<TASK, 0, true, false>::run(kind, false, grid, s, a, f.motor, f.dr, false, f.tn, f.on);
+  if (TASK == PDS_TASK_TAKEOFF || f.ctrl == 0) VariantDispatch<TASK, 0, true, false>::run(kind, false, grid, s, a, f.motor, f.dr, f.ge, f.tn, f.on);
   else if constexpr (TASK != PDS_TASK_TAKEOFF) {  // TakeOff fixes control_mode='PWM', envs/takeoff.py:225
     if (f.ctrl == 1) VariantDispatch<TASK, 1, true, false>::run(kind, false, grid, s, a, f.motor, f.dr, false, f.tn, f.on);
     else VariantDispatch<TASK, 2, true, false>::run(kind, false, grid, s, a, f.motor, f.dr, false, f.tn, f.on);
   }
 }
 
-// hold: observation noise with obs_rate > 1 (control_mode PWM, no latency, no ground effect): motor x DR x TN
+// hold: observation noise with obs_rate > 1 (control_mode PWM, no latency): motor x DR x GE x TN
 template <int TASK>
 inline void launch_hold(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a) {
-  // MOTOR, DR, GE = false, TN, ON = true: bind the two constants first
-  if (f.motor) {
-    if (f.dr) { if (f.tn) launch_variant<Variant<TASK, true, true, false, true, true, 0, false, true>>(kind, false, grid, s, a);
-                else launch_variant<Variant<TASK, true, true, false, false, true, 0, false, true>>(kind, false, grid, s, a); }
-    else { if (f.tn) launch_variant<Variant<TASK, true, false, false, true, true, 0, false, true>>(kind, false, grid, s, a);
-           else launch_variant<Variant<TASK, true, false, false, false, true, 0, false, true>>(kind, false, grid, s, a); }
-  } else {
-    if (f.dr) { if (f.tn) launch_variant<Variant<TASK, false, true, false, true, true, 0, false, true>>(kind, false, grid, s, a);
-                else launch_variant<Variant<TASK, false, true, false, false, true, 0, false, true>>(kind, false, grid, s, a); }
-    else { if (f.tn) launch_variant<Variant<TASK, false, false, false, true, true, 0, false, true>>(kind, false, grid, s, a);
-           else launch_variant<Variant<TASK, false, false, false, false, true, 0, false, true>>(kind, false, grid, s, a); }
-  }
+  // ON = true, HOLD = true, control_mode PWM, no latency: MOTOR x DR x GE x TN
+#define PDS_HOLD(M, R, G, T) launch_variant<Variant<TASK, M, R, G, T, true, 0, false, true>>(kind, false, grid, s, a)
+#define PDS_HOLD_T(M, R, G) do { if (f.tn) PDS_HOLD(M, R, G, true); else PDS_HOLD(M, R, G, false); } while (0)
+#define PDS_HOLD_G(M, R) do { if (f.ge) PDS_HOLD_T(M, R, true); else PDS_HOLD_T(M, R, false); } while (0)
+  if (f.motor) { if (f.dr) PDS_HOLD_G(true, true); else PDS_HOLD_G(true, false); }
+  else { if (f.dr) PDS_HOLD_G(false, true); else PDS_HOLD_G(false, false); }
+#undef PDS_HOLD_G
+#undef PDS_HOLD_T
+#undef PDS_HOLD
 }
 
 }  // namespace pds

@@ -395,12 +395,27 @@ def _variant_grid(task):
         if agg != 1 and task == "takeoff":
             continue
         yield motor, dr, tn, 1, 0, "PWM", agg, dict(observation_frequency=50)
+    # round 3: the ground-effect extension together with the latency ring / the Kalman-hold branch (control_mode PWM)
+    for motor, dr, tn, on in itertools.product((0, 1), (0, 1), (0, 1), (0, 1)):
+        if motor and dr and not tn:  # thin the sweep a little
+            continue
+        if task == "takeoff" and motor:
+            # TakeOff starts ON the ground with the motors at rest: with the PT1 lag and two delayed steps it is still
+            # there when the thrust arrives, where the opt-in ground-effect formula divides by the 3.5e-6 m clip height
+            # (envs/agents.py:153) -- a 1e7 x kick.  GPU and f32 oracle agree to 2e-7 step by step until then (and
+            # again after every reset); WHICH step an env receives the kick in flips with the last bit, and the
+            # velocities afterwards differ by 1e4.  Identical in the f64 restatement of the reference: nothing to compare.
+            continue
+        yield motor, dr, tn, on, 1, "PWM", 1, dict(use_latency=True, latency=0.025)
+    for motor, dr, tn in itertools.product((0, 1), (0, 1), (0, 1)):
+        yield motor, dr, tn, 1, 1, "PWM", 1, dict(observation_frequency=50)
 
 
 @pytest.mark.parametrize("task", ["hover", "circle", "takeoff"])
 def test_every_kernel_variant_in_lockstep_with_the_f32_oracle(task):
     """Every kernel variant family -- 244 base / PID combinations (task x motor x DR x thrust noise x observation
-    noise x ground effect x control mode x sub-steps) plus the latency-ring and Kalman-hold variants, ~440 in
+    noise x ground effect x control mode x sub-steps) plus the latency-ring and Kalman-hold variants (round 3: also with
+    the ground-effect extension), ~500 in
     all -- for 24 steps with auto-resets (max_episode_steps=9), in lockstep with the f32
     oracle on identical seeds.  Bars: relative error (|d| / (1 + |x|)) of the synchronised envs < 2e-3
     (typically 1e-5), at most 3 of 777 envs desynchronised by a differing termination.  The PID modes without

@@ -102,7 +102,7 @@ _BAD_CONFIGS = [
     (0, dict(observation_frequency=50, use_latency=1), "EUNSUPPORTED", b"Kalman-hold"),
     (0, dict(observation_frequency=50, control_mode=1), "EUNSUPPORTED", b"Kalman-hold"),
     (0, dict(use_latency=1, latency=0.10), "EUNSUPPORTED", b"latency"),  # 10 rows > PDS_MAX_LATENCY_STEPS
-    (0, dict(use_latency=1, use_ground_effect=1), "EUNSUPPORTED", b"ground-effect"),
+    (0, dict(use_latency=1, use_ground_effect=1, control_mode=1), "EUNSUPPORTED", b"PID modes"),  # (latency + ground effect: PWM only)
 ]
 
 
