@@ -95,6 +95,9 @@ __host__ __device__ inline Offsets offsets(const pds_mlp &m) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       \
   } while (0)
 
+#ifndef PDS_MLP_EDGE
+#define PDS_MLP_EDGE 1  // A/B: 0 = the fourth output tile of the 50-wide layers on the matrix cores as well
+#endif
 #define PDS_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 __device__ __forceinline__ f32x4 lds4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
@@ -142,6 +145,47 @@ __device__ __forceinline__ void gemm_wt2(const float *Ws, int it, const f32x4 (&
   }
 }
 
+// ---- the two edge features of a 50-wide layer on the vector ALU (round 3) --------------------------------------
+// 50 hidden units fill three 16-row MFMA tiles and TWO rows of a fourth: that tile is 12-14 MFMAs (384-448 cycles of
+// the matrix pipe) for 2 useful rows of 16.  The gradient kernels of the reference's default policy net (h1 = h2 = 50:
+// KJH == 2) compute features 48 and 49 as plain dot products instead -- each lane over the 12-16 input features it
+// holds, the four lane groups of a sample added up with two cross-lane exchanges -- ~45 vector instructions that
+// run on the OTHER pipe while the co-resident wave issues MFMAs.  Result in the C/D layout of tile 3: lanes of group
+// 0 hold (feature 48, feature 49, 0, 0), the other groups zeros (features 52..63 are padding).
+// edge_rows: rows 48, 49 of W (forward: z = W in);  edge_cols: columns 48, 49 of W (backward: dz1 = W^T dz2).
+template <int NK>
+__device__ __forceinline__ f32x4 edge_rows(const float *Ws, const f32x4 (&in)[NK], int g) {
+  float e0 = 0.f, e1 = 0.f;
+  const float *w0 = Ws + 48 * kS + 4 * g;
+#pragma unroll
+  for (int kt = 0; kt < NK; ++kt) {
+    const f32x4 a0 = lds4(w0 + kt * kTW), a1 = lds4(w0 + kS + kt * kTW);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { e0 = fmaf(a0[q], in[kt][q], e0); e1 = fmaf(a1[q], in[kt][q], e1); }
+  }
+  e0 += __shfl_xor(e0, 16); e1 += __shfl_xor(e1, 16);
+  e0 += __shfl_xor(e0, 32); e1 += __shfl_xor(e1, 32);
+  f32x4 r = (f32x4)(0.f);
+  if (g == 0) { r[0] = e0; r[1] = e1; }
+  return r;
+}
+__device__ __forceinline__ f32x4 edge_cols(const float *Ws, const f32x4 (&in)[kNT], int g) {
+  float e0 = 0.f, e1 = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < kNT; ++kt) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float2 w = *reinterpret_cast<const float2 *>(Ws + (kt * kTW + 4 * g + q) * kS + 48);
+      e0 = fmaf(w.x, in[kt][q], e0); e1 = fmaf(w.y, in[kt][q], e1);
+    }
+  }
+  e0 += __shfl_xor(e0, 16); e1 += __shfl_xor(e1, 16);
+  e0 += __shfl_xor(e0, 32); e1 += __shfl_xor(e1, 32);
+  f32x4 r = (f32x4)(0.f);
+  if (g == 0) { r[0] = e0; r[1] = e1; }
+  return r;
+}
+
 // NINB: 16-wide tiles of the input dimension beyond the first two (1: d_in <= 48, 2: d_in <= 64) -- 16
 // accumulator registers that decide whether the gradient kernels fit 256 registers (two waves per SIMD)
 // GB: bias gradients as per-lane partial sums (36 registers).  Otherwise they come for free out of
@@ -152,6 +196,7 @@ __device__ __forceinline__ void gemm_wt2(const float *Ws, int it, const f32x4 (&
 template <int LOSS, int ACT, int NINB, bool GB, int KJI = 4, int KJH = 4>
 __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
   constexpr int NIN = 2 + NINB;
+  constexpr bool EDGE = PDS_MLP_EDGE && LOSS != LOSS_NONE && KJH == 2;  // h1 == h2 == 50: features 48, 49 on the vector ALU
   // ---- LDS images ---------------------------------------------------------------------------------
   __shared__ __attribute__((aligned(16))) float W1s[kMaxDim * kS];  // [out][in], zero padded
   __shared__ __attribute__((aligned(16))) float W2s[kMaxDim * kS];
@@ -248,8 +293,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
     // ---- forward: activations stay in registers from layer to layer -------------------------------
     f32x4 h1r[kNT], h2r[kNT];
     f32x4 cc[kNT];
+    if constexpr (EDGE) {
+      gemm_wt2<NIN, KJI>(W1s, 0, xin, n, g, cc[0], cc[1]);
+      cc[2] = gemm_wt<NIN, KJI>(W1s, 2, xin, n, g);
+      cc[3] = edge_rows<NIN>(W1s, xin, g);
+    } else {
 #pragma unroll
-    for (int it = 0; it < kNT; it += 2) gemm_wt2<NIN, KJI>(W1s, it, xin, n, g, cc[it], cc[it + 1]);
+      for (int it = 0; it < kNT; it += 2) gemm_wt2<NIN, KJI>(W1s, it, xin, n, g, cc[it], cc[it + 1]);
+    }
 #pragma unroll
     for (int it = 0; it < kNT; ++it) {  // H1^T = act(W1 X^T + b1); rows >= h1: act(0) = 0
       const f32x4 c = cc[it];
@@ -265,8 +316,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
         sts4(H1img + n * kS + it * kTW + 4 * g, v);
       }
     }
+    if constexpr (EDGE) {
+      gemm_wt2<kNT, KJH>(W2s, 0, h1r, n, g, cc[0], cc[1]);
+      cc[2] = gemm_wt<kNT, KJH>(W2s, 2, h1r, n, g);
+      cc[3] = edge_rows<kNT>(W2s, h1r, g);
+    } else {
 #pragma unroll
-    for (int it = 0; it < kNT; it += 2) gemm_wt2<kNT, KJH>(W2s, it, h1r, n, g, cc[it], cc[it + 1]);
+      for (int it = 0; it < kNT; it += 2) gemm_wt2<kNT, KJH>(W2s, it, h1r, n, g, cc[it], cc[it + 1]);
+    }
 #pragma unroll
     for (int it = 0; it < kNT; ++it) {  // H2^T = act(W2 H1^T + b2)
       const f32x4 c = cc[it];
@@ -388,8 +445,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int jt = 0; jt < kNT; ++jt)
+        for (int jt = 0; jt < (EDGE ? kNT - 1 : kNT); ++jt)
           if (kt < kNT - 1 || j < KJH) cc[jt] = PDS_MFMA(W2s[(kt * kTW + 4 * h + j) * kS + jt * kTW + r], dz2[kt][j], cc[jt]);
+    if constexpr (EDGE) cc[kNT - 1] = edge_cols(W2s, dz2, g);
 #pragma unroll
     for (int jt = 0; jt < kNT; ++jt) {
       const f32x4 c = cc[jt];
