@@ -95,6 +95,18 @@ __host__ __device__ inline Offsets offsets(const pds_mlp &m) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       \
   } while (0)
 
+#ifndef PDS_SPLIT_FPRIO
+#define PDS_SPLIT_FPRIO 3
+#endif
+#ifndef PDS_SPLIT_STAMPS
+#define PDS_SPLIT_STAMPS 0
+#endif
+#ifndef PDS_SPLIT_DEBUG
+#define PDS_SPLIT_DEBUG 0
+#endif
+#ifndef PDS_MLP_SPLIT
+#define PDS_MLP_SPLIT 1  // A/B: 0 = the default policy's PPO gradient on mlp_kernel (every wave runs every GEMM of its tiles)
+#endif
 #ifndef PDS_MLP_EDGE
 #define PDS_MLP_EDGE 1  // A/B: 0 = the fourth output tile of the 50-wide layers on the matrix cores as well
 #endif
@@ -574,6 +586,513 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
   }
 }
 
+// ---- round 3: the PPO gradient of the reference's default policy net (50-50 relu, d_in < 48), wave roles ---------
+// mlp_kernel keeps 128 weight-gradient accumulator registers live through the forward and backward GEMMs of every
+// tile; at two waves per SIMD (256 registers each) that leaves the compiler no room to fetch LDS operands ahead of
+// the MFMAs that use them -- its schedule is read -> wait -> 2 MFMAs, the waves sit in s_waitcnt for ~20 % of their
+// cycles and the matrix pipe idles a third of the time (profiles/r01_mlp_bench.txt: SQ_VALU_MFMA_BUSY 67 %).
+// Here the two waves of a SIMD take different ROLES on the same tile stream instead of different tiles:
+//   F (waves 0-3): forward, loss, dZ2 and the small dW3                -- no large accumulators, 112 MFMAs per tile
+//                    plus all the vector-ALU work of the activations and of the loss;
+//   G (waves 4-7): dZ1, dW2 += dZ2^T H1 and dW1 += dZ1^T X           -- 112 accumulator registers, 154 MFMAs per tile.
+// F hands a tile to its G through a set of three [16 samples][52] LDS images (X, H1, dZ2); two sets per pair, so F
+// works on tile k + 1 while G consumes tile k.  Hand-over: monotonic counters in LDS (full / empty per set), release
+// fence + store after the last image write, acquire load in a sleep loop -- the 8 waves of the block are resident
+// together (one block per CU), so the wait cannot deadlock.  Measured alone (profiling builds, PDS_SPLIT_DEBUG) F needs
+// ~2 x the cycles of its MFMAs (epilogues, loss, stores), G ~1.15 x: hence dZ1 on G's side.
+constexpr int kSI = 52;                       // image row stride: 50 features + ones column, 4 * kSI == 16 (mod 32)
+constexpr int kPairs = kWaves / 2;
+constexpr int kSetFloats = 3 * kTS * kSI;     // X, H1, dZ2
+constexpr int kPrivFloats = kTS * kSI + kTS * kSY;  // F's own H2 and dY images
+constexpr int kPrivGFloats = kTS * kSI;             // G's own dZ1 image
+constexpr int kW1Rows = 50;
+
+__device__ __forceinline__ void wait_ge(int *flag, int need) {
+  while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < need)
+    __builtin_amdgcn_s_sleep(1);
+}
+__device__ __forceinline__ void signal(int *flag, int value, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");  // every lane's image accesses are complete
+  if (lane == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+#if PDS_SPLIT_STAMPS  // profiling build: s_memtime at the phase boundaries of one tile of pair 0 of block 0
+__device__ unsigned long long g_split_stamps[32];
+#define PDS_SSTAMP(role, i)                                                                   \
+  do {                                                                                        \
+    if (k == 10 && blockIdx.x == 0 && pair == 0) {                                            \
+      const unsigned long long tt_ = __builtin_amdgcn_s_memtime();                            \
+      if (lane == 0) g_split_stamps[(role) * 16 + (i)] = tt_;                                 \
+    }                                                                                         \
+  } while (0)
+#else
+#define PDS_SSTAMP(role, i) do { } while (0)
+#endif
+
+template <int KJI>
+__global__ __launch_bounds__(kWaves * 64, 2) void ppo_split_kernel(const Args a) {
+  constexpr int NIN = 3, KJH = 2, ACT = 0;
+  __shared__ __attribute__((aligned(16))) float W1s[kW1Rows * kS];  // rows 48, 49: the vector-ALU features
+  __shared__ __attribute__((aligned(16))) float W2s[kMaxDim * kS];
+  __shared__ __attribute__((aligned(16))) float W3s[kTW * kS];
+  __shared__ __attribute__((aligned(16))) float b1s[kMaxDim], b2s[kMaxDim], b3s[kTW];
+  __shared__ __attribute__((aligned(16))) float isg[kTW], lsg[kTW];
+  __shared__ __attribute__((aligned(16))) float sets[kPairs * 2 * kSetFloats];
+  __shared__ __attribute__((aligned(16))) float priv[kPairs * kPrivFloats];
+  __shared__ __attribute__((aligned(16))) float privg[kPairs * kPrivGFloats];
+  __shared__ int flags[kPairs * 4];  // per pair: full[2], empty[2]
+  const pds_mlp &m = a.m;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pair = wave & 3;
+  const bool role_g = wave >= kPairs;
+  const int n = lane & 15, g = lane >> 4;
+  for (int i = tid; i < kMaxDim * kS; i += kWaves * 64) {
+    const int r = i / kS, k = i - r * kS;
+    if (r < kW1Rows) W1s[i] = (r < m.h1 && k < m.d_in) ? m.w1[r * m.d_in + k] : 0.f;
+    W2s[i] = (r < m.h2 && k < m.h1) ? m.w2[r * m.h1 + k] : 0.f;
+    if (i < kTW * kS) W3s[i] = (r < m.d_out && k < m.h2) ? m.w3[r * m.h2 + k] : 0.f;
+  }
+  if (tid < kMaxDim) {
+    b1s[tid] = tid < m.h1 ? m.b1[tid] : 0.f;
+    b2s[tid] = tid < m.h2 ? m.b2[tid] : 0.f;
+  }
+  if (tid < kTW) {
+    b3s[tid] = tid < m.d_out ? m.b3[tid] : 0.f;
+    const float ls = tid < m.d_out ? a.log_std[tid] : 0.f;
+    lsg[tid] = ls;
+    isg[tid] = expf(-ls);
+    flags[tid] = 0;
+  }
+  __syncthreads();
+
+  const long long ntiles = (a.B + kTS - 1) / kTS;
+  const long long pid = (long long)blockIdx.x * kPairs + pair, np = (long long)gridDim.x * kPairs;
+  int *full = flags + pair * 4, *empty = full + 2;
+  float *pset = sets + pair * 2 * kSetFloats;
+  const int r = n, h = g;  // A-operand lane roles of the weight-gradient GEMMs (k-slot (j, h) = sample 4 h + j)
+  const int n3 = min(n, 3);  // column tile 3 of a 52-wide image holds columns 48..51 only
+
+  f32x4 gW1[kNT][NIN], gW2[kNT][kNT], gW3[kNT];
+  float st_loss = 0.f, st_ratio = 0.f, st_kl = 0.f, st_cnt = 0.f;
+#pragma unroll
+  for (int i = 0; i < kNT; ++i) {
+    gW3[i] = (f32x4)(0.f);
+#pragma unroll
+    for (int j = 0; j < kNT; ++j) gW2[i][j] = (f32x4)(0.f);
+#pragma unroll
+    for (int j = 0; j < NIN; ++j) gW1[i][j] = (f32x4)(0.f);
+  }
+
+  if (role_g) {
+    // ================= G: dZ1 and the two large weight-gradient GEMMs =========================================
+    float *dZ1img = privg + pair * kPrivGFloats;
+    float wz1[kNT][4][kNT - 1];  // W2^T read column-wise: tile invariant, kept in registers
+#pragma unroll
+    for (int kt = 0; kt < kNT; ++kt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int jt = 0; jt < kNT - 1; ++jt)
+          wz1[kt][j][jt] = (kt < kNT - 1 || j < KJH) ? W2s[(kt * kTW + 4 * h + j) * kS + jt * kTW + r] : 0.f;
+    const int r3 = min(r, 3);
+    int k = 0;
+    for (long long t = pid; t < ntiles; t += np, ++k) {
+      const int s = k & 1;
+      const float *Ximg = pset + s * kSetFloats, *H1img = Ximg + kTS * kSI, *dZ2img = H1img + kTS * kSI;
+      PDS_SSTAMP(1, 0);
+      wait_ge(full + s, (k >> 1) + 1);
+      PDS_SSTAMP(1, 1);
+#if PDS_SPLIT_DEBUG != 1  // profiling: 1 = G only acknowledges (F's own rate), 2 = F only signals (G's own rate)
+      // this lane's dZ2 values (the B operands of dZ1) and columns 48, 49 of W2 (its vector-ALU part)
+      f32x4 dz2[kNT];
+#pragma unroll
+      for (int kt = 0; kt < kNT; ++kt)
+        dz2[kt] = (kt < kNT - 1 || g == 0) ? lds4(dZ2img + n * kSI + kt * kTW + 4 * g) : (f32x4)(0.f);
+      float2 we[kNT][4];
+#pragma unroll
+      for (int kt = 0; kt < kNT; ++kt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) we[kt][q] = *reinterpret_cast<const float2 *>(W2s + (kt * kTW + 4 * g + q) * kS + 48);
+      // ---- dZ1^T = (W2^T dZ2^T) * act'(H1^T): three chains ----
+      f32x4 cc[kNT];
+#pragma unroll
+      for (int kt = 0; kt < kNT; ++kt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int jt = 0; jt < kNT - 1; ++jt)
+            if (kt < kNT - 1 || j < KJH)
+              cc[jt] = PDS_MFMA(wz1[kt][j][jt], dz2[kt][j], (kt == 0 && j == 0) ? (f32x4)(0.f) : cc[jt]);
+      PDS_SSTAMP(1, 2);
+      // ---- dW2 += dZ2^T H1 (covers the result latency of dZ1) ----
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float av[kNT], bv[kNT];
+        const int row = (4 * h + j) * kSI;
+#pragma unroll
+        for (int i = 0; i < kNT; ++i) {
+          av[i] = dZ2img[row + i * kTW + (i == kNT - 1 ? r3 : r)];
+          bv[i] = H1img[row + i * kTW + (i == kNT - 1 ? n3 : n)];
+        }
+#pragma unroll
+        for (int it = 0; it < kNT; ++it)
+#pragma unroll
+          for (int jt = 0; jt < kNT; ++jt) gW2[it][jt] = PDS_MFMA(av[it], bv[jt], gW2[it][jt]);
+      }
+      PDS_SSTAMP(1, 3);
+      {
+        float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < kNT; ++kt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { v0 = fmaf(we[kt][q].x, dz2[kt][q], v0); v1 = fmaf(we[kt][q].y, dz2[kt][q], v1); }
+        v0 += __shfl_xor(v0, 16); v1 += __shfl_xor(v1, 16);
+        v0 += __shfl_xor(v0, 32); v1 += __shfl_xor(v1, 32);
+        cc[kNT - 1] = (f32x4)(0.f);
+        if (g == 0) { cc[kNT - 1][0] = v0; cc[kNT - 1][1] = v1; }
+      }
+#pragma unroll
+      for (int jt = 0; jt < kNT; ++jt) {
+        // this lane's own H1 values (column 50 of the image is the ones column: its dz1 is 0 * 1)
+        const f32x4 hv = (jt < kNT - 1 || g == 0) ? lds4(H1img + n * kSI + jt * kTW + 4 * g) : (f32x4)(0.f);
+        f32x4 dz1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dz1[q] = cc[jt][q] * act_grad<ACT>(hv[q]);
+        if (jt < kNT - 1 || g == 0) sts4(dZ1img + n * kSI + jt * kTW + 4 * g, dz1);
+      }
+      PDS_WAVE_SYNC();
+      PDS_SSTAMP(1, 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {  // dW1 += dZ1^T X
+        float av[kNT], bv[NIN];
+        const int row = (4 * h + j) * kSI;
+#pragma unroll
+        for (int i = 0; i < kNT; ++i) av[i] = dZ1img[row + i * kTW + (i == kNT - 1 ? r3 : r)];
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) bv[i] = Ximg[row + i * kTW + n];
+#pragma unroll
+        for (int it = 0; it < kNT; ++it)
+#pragma unroll
+          for (int kt = 0; kt < NIN; ++kt) gW1[it][kt] = PDS_MFMA(av[it], bv[kt], gW1[it][kt]);
+      }
+      PDS_SSTAMP(1, 5);
+#endif
+      signal(empty + s, (k >> 1) + 1, lane);
+      PDS_SSTAMP(1, 6);
+    }
+  } else {
+    // ================= F: forward, loss, backward through the activations, dW3 ================================
+    // Source order = issue order here (the compiler keeps it when registers allow): the LDS operands of a GEMM are
+    // read one phase AHEAD of its MFMAs; W3^T (dZ2's operand) stays in registers.
+    // F is the longer role and its MFMAs come in bursts between vector-ALU phases: with equal priority the arbiter
+    // gives G, which always has MFMAs ready, every other slot of a burst and F stretches; with F first, G fills the gaps
+    __builtin_amdgcn_s_setprio(PDS_SPLIT_FPRIO);
+    float *H2img = priv + pair * kPrivFloats, *dYimg = H2img + kTS * kSI;
+    float wz2[kNT];
+#pragma unroll
+    for (int it = 0; it < kNT; ++it) wz2[it] = W3s[h * kS + it * kTW + r];
+    auto load_x = [&](long long tt, f32x4 (&raw)[NIN]) {
+      const long long s = tt * kTS + n;
+      const float *xr = a.x + (s < a.B ? s : 0) * m.d_in;
+#pragma unroll
+      for (int kt = 0; kt < NIN; ++kt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) raw[kt][q] = xr[min(kt * kTW + 4 * g + q, m.d_in - 1)];
+    };
+    const float *w1p = W1s + n * kS + 4 * g, *w2p = W2s + n * kS + 4 * g, *w3p = W3s + n * kS + 4 * g;
+    const float *e1p = W1s + 48 * kS + 4 * g, *e2p = W2s + 48 * kS + 4 * g;
+    f32x4 xraw[NIN];
+    load_x(pid, xraw);
+    int k = 0;
+    for (long long t = pid; t < ntiles; t += np, ++k) {
+      const int s = k & 1;
+      float *Ximg = pset + s * kSetFloats, *H1img = Ximg + kTS * kSI, *dZ2img = H1img + kTS * kSI;
+#if PDS_SPLIT_DEBUG == 2
+      if (k >= 2) wait_ge(empty + s, k >> 1);
+      signal(full + s, (k >> 1) + 1, lane);
+      continue;
+#endif
+      PDS_SSTAMP(0, 0);
+      const long long s0 = t * kTS;
+      const bool valid = s0 + n < a.B;
+      // operands of layer 1 (and of its two vector-ALU rows)
+      f32x4 a1[kNT - 1][NIN];
+#pragma unroll
+      for (int kt = 0; kt < NIN; ++kt)
+#pragma unroll
+        for (int it = 0; it < kNT - 1; ++it) a1[it][kt] = lds4(w1p + it * kTW * kS + kt * kTW);
+      f32x4 xin[NIN];
+#pragma unroll
+      for (int kt = 0; kt < NIN; ++kt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xin[kt][q] = (valid && kt * kTW + 4 * g + q < m.d_in) ? xraw[kt][q] : 0.f;
+      float c_act[4] = {0.f, 0.f, 0.f, 0.f}, c_adv = 0.f, c_old = 0.f;
+      if (valid) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (4 * g + q < m.d_out) c_act[q] = a.act[(s0 + n) * m.d_out + 4 * g + q];
+        c_adv = a.adv[s0 + n]; c_old = a.logp_old[s0 + n];
+      }
+      if (k >= 2) wait_ge(empty + s, k >> 1);  // G is done with the tile that used this set
+      PDS_SSTAMP(0, 1);
+#pragma unroll
+      for (int kt = 0; kt < NIN; ++kt) {
+        f32x4 v = xin[kt];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (kt * kTW + 4 * g + q == m.d_in) v[q] = 1.f;  // the bias column of dW1
+        sts4(Ximg + n * kSI + kt * kTW + 4 * g, v);
+      }
+      // operands of layer 2: in flight during the MFMAs of layer 1
+      f32x4 a2[kNT - 1][kNT];
+#pragma unroll
+      for (int kt = 0; kt < kNT; ++kt)
+#pragma unroll
+        for (int it = 0; it < kNT - 1; ++it) a2[it][kt] = lds4(w2p + it * kTW * kS + kt * kTW);
+      // ---- layer 1: three accumulation chains alternate (tiles 0..2); features 48, 49 on the vector ALU ----
+      f32x4 h1r[kNT], h2r[kNT], cc[kNT];
+      cc[kNT - 1] = (f32x4)(0.f);
+#pragma unroll
+      for (int kt = 0; kt < NIN; ++kt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int it = 0; it < kNT - 1; ++it)
+            if (kt < NIN - 1 || j < KJI)
+              cc[it] = PDS_MFMA(a1[it][kt][j], xin[kt][j], (kt == 0 && j == 0) ? (f32x4)(0.f) : cc[it]);
+      PDS_SSTAMP(0, 2);
+      load_x(t + np, xraw);  // the next tile's rows: in flight during the rest of this tile
+      {
+        f32x4 e1[2][NIN];
+#pragma unroll
+        for (int kt = 0; kt < NIN; ++kt) {
+          e1[0][kt] = lds4(e1p + kt * kTW);
+          e1[1][kt] = lds4(e1p + kS + kt * kTW);
+        }
+        float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NIN; ++kt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { v0 = fmaf(e1[0][kt][q], xin[kt][q], v0); v1 = fmaf(e1[1][kt][q], xin[kt][q], v1); }
+        v0 += __shfl_xor(v0, 16); v1 += __shfl_xor(v1, 16);
+        v0 += __shfl_xor(v0, 32); v1 += __shfl_xor(v1, 32);
+        if (g == 0) { cc[kNT - 1][0] = v0; cc[kNT - 1][1] = v1; }
+      }
+      // operands of layer 3
+      f32x4 a3[kNT];
+#pragma unroll
+      for (int kt = 0; kt < kNT; ++kt) a3[kt] = lds4(w3p + kt * kTW);
+#pragma unroll
+      for (int it = 0; it < kNT; ++it) {
+        const f32x4 b = lds4(b1s + it * kTW + 4 * g);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) h1r[it][q] = act_fn<ACT>(cc[it][q] + b[q]);
+        f32x4 v = h1r[it];
+        if (it == kNT - 1) v[2] = 1.f;  // column 50: the bias column of dW2
+        if (it < kNT - 1 || g == 0) sts4(H1img + n * kSI + it * kTW + 4 * g, v);
+      }
+      PDS_SSTAMP(0, 3);
+      // ---- layer 2 ----
+      cc[kNT - 1] = (f32x4)(0.f);
+#pragma unroll
+      for (int kt = 0; kt < kNT; ++kt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int it = 0; it < kNT - 1; ++it)
+            if (kt < kNT - 1 || j < KJH)
+              cc[it] = PDS_MFMA(a2[it][kt][j], h1r[kt][j], (kt == 0 && j == 0) ? (f32x4)(0.f) : cc[it]);
+      PDS_SSTAMP(0, 4);
+      {
+        f32x4 e2[2][kNT];
+#pragma unroll
+        for (int kt = 0; kt < kNT; ++kt) {
+          e2[0][kt] = lds4(e2p + kt * kTW);
+          e2[1][kt] = lds4(e2p + kS + kt * kTW);
+        }
+        float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < kNT; ++kt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { v0 = fmaf(e2[0][kt][q], h1r[kt][q], v0); v1 = fmaf(e2[1][kt][q], h1r[kt][q], v1); }
+        v0 += __shfl_xor(v0, 16); v1 += __shfl_xor(v1, 16);
+        v0 += __shfl_xor(v0, 32); v1 += __shfl_xor(v1, 32);
+        if (g == 0) { cc[kNT - 1][0] = v0; cc[kNT - 1][1] = v1; }
+      }
+#pragma unroll
+      for (int it = 0; it < kNT; ++it) {
+        const f32x4 b = lds4(b2s + it * kTW + 4 * g);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) h2r[it][q] = act_fn<ACT>(cc[it][q] + b[q]);
+        f32x4 v = h2r[it];
+        if (it == kNT - 1) v[2] = 1.f;  // the bias column of dW3
+        if (it < kNT - 1 || g == 0) sts4(H2img + n * kSI + it * kTW + 4 * g, v);
+      }
+      PDS_SSTAMP(0, 5);
+      // ---- layer 3: two chains (even / odd k-tiles) ----
+      f32x4 y;
+      {
+        f32x4 c0, c1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          c0 = PDS_MFMA(a3[0][j], h2r[0][j], j == 0 ? (f32x4)(0.f) : c0);
+          c1 = PDS_MFMA(a3[1][j], h2r[1][j], j == 0 ? (f32x4)(0.f) : c1);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          c0 = PDS_MFMA(a3[2][j], h2r[2][j], c0);
+          if (j < KJH) c1 = PDS_MFMA(a3[3][j], h2r[3][j], c1);
+        }
+        const f32x4 b = lds4(b3s + 4 * g);
+        y = (c0 + c1) + b;
+      }
+      PDS_SSTAMP(0, 6);
+      // ---- loss: compute_loss_pi, algs/ppo/ppo.py:22-40 (see mlp_kernel) ----
+      f32x4 dy = (f32x4)(0.f);
+      {
+        float lp = 0.f, kl = 0.f;
+        f32x4 zs = (f32x4)(0.f);
+        const f32x4 is4 = lds4(isg + 4 * g), ls4 = lds4(lsg + 4 * g);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool on = 4 * g + q < m.d_out;  // selects, not branches
+          const float z = (c_act[q] - y[q]) * is4[q];
+          lp += on ? -0.5f * z * z - ls4[q] - 0.91893853320467274178f : 0.f;
+          kl += on ? 0.5f * z * z : 0.f;
+          zs[q] = on ? z * is4[q] : 0.f;
+        }
+        lp += __shfl_xor(lp, 16); lp += __shfl_xor(lp, 32);
+        kl += __shfl_xor(kl, 16); kl += __shfl_xor(kl, 32);
+        const float ratio = expf(lp - c_old);
+        const float lo = 1.f - a.clip, hi = 1.f + a.clip;
+        const float obj = fminf(ratio * c_adv, fminf(fmaxf(ratio, lo), hi) * c_adv);
+        const bool cut = (c_adv > 0.f && ratio > hi) || (c_adv < 0.f && ratio < lo);
+        const float gcoef = (cut || !valid) ? 0.f : -c_adv * ratio;
+        dy = gcoef * zs;
+        if (valid && g == 0) { st_loss += -obj; st_ratio += ratio; st_kl += kl; st_cnt += 1.f; }
+      }
+      sts4(dYimg + n * kSY + 4 * g, dy);
+      PDS_WAVE_SYNC();
+      PDS_SSTAMP(0, 7);
+      // operands of dZ2 (B: one dword of dY) and of dW3
+      const float dyb = dYimg[n * kSY + h];
+      float av3[4], bv3[4][kNT];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        av3[j] = dYimg[(4 * h + j) * kSY + r];
+#pragma unroll
+        for (int jt = 0; jt < kNT; ++jt) bv3[j][jt] = H2img[(4 * h + j) * kSI + jt * kTW + (jt == kNT - 1 ? n3 : n)];
+      }
+      // ---- dZ2^T = (W3^T dY^T) * act'(H2^T): the k-slot (step jj, lane group h) carries output 4 jj + h, so one
+      // step covers the 4 action dimensions of the drone (mlp_kernel's slot order needs 4 steps for them) ----
+#pragma unroll
+      for (int it = 0; it < kNT; ++it) cc[it] = PDS_MFMA(wz2[it], dyb, (f32x4)(0.f));
+      if (m.d_out > 4) {
+        const float dyb2 = dYimg[n * kSY + 4 + h];
+#pragma unroll
+        for (int it = 0; it < kNT; ++it) cc[it] = PDS_MFMA(W3s[(4 + h) * kS + it * kTW + r], dyb2, cc[it]);
+      }
+      // ---- dW3 += dY^T H2 (its 16 MFMAs cover the result latency of dZ2) ----
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int jt = 0; jt < kNT; ++jt) gW3[jt] = PDS_MFMA(av3[j], bv3[j][jt], gW3[jt]);
+      PDS_SSTAMP(0, 8);
+#pragma unroll
+      for (int it = 0; it < kNT; ++it) {
+        f32x4 dz2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dz2[q] = cc[it][q] * act_grad<ACT>(h2r[it][q]);
+        if (it < kNT - 1 || g == 0) sts4(dZ2img + n * kSI + it * kTW + 4 * g, dz2);
+      }
+      PDS_SSTAMP(0, 9);
+      signal(full + s, (k >> 1) + 1, lane);
+      PDS_SSTAMP(0, 10);
+    }
+  }
+
+  // ---- block sums: the 4 G waves add up (dW1, dW2), the 4 F waves (dW3, statistics); rounds 2,3 -> 0,1 and 1 -> 0
+  // of each role through LDS (the images are free now) -------------------------------------------------------------
+  {
+    constexpr int kRegsG = 4 * (kNT * NIN + kNT * kNT), kRegsF = 4 * kNT + kStats;
+    static_assert(2 * kRegsG * 64 <= kPairs * 2 * kSetFloats, "two G register images must fit in the tile sets");
+    static_assert(2 * kRegsF * 64 <= kPairs * kPrivFloats, "two F register images must fit in the private images");
+    auto xfer = [&](float *slot, bool add) {
+      int c = 0;
+      auto one = [&](float &v) {
+        if (add) v += slot[c * 64 + lane]; else slot[c * 64 + lane] = v;
+        ++c;
+      };
+      auto four = [&](f32x4 &v) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { float tmp = v[q]; one(tmp); v[q] = tmp; }
+      };
+      if (role_g) {
+#pragma unroll
+        for (int i = 0; i < kNT; ++i) {
+#pragma unroll
+          for (int j = 0; j < NIN; ++j) four(gW1[i][j]);
+#pragma unroll
+          for (int j = 0; j < kNT; ++j) four(gW2[i][j]);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < kNT; ++i) four(gW3[i]);
+        one(st_loss); one(st_ratio); one(st_kl); one(st_cnt);
+      }
+    };
+    float *red = role_g ? sets : priv;
+    const int stride = (role_g ? kRegsG : kRegsF) * 64;
+    __syncthreads();
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+      const int src0 = round == 0 ? 2 : 1, nsrc = round == 0 ? 2 : 1;
+      if (pair >= src0 && pair < src0 + nsrc) xfer(red + (pair - src0) * stride, false);
+      __syncthreads();
+      if (pair < nsrc) xfer(red + pair * stride, true);
+      __syncthreads();
+    }
+    if (pair != 0) return;
+  }
+  float *out = a.partials + (long long)blockIdx.x * a.pstride;
+  const Offsets o = offsets(m);
+  if (role_g) {
+#pragma unroll
+    for (int it = 0; it < kNT; ++it) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = it * kTW + 4 * g + q;
+#pragma unroll
+        for (int jt = 0; jt < kNT; ++jt) {
+          const int j = jt * kTW + n;
+          if (jt < NIN && i < m.h1 && j < m.d_in) out[o.w1 + i * m.d_in + j] = gW1[it][jt < NIN ? jt : 0][q];
+          if (jt < NIN && i < m.h1 && j == m.d_in) out[o.b1 + i] = gW1[it][jt < NIN ? jt : 0][q];
+          if (i < m.h2 && j < m.h1) out[o.w2 + i * m.h1 + j] = gW2[it][jt][q];
+          if (i < m.h2 && j == m.h1) out[o.b2 + i] = gW2[it][jt][q];
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = 4 * g + q;
+#pragma unroll
+      for (int jt = 0; jt < kNT; ++jt) {
+        const int j = jt * kTW + n;
+        if (i < m.d_out && j < m.h2) out[o.w3 + i * m.h2 + j] = gW3[jt][q];
+        if (i < m.d_out && j == m.h2) out[o.b3 + i] = gW3[jt][q];
+      }
+    }
+    float s4[kStats] = {st_loss, st_ratio, st_kl, st_cnt};
+#pragma unroll
+    for (int q = 0; q < kStats; ++q) {
+      float v = s4[q];
+      for (int d = 8; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+      if (lane == 0) out[o.total + q] = v;
+    }
+  }
+}
+
 // block = 64 outputs x 16 slices of the wave range: 16 x fewer dependent loads per thread
 __global__ __launch_bounds__(1024) void reduce_kernel(const float *partials, int pstride, int nwaves, int total,
                                                       float denom_scale, float *grads, float *stats) {
@@ -634,6 +1153,12 @@ constexpr int kMaxGridBlocks = 256;  // one partial per block
 }  // namespace pds_mlp_detail
 using namespace pds_mlp_detail;
 
+#if PDS_SPLIT_STAMPS
+extern "C" int pds_debug_split_stamps(unsigned long long *out32) {
+  return hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_split_stamps), 32 * sizeof(unsigned long long)) == hipSuccess ? PDS_OK : PDS_EHIP;
+}
+#endif
+
 extern "C" int pds_mlp_param_count(const pds_mlp *m) {
   if (check(m) != PDS_OK) return PDS_EINVAL;
   return offsets(*m).total;
@@ -668,7 +1193,7 @@ extern "C" int pds_mlp_forward(const pds_mlp *m, const float *d_x, const int64_t
 
 static int launch_grad(int loss, Args &a, float *d_grads, float *d_stats, float *d_workspace, void *stream) {
   const Offsets o = offsets(a.m);
-  const int blocks = grid_blocks(a.B);
+  int blocks = grid_blocks(a.B);
   a.partials = d_workspace;
   a.pstride = o.total + kStats;
   hipStream_t s = (hipStream_t)stream;
@@ -689,7 +1214,15 @@ static int launch_grad(int loss, Args &a, float *d_grads, float *d_stats, float 
   } while (0)
   // the reference's default policy (algs/ppo/defaults.py: 50-50 relu) on 34 (Hover, noisy) / 40 / 42 / 48
   // inputs: hidden k-tile 3 holds features 48, 49 only, input k-tile 2 of the 34-input net 32, 33 only
-  if (loss == LOSS_PPO && a.m.activation == 0 && !gb && !wide && two_hidden_steps(a.m)) {
+  if (PDS_MLP_SPLIT && loss == LOSS_PPO && a.m.activation == 0 && !gb && !wide && two_hidden_steps(a.m) &&
+      a.index == nullptr && a.mean == nullptr) {
+    // wave roles (ppo_split_kernel): a block takes 4 tiles at a time, not 8
+    const long long tiles = (a.B + kTS - 1) / kTS;
+    blocks = (int)((tiles + kPairs - 1) / kPairs < kMaxGridBlocks ? (tiles + kPairs - 1) / kPairs : kMaxGridBlocks);
+    const dim3 gs(blocks);
+    if (two_input_steps(a.m)) hipLaunchKernelGGL((ppo_split_kernel<2>), gs, b, 0, s, a);
+    else hipLaunchKernelGGL((ppo_split_kernel<4>), gs, b, 0, s, a);
+  } else if (loss == LOSS_PPO && a.m.activation == 0 && !gb && !wide && two_hidden_steps(a.m)) {
     if (two_input_steps(a.m)) hipLaunchKernelGGL((mlp_kernel<LOSS_PPO, 0, 1, false, 2, 2>), g, b, 0, s, a);
     else hipLaunchKernelGGL((mlp_kernel<LOSS_PPO, 0, 1, false, 4, 2>), g, b, 0, s, a);
   } else if (loss == LOSS_MSE && a.m.activation == 1 && gb && !wide && two_input_steps(a.m) && !two_hidden_steps(a.m)) {

@@ -22,7 +22,7 @@ fs = glob.glob("/tmp/pmc_mlp/**/*counter_collection.csv", recursive=True)
 acc = collections.defaultdict(list)
 for f in fs:
     for r in csv.DictReader(open(f)):
-        if "mlp_kernel" in r["Kernel_Name"]: acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if "mlp_kernel" in r["Kernel_Name"] or "ppo_split_kernel" in r["Kernel_Name"]: acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in sorted(acc.items()): print(f"{k:28s} {sum(v)/len(v):16.1f}   (n={len(v)})")
 PY
 done
