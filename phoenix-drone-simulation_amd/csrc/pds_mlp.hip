@@ -95,6 +95,9 @@ __host__ __device__ inline Offsets offsets(const pds_mlp &m) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       \
   } while (0)
 
+#ifndef PDS_SPLIT_GPRIO
+#define PDS_SPLIT_GPRIO 0
+#endif
 #ifndef PDS_SPLIT_FPRIO
 #define PDS_SPLIT_FPRIO 3
 #endif
@@ -629,6 +632,43 @@ __device__ unsigned long long g_split_stamps[32];
 #define PDS_SSTAMP(role, i) do { } while (0)
 #endif
 
+// relu in ONE instruction: fmaxf() costs two (LLVM quiets a possible signalling NaN with v_max x, x first); the
+// hardware's v_max_f32 returns the non-NaN operand, i.e. 0 for a NaN input either way
+__device__ __forceinline__ float relu1(float v) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
+  return r;
+}
+template <int ACT>
+__device__ __forceinline__ float act_fast(float v) { return ACT == 0 ? relu1(v) : act_fn<ACT>(v); }
+
+// gradient through the activation, given its OUTPUT h: relu as a select (one instruction less than c * (0 or 1))
+template <int ACT>
+__device__ __forceinline__ float act_back(float c, float h) { return ACT == 0 ? (h > 0.f ? c : 0.f) : c * (1.f - h * h); }
+
+// rows 48, 49 of a 50-wide layer on the vector ALU (see edge_rows), bias included: even / odd feature slots accumulate
+// in the two halves of v_pk_fma_f32 -- the operand pairs are adjacent registers, no moves.  wp: row 48 at this lane
+// group's column offset; result in the C/D layout of tile 3 (lane group 0: features 48, 49, then zeros).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int NK>
+__device__ __forceinline__ f32x4 edge_pair(const float *wp, const f32x4 (&in)[NK], const float *bias, int g) {
+  f32x2 s0 = (f32x2)(0.f), s1 = (f32x2)(0.f);
+#pragma unroll
+  for (int kt = 0; kt < NK; ++kt) {
+    const f32x4 w0 = lds4(wp + kt * kTW), w1 = lds4(wp + kS + kt * kTW);
+    s0 = __builtin_elementwise_fma(w0.xy, in[kt].xy, s0);
+    s1 = __builtin_elementwise_fma(w1.xy, in[kt].xy, s1);
+    s0 = __builtin_elementwise_fma(w0.zw, in[kt].zw, s0);
+    s1 = __builtin_elementwise_fma(w1.zw, in[kt].zw, s1);
+  }
+  float v0 = s0.x + s0.y, v1 = s1.x + s1.y;
+  v0 += __shfl_xor(v0, 16); v1 += __shfl_xor(v1, 16);
+  v0 += __shfl_xor(v0, 32); v1 += __shfl_xor(v1, 32);
+  f32x4 r = (f32x4)(0.f);
+  if (g == 0) { r[0] = v0 + bias[0]; r[1] = v1 + bias[1]; }
+  return r;
+}
+
 template <int KJI>
 __global__ __launch_bounds__(kWaves * 64, 2) void ppo_split_kernel(const Args a) {
   constexpr int NIN = 3, KJH = 2, ACT = 0;
@@ -686,6 +726,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void ppo_split_kernel(const Args a)
 
   if (role_g) {
     // ================= G: dZ1 and the two large weight-gradient GEMMs =========================================
+    __builtin_amdgcn_s_setprio(PDS_SPLIT_GPRIO);
     float *dZ1img = privg + pair * kPrivGFloats;
     float wz1[kNT][4][kNT - 1];  // W2^T read column-wise: tile invariant, kept in registers
 #pragma unroll
@@ -758,7 +799,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void ppo_split_kernel(const Args a)
         const f32x4 hv = (jt < kNT - 1 || g == 0) ? lds4(H1img + n * kSI + jt * kTW + 4 * g) : (f32x4)(0.f);
         f32x4 dz1;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dz1[q] = cc[jt][q] * act_grad<ACT>(hv[q]);
+        for (int q = 0; q < 4; ++q) dz1[q] = act_back<ACT>(cc[jt][q], hv[q]);
         if (jt < kNT - 1 || g == 0) sts4(dZ1img + n * kSI + jt * kTW + 4 * g, dz1);
       }
       PDS_WAVE_SYNC();
@@ -822,11 +863,12 @@ __global__ __launch_bounds__(kWaves * 64, 2) void ppo_split_kernel(const Args a)
       for (int kt = 0; kt < NIN; ++kt)
 #pragma unroll
         for (int it = 0; it < kNT - 1; ++it) a1[it][kt] = lds4(w1p + it * kTW * kS + kt * kTW);
+      // no masking of the input: a sample outside the batch carries gcoef = 0 (its forward pass runs on the clamped
+      // row and is discarded), and a feature slot >= d_in (a clamped re-read) meets a zero column of W1 on the way
+      // forward and a discarded column of dW1 on the way back
       f32x4 xin[NIN];
 #pragma unroll
-      for (int kt = 0; kt < NIN; ++kt)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) xin[kt][q] = (valid && kt * kTW + 4 * g + q < m.d_in) ? xraw[kt][q] : 0.f;
+      for (int kt = 0; kt < NIN; ++kt) xin[kt] = xraw[kt];
       float c_act[4] = {0.f, 0.f, 0.f, 0.f}, c_adv = 0.f, c_old = 0.f;
       if (valid) {
 #pragma unroll
@@ -837,93 +879,58 @@ __global__ __launch_bounds__(kWaves * 64, 2) void ppo_split_kernel(const Args a)
       if (k >= 2) wait_ge(empty + s, k >> 1);  // G is done with the tile that used this set
       PDS_SSTAMP(0, 1);
 #pragma unroll
-      for (int kt = 0; kt < NIN; ++kt) {
-        f32x4 v = xin[kt];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) if (kt * kTW + 4 * g + q == m.d_in) v[q] = 1.f;  // the bias column of dW1
-        sts4(Ximg + n * kSI + kt * kTW + 4 * g, v);
-      }
+      for (int kt = 0; kt < NIN; ++kt) sts4(Ximg + n * kSI + kt * kTW + 4 * g, xin[kt]);
+      if (g == 0) Ximg[n * kSI + m.d_in] = 1.f;  // the bias column of dW1 (after the row's b128 stores: LDS keeps a wave's order)
       // operands of layer 2: in flight during the MFMAs of layer 1
       f32x4 a2[kNT - 1][kNT];
 #pragma unroll
       for (int kt = 0; kt < kNT; ++kt)
 #pragma unroll
         for (int it = 0; it < kNT - 1; ++it) a2[it][kt] = lds4(w2p + it * kTW * kS + kt * kTW);
-      // ---- layer 1: three accumulation chains alternate (tiles 0..2); features 48, 49 on the vector ALU ----
+      // ---- layer 1: three accumulation chains alternate (tiles 0..2), each started from its bias; features 48, 49
+      // on the vector ALU (packed pairs: even / odd feature slots) ----
       f32x4 h1r[kNT], h2r[kNT], cc[kNT];
-      cc[kNT - 1] = (f32x4)(0.f);
+#pragma unroll
+      for (int it = 0; it < kNT - 1; ++it) cc[it] = lds4(b1s + it * kTW + 4 * g);
 #pragma unroll
       for (int kt = 0; kt < NIN; ++kt)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int it = 0; it < kNT - 1; ++it)
-            if (kt < NIN - 1 || j < KJI)
-              cc[it] = PDS_MFMA(a1[it][kt][j], xin[kt][j], (kt == 0 && j == 0) ? (f32x4)(0.f) : cc[it]);
+            if (kt < NIN - 1 || j < KJI) cc[it] = PDS_MFMA(a1[it][kt][j], xin[kt][j], cc[it]);
       PDS_SSTAMP(0, 2);
       load_x(t + np, xraw);  // the next tile's rows: in flight during the rest of this tile
-      {
-        f32x4 e1[2][NIN];
-#pragma unroll
-        for (int kt = 0; kt < NIN; ++kt) {
-          e1[0][kt] = lds4(e1p + kt * kTW);
-          e1[1][kt] = lds4(e1p + kS + kt * kTW);
-        }
-        float v0 = 0.f, v1 = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < NIN; ++kt)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { v0 = fmaf(e1[0][kt][q], xin[kt][q], v0); v1 = fmaf(e1[1][kt][q], xin[kt][q], v1); }
-        v0 += __shfl_xor(v0, 16); v1 += __shfl_xor(v1, 16);
-        v0 += __shfl_xor(v0, 32); v1 += __shfl_xor(v1, 32);
-        if (g == 0) { cc[kNT - 1][0] = v0; cc[kNT - 1][1] = v1; }
-      }
+      cc[kNT - 1] = edge_pair<NIN>(e1p, xin, b1s + 48, g);
       // operands of layer 3
       f32x4 a3[kNT];
 #pragma unroll
       for (int kt = 0; kt < kNT; ++kt) a3[kt] = lds4(w3p + kt * kTW);
 #pragma unroll
       for (int it = 0; it < kNT; ++it) {
-        const f32x4 b = lds4(b1s + it * kTW + 4 * g);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) h1r[it][q] = act_fn<ACT>(cc[it][q] + b[q]);
+        for (int q = 0; q < 4; ++q) h1r[it][q] = act_fast<ACT>(cc[it][q]);
         f32x4 v = h1r[it];
         if (it == kNT - 1) v[2] = 1.f;  // column 50: the bias column of dW2
         if (it < kNT - 1 || g == 0) sts4(H1img + n * kSI + it * kTW + 4 * g, v);
       }
       PDS_SSTAMP(0, 3);
       // ---- layer 2 ----
-      cc[kNT - 1] = (f32x4)(0.f);
+#pragma unroll
+      for (int it = 0; it < kNT - 1; ++it) cc[it] = lds4(b2s + it * kTW + 4 * g);
 #pragma unroll
       for (int kt = 0; kt < kNT; ++kt)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int it = 0; it < kNT - 1; ++it)
-            if (kt < kNT - 1 || j < KJH)
-              cc[it] = PDS_MFMA(a2[it][kt][j], h1r[kt][j], (kt == 0 && j == 0) ? (f32x4)(0.f) : cc[it]);
+            if (kt < kNT - 1 || j < KJH) cc[it] = PDS_MFMA(a2[it][kt][j], h1r[kt][j], cc[it]);
       PDS_SSTAMP(0, 4);
-      {
-        f32x4 e2[2][kNT];
-#pragma unroll
-        for (int kt = 0; kt < kNT; ++kt) {
-          e2[0][kt] = lds4(e2p + kt * kTW);
-          e2[1][kt] = lds4(e2p + kS + kt * kTW);
-        }
-        float v0 = 0.f, v1 = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < kNT; ++kt)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { v0 = fmaf(e2[0][kt][q], h1r[kt][q], v0); v1 = fmaf(e2[1][kt][q], h1r[kt][q], v1); }
-        v0 += __shfl_xor(v0, 16); v1 += __shfl_xor(v1, 16);
-        v0 += __shfl_xor(v0, 32); v1 += __shfl_xor(v1, 32);
-        if (g == 0) { cc[kNT - 1][0] = v0; cc[kNT - 1][1] = v1; }
-      }
+      cc[kNT - 1] = edge_pair<kNT>(e2p, h1r, b2s + 48, g);
 #pragma unroll
       for (int it = 0; it < kNT; ++it) {
-        const f32x4 b = lds4(b2s + it * kTW + 4 * g);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) h2r[it][q] = act_fn<ACT>(cc[it][q] + b[q]);
+        for (int q = 0; q < 4; ++q) h2r[it][q] = act_fast<ACT>(cc[it][q]);
         f32x4 v = h2r[it];
         if (it == kNT - 1) v[2] = 1.f;  // the bias column of dW3
         if (it < kNT - 1 || g == 0) sts4(H2img + n * kSI + it * kTW + 4 * g, v);
@@ -935,7 +942,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void ppo_split_kernel(const Args a)
         f32x4 c0, c1;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          c0 = PDS_MFMA(a3[0][j], h2r[0][j], j == 0 ? (f32x4)(0.f) : c0);
+          c0 = PDS_MFMA(a3[0][j], h2r[0][j], j == 0 ? lds4(b3s + 4 * g) : c0);
           c1 = PDS_MFMA(a3[1][j], h2r[1][j], j == 0 ? (f32x4)(0.f) : c1);
         }
 #pragma unroll
@@ -943,8 +950,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void ppo_split_kernel(const Args a)
           c0 = PDS_MFMA(a3[2][j], h2r[2][j], c0);
           if (j < KJH) c1 = PDS_MFMA(a3[3][j], h2r[3][j], c1);
         }
-        const f32x4 b = lds4(b3s + 4 * g);
-        y = (c0 + c1) + b;
+        y = c0 + c1;
       }
       PDS_SSTAMP(0, 6);
       // ---- loss: compute_loss_pi, algs/ppo/ppo.py:22-40 (see mlp_kernel) ----
@@ -1002,7 +1008,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void ppo_split_kernel(const Args a)
       for (int it = 0; it < kNT; ++it) {
         f32x4 dz2;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dz2[q] = cc[it][q] * act_grad<ACT>(h2r[it][q]);
+        for (int q = 0; q < 4; ++q) dz2[q] = act_back<ACT>(cc[it][q], h2r[it][q]);
         if (it < kNT - 1 || g == 0) sts4(dZ2img + n * kSI + it * kTW + 4 * g, dz2);
       }
       PDS_SSTAMP(0, 9);
