@@ -24,6 +24,10 @@
 //   backward     dH2 = dY W3, dH1 = dZ2 W2                          (M = samples)
 //   weight grads dW3 = dY^T H2, dW2 = dZ2^T H1, dW1 = dZ1^T X       (K = the tile's 16 samples)
 // Bound: MFMA f32 (157 TFLOP/s dense peak on MI355X = the f32 vector rate; MI355X_MICROARCH.md).
+//
+// Round 3: the PPO gradient of the reference's default policy (50-50 relu) runs on ppo_split_kernel below instead --
+// the two waves of a SIMD take different ROLES on the same tiles (forward / loss / small GEMMs vs. the large
+// weight-gradient GEMMs) so that neither carries 128 accumulator registers through phases that do not need them.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
