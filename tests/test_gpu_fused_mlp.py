@@ -67,6 +67,87 @@ def test_ppo_policy_grad_matches_autograd(d_in, h, act, B):
     assert float(stats[3]) == B
 
 
+def _ppo_case_inputs(d_in, h, A, act, B, seed):
+    net = _net(d_in, h, h, A, act, seed)
+    torch.manual_seed(5 + B % 7)
+    x = torch.randn(B, d_in, device="cuda")
+    log_std = torch.full((A,), math.log(0.3), device="cuda") + 0.1 * torch.randn(A, device="cuda")
+    with torch.no_grad():
+        mu0 = net(x)
+        act_t = mu0 + torch.exp(log_std) * torch.randn(B, A, device="cuda")
+        logp_old = torch.distributions.Normal(mu0, torch.exp(log_std)).log_prob(act_t).sum(-1)
+        logp_old = logp_old + 0.3 * torch.randn(B, device="cuda")
+    return net, x, act_t, torch.randn(B, device="cuda"), logp_old, log_std
+
+
+def _ppo_grad_case(d_in, h, A, act, B, seed=2):
+    """fused PPO-clip gradient and statistics of a d_in-h-h-A net against compute_loss_pi (algs/ppo/ppo.py:22-40) through
+    autograd in FLOAT64: the loss has kinks (clip range, relu), and a sample that sits on one within f32 rounding takes
+    the other branch in an f32 reference as easily as in the kernel -- measured: torch's own f32 gradient is 6e-6 off
+    the f64 one at B = 70 001 where the kernel is 9e-9 off.  Such a sample moves an element by (its gradient) / B,
+    which the tolerance of the large batches allows for; dropped or repeated tiles are the additivity test's job."""
+    import copy
+    from phoenix_drone_simulation_amd.fused import FusedMLP
+    clip = 0.2
+    net, x, act_t, adv, logp_old, log_std = _ppo_case_inputs(d_in, h, A, act, B, seed)
+    fm = FusedMLP(net, act)
+    stats = fm.ppo_grad(x, act_t, adv, logp_old, log_std, clip).clone()
+    got = fm.flat_grad.clone().double()
+    net64 = copy.deepcopy(net).double()
+    d = torch.distributions.Normal(net64(x.double()), torch.exp(log_std.double()))
+    ratio = torch.exp(d.log_prob(act_t.double()).sum(-1) - logp_old.double())
+    loss = -(torch.min(ratio * adv.double(), adv.double() * torch.clamp(ratio, 1 - clip, 1 + clip))).mean()
+    loss.backward()
+    want = torch.cat([p.grad.reshape(-1) for p in net64.parameters()])
+    scale = float(want.abs().max())
+    atol = 2e-6 * max(scale, 1.0) + (10.0 / B if B > 20000 else 0.0)
+    assert torch.allclose(got, want, rtol=2e-4, atol=atol), float((got - want).abs().max())
+    assert abs(float(stats[0]) / B - float(loss)) < 2e-5 * max(1.0, abs(float(loss)))
+    assert abs(float(stats[1]) / B - float(ratio.mean())) < 2e-5 * float(ratio.mean())
+    assert float(stats[3]) == B
+
+
+@pytest.mark.parametrize("d_in,B,cut", [(34, 300007, 123457), (42, 70001, 16 * 1000), (42, 1000003, 500001)])
+def test_wave_role_policy_gradient_is_additive_over_batch_splits(d_in, B, cut):
+    """every tile is handed from a forward wave to its weight-gradient wave exactly once: the gradient of a batch equals
+    the sample-weighted sum of the gradients of its two parts up to the rounding of the partial sums (a sample's own
+    arithmetic does not depend on the batch around it, so the loss's kinks cancel) -- a dropped, repeated or half-written
+    tile of 16 samples shows up 16 / B ~ 1e-5..2e-4 relative; the per-sample count is exact"""
+    from phoenix_drone_simulation_amd.fused import FusedMLP
+    net, x, act_t, adv, logp_old, log_std = _ppo_case_inputs(d_in, 50, 4, "relu", B, 11)
+    fm = FusedMLP(net, "relu")
+
+    def grad(lo, hi):
+        st = fm.ppo_grad(x[lo:hi].contiguous(), act_t[lo:hi].contiguous(), adv[lo:hi].contiguous(),
+                         logp_old[lo:hi].contiguous(), log_std, 0.2).clone().double()
+        assert float(st[3]) == hi - lo
+        return fm.flat_grad.clone().double() * (hi - lo), st
+    full, st_full = grad(0, B)
+    a, st_a = grad(0, cut)
+    b, st_b = grad(cut, B)
+    err = float((full - (a + b)).abs().max()) / float(full.abs().max())
+    assert err < 2e-6, err
+    assert torch.allclose(st_full[:3], st_a[:3] + st_b[:3], rtol=1e-5)
+
+
+@pytest.mark.parametrize("B", [1, 15, 16, 17, 64 * 3 + 1, 16 * 1024 * 3, 70001, 300007])
+def test_wave_role_policy_gradient_over_batch_shapes(B):
+    """ppo_split_kernel (round 3; default policy 50-50 relu): a batch smaller than one tile, ragged tails, fewer tiles than
+    wave pairs, exactly 3 tiles per pair of every block, and batches where every pair reuses its two LDS image sets
+    several times (the full / empty hand-over of the two roles)"""
+    _ppo_grad_case(34, 50, 4, "relu", B)
+    _ppo_grad_case(42, 50, 4, "relu", B, seed=3)
+
+
+@pytest.mark.parametrize("d_in,A", [(33, 4), (47, 4), (20, 4), (3, 2), (42, 1), (42, 6), (34, 8), (40, 5)])
+def test_wave_role_policy_gradient_over_net_shapes(d_in, A):
+    """input widths on either side of the 34-input specialisation, the widest one the kernel takes (47: the ones column
+    of dW1 is the last column of the third input tile), tiny inputs; action dimensions 1..8 (> 4: the second k-step of
+    the output-layer backward GEMM, log-prob sums across lane groups)"""
+    _ppo_grad_case(d_in, 50, A, "relu", 5000 + d_in)
+    _ppo_grad_case(d_in, 50, A, "relu", 40000 + A, seed=7)
+
+
 @pytest.mark.parametrize("d_in,B,use_index", [(34, 3000, False), (42, 4096, True), (40, 17, True)])
 def test_value_grad_matches_autograd(d_in, B, use_index):
     from phoenix_drone_simulation_amd.fused import FusedMLP
