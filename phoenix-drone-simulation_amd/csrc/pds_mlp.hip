@@ -205,6 +205,30 @@ __device__ __forceinline__ f32x4 edge_cols(const float *Ws, const f32x4 (&in)[kN
   return r;
 }
 
+// The weight images of a block: [out][in] rows of kS floats, zero padded (W1, W2: 64 rows -- W1 may be cut to W1ROWS --,
+// W3: 16 rows).  All loads of a thread are issued before its first LDS store (nine L2 round trips in flight instead of
+// one after the other: the prologue is most of a small batch's time).
+template <int W1ROWS>
+__device__ __forceinline__ void stage_weights(const pds_mlp &m, float *W1s, float *W2s, float *W3s, int tid) {
+  constexpr int kThreads = kWaves * 64, kIters = (kMaxDim * kS + kThreads - 1) / kThreads;
+  float v1[kIters], v2[kIters], v3[kIters];
+#pragma unroll
+  for (int it = 0; it < kIters; ++it) {
+    const int i = tid + it * kThreads, r = i / kS, k = i - r * kS;
+    const bool in = i < kMaxDim * kS;
+    v1[it] = (in && r < W1ROWS && r < m.h1 && k < m.d_in) ? m.w1[r * m.d_in + k] : 0.f;
+    v2[it] = (in && r < m.h2 && k < m.h1) ? m.w2[r * m.h1 + k] : 0.f;
+    v3[it] = (i < kTW * kS && r < m.d_out && k < m.h2) ? m.w3[r * m.h2 + k] : 0.f;
+  }
+#pragma unroll
+  for (int it = 0; it < kIters; ++it) {
+    const int i = tid + it * kThreads;
+    if (i < W1ROWS * kS) W1s[i] = v1[it];
+    if (i < kMaxDim * kS) W2s[i] = v2[it];
+    if (i < kTW * kS) W3s[i] = v3[it];
+  }
+}
+
 // NINB: 16-wide tiles of the input dimension beyond the first two (1: d_in <= 48, 2: d_in <= 64) -- 16
 // accumulator registers that decide whether the gradient kernels fit 256 registers (two waves per SIMD)
 // GB: bias gradients as per-lane partial sums (36 registers).  Otherwise they come for free out of
@@ -226,12 +250,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
   const pds_mlp &m = a.m;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, g = lane >> 4;  // C/D layout: column (sample) n, rows 4 g + q
-  for (int i = tid; i < kMaxDim * kS; i += kWaves * 64) {
-    const int r = i / kS, k = i - r * kS;
-    W1s[i] = (r < m.h1 && k < m.d_in) ? m.w1[r * m.d_in + k] : 0.f;
-    W2s[i] = (r < m.h2 && k < m.h1) ? m.w2[r * m.h1 + k] : 0.f;
-    if (i < kTW * kS) W3s[i] = (r < m.d_out && k < m.h2) ? m.w3[r * m.h2 + k] : 0.f;
-  }
+  stage_weights<kMaxDim>(m, W1s, W2s, W3s, tid);
   if (tid < kMaxDim) {
     b1s[tid] = tid < m.h1 ? m.b1[tid] : 0.f;
     b2s[tid] = tid < m.h2 ? m.b2[tid] : 0.f;
@@ -691,12 +710,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void ppo_split_kernel(const Args a)
   const int pair = wave & 3;
   const bool role_g = wave >= kPairs;
   const int n = lane & 15, g = lane >> 4;
-  for (int i = tid; i < kMaxDim * kS; i += kWaves * 64) {
-    const int r = i / kS, k = i - r * kS;
-    if (r < kW1Rows) W1s[i] = (r < m.h1 && k < m.d_in) ? m.w1[r * m.d_in + k] : 0.f;
-    W2s[i] = (r < m.h2 && k < m.h1) ? m.w2[r * m.h1 + k] : 0.f;
-    if (i < kTW * kS) W3s[i] = (r < m.d_out && k < m.h2) ? m.w3[r * m.h2 + k] : 0.f;
-  }
+  stage_weights<kW1Rows>(m, W1s, W2s, W3s, tid);
   if (tid < kMaxDim) {
     b1s[tid] = tid < m.h1 ? m.b1[tid] : 0.f;
     b2s[tid] = tid < m.h2 ? m.b2[tid] : 0.f;
