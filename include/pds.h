@@ -357,6 +357,12 @@ int pds_gaussian_sample_dev(const float *d_mu, const float *d_log_std, int64_t n
                             float *d_act, float *d_logp, void *stream);
 int pds_counter_add(uint64_t *d_counter, uint64_t inc, void *stream);
 
+/* d_out[i] = p(i), i < n: a pseudo-random permutation of 0 .. n-1 keyed by (seed, call) -- a 6-round Feistel network
+ * (round keys from Philox4x32-10) over the next even-width power of two, cycle-walked into [0, n).  One elementwise
+ * launch; stands in for the index shuffle of the value net's mini-batches (np.random.shuffle in
+ * IWPGAlgorithm.update_value_net, algs/iwpg/iwpg.py:487-522), whose stream the GPU trainer does not share anyway. */
+int pds_permutation(int64_t *d_out, int64_t n, uint64_t seed, uint64_t call, void *stream);
+
 /* One rollout step's bookkeeping (buf.store + episode statistics of IWPGAlgorithm.roll_out,
  * algs/iwpg/iwpg.py:350-385): copies reward / terminated / truncated [n] into their [T, N] slices, adds
  * the reward to the running episode return and 1 to the length, and for finished envs adds

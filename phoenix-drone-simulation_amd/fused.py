@@ -131,6 +131,17 @@ class FusedMLP:
         return self.stats
 
 
+def random_permutation(n, seed, call, device):
+    """int64 tensor p with p[i] = a pseudo-random permutation of range(n) keyed by (seed, call): one launch
+    (include/pds.h pds_permutation) where torch.randperm sorts."""
+    out = torch.empty(int(n), dtype=torch.int64, device=device)
+    with _on(out):
+        rc = native.load().pds_permutation(_ptr(out), int(n), int(seed) & (2 ** 64 - 1), int(call), FusedMLP._stream(out))
+    if rc != native.OK:
+        raise RuntimeError(f"pds_permutation -> {rc}")
+    return out
+
+
 def counter_add(counter, inc):
     """counter (int64 device tensor of one element) += inc, stream-ordered (captured-rollout call counter)."""
     with _on(counter):

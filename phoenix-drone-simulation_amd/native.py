@@ -36,7 +36,7 @@ EXPORTS = ["pds_version", "pds_default_config", "pds_create", "pds_destroy", "pd
            "pds_bytes_per_env_step", "pds_bytes_per_env_step_k", "pds_last_error", "pds_step_k", "pds_set_latency",
            "pds_latency_steps", "pds_philox4x32", "pds_gae", "pds_history_advance",
            "pds_mlp_param_count", "pds_mlp_workspace_floats", "pds_mlp_forward", "pds_ppo_policy_grad",
-           "pds_value_grad", "pds_gaussian_sample", "pds_gaussian_sample_dev", "pds_counter_add", "pds_rollout_record",
+           "pds_value_grad", "pds_gaussian_sample", "pds_gaussian_sample_dev", "pds_counter_add", "pds_permutation", "pds_rollout_record",
            "pds_adam_step", "pds_rollout"]
 
 
@@ -126,6 +126,7 @@ def load():
     lib.pds_gaussian_sample.argtypes = [vp, vp, i64, i32, u64, u64, u64, i32, vp, vp, vp]
     lib.pds_gaussian_sample_dev.argtypes = [vp, vp, i64, i32, u64, vp, u64, u64, i32, vp, vp, vp]
     lib.pds_counter_add.argtypes = [vp, u64, vp]
+    lib.pds_permutation.argtypes = [vp, i64, u64, u64, vp]
     lib.pds_rollout_record.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp]
     lib.pds_adam_step.argtypes = [mp, vp, vp, vp, i64, C.c_float, C.c_float, C.c_float, C.c_float, vp]
     lib.pds_rollout.argtypes = [vp, i32, mp, mp, vp, vp, C.c_float, vp, u64, vp, u64, i32] + [vp] * 14

@@ -244,3 +244,33 @@ def test_gaussian_sample_and_rollout_record():
         assert torch.equal(rew_buf[t], r) and torch.equal(term_buf[t], te) and torch.equal(trunc_buf[t], tr)
     assert torch.allclose(ep_ret, er) and torch.equal(ep_len, el)
     assert torch.allclose(stats.double(), st, rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 1000, 4096, 65536, 524288 + 3])
+def test_permutation_is_a_permutation_and_keyed(n):
+    """pds_permutation (csrc/pds_train.hip): the value net's mini-batch shuffle in one launch -- every index exactly once
+    for domain sizes on both sides of a power of two, reproducible per (seed, call), different between calls"""
+    from phoenix_drone_simulation_amd.fused import random_permutation
+    p = random_permutation(n, 7, 1, "cuda")
+    assert p.dtype == torch.int64 and p.shape == (n,)
+    assert torch.equal(torch.sort(p).values, torch.arange(n, device="cuda"))
+    assert torch.equal(p, random_permutation(n, 7, 1, "cuda"))
+    if n >= 17:
+        assert not torch.equal(p, random_permutation(n, 7, 2, "cuda"))
+        assert not torch.equal(p, random_permutation(n, 8, 1, "cuda"))
+
+
+def test_permutation_statistics():
+    """over 400 keys: where element 0 goes is uniform over the 50 positions (chi-square), neighbours do not stay
+    neighbours, and the mean displacement is that of a uniform shuffle, n / 3"""
+    from phoenix_drone_simulation_amd.fused import random_permutation
+    n, calls = 50, 400
+    ps = torch.stack([random_permutation(n, 3, c, "cuda") for c in range(calls)]).cpu()
+    counts = torch.bincount(ps[:, 0], minlength=n).double()
+    chi2 = float(((counts - calls / n) ** 2 / (calls / n)).sum())
+    assert chi2 < 100.0, chi2            # 49 degrees of freedom: mean 49, P(> 100) ~ 2e-5
+    adjacent = float(((ps[:, 1:] - ps[:, :-1]).abs() == 1).double().mean())
+    assert adjacent < 0.08, adjacent     # uniform shuffle: 2 / n = 0.04
+    big = random_permutation(1 << 18, 5, 9, "cuda").double()
+    disp = float((big - torch.arange(1 << 18, device="cuda").double()).abs().mean()) / (1 << 18)
+    assert abs(disp - 1.0 / 3.0) < 0.01, disp
