@@ -376,6 +376,22 @@ int pds_rollout_record(const float *d_rew, const uint8_t *d_term, const uint8_t 
 int pds_adam_step(const pds_mlp *m, const float *d_grads, float *d_exp_avg, float *d_exp_avg_sq, int64_t step, float lr,
                   float beta1, float beta2, float eps, void *stream);
 
+/* Gradient + optimiser step in the SAME two launches as the gradient alone: the partial-sum kernel of
+ * pds_ppo_policy_grad / pds_value_grad applies torch.optim.Adam.step to each parameter right after it has summed its
+ * gradient (same arithmetic as pds_adam_step: the two routes give the same bits; d_grads and d_stats are written as
+ * before).  opt == NULL: no step (= the plain entry points).  For single-process training without gradient clipping --
+ * with several ranks the gradient all-reduce sits between the two. */
+typedef struct pds_adam {
+  float *d_exp_avg, *d_exp_avg_sq; /* optimiser state [param_count] */
+  int64_t step;                    /* counts from 1 */
+  float lr, beta1, beta2, eps;
+} pds_adam;
+int pds_ppo_policy_grad_step(const pds_mlp *m, const float *d_x, const float *d_act, const float *d_adv,
+                             const float *d_logp_old, const float *d_log_std, int64_t B, float clip_ratio, float *d_grads,
+                             float *d_stats, float *d_workspace, const pds_adam *opt, void *stream);
+int pds_value_grad_step(const pds_mlp *m, const float *d_x, const int64_t *d_index, const float *d_target, int64_t B,
+                        float *d_grads, float *d_stats, float *d_workspace, const pds_adam *opt, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1117,9 +1117,16 @@ __global__ __launch_bounds__(kWaves * 64, 2) void ppo_split_kernel(const Args a)
   }
 }
 
+// The optimiser step that may ride on the partial-sum kernel (pds_*_grad_step): torch.optim.Adam, the arithmetic of
+// pds_adam_step (csrc/pds_train.hip adam_kernel) expression for expression, so both routes give the same bits.
+struct AdamK {
+  float *em, *ev;  // exp_avg, exp_avg_sq [total]; em == nullptr: no step
+  float lr, b1, b2, eps, bc1, bc2s;
+};
+
 // block = 64 outputs x 16 slices of the wave range: 16 x fewer dependent loads per thread
 __global__ __launch_bounds__(1024) void reduce_kernel(const float *partials, int pstride, int nwaves, int total,
-                                                      float denom_scale, float *grads, float *stats) {
+                                                      float denom_scale, float *grads, float *stats, pds_mlp m, AdamK ad) {
   __shared__ float part[16][64];
   const int px = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int p = blockIdx.x * 64 + px;
@@ -1143,8 +1150,27 @@ __global__ __launch_bounds__(1024) void reduce_kernel(const float *partials, int
     float t = 0.f;
 #pragma unroll
     for (int q = 0; q < 16; ++q) t += part[q][px];
-    if (p < total) grads[p] = t * denom_scale;
-    else stats[p - total] = t;
+    if (p < total) {
+      const float gr = t * denom_scale;
+      grads[p] = gr;
+      if (ad.em != nullptr) {
+        const Offsets o = offsets(m);
+        float *dst;
+        if (p < o.b1) dst = const_cast<float *>(m.w1) + p;
+        else if (p < o.w2) dst = const_cast<float *>(m.b1) + (p - o.b1);
+        else if (p < o.b2) dst = const_cast<float *>(m.w2) + (p - o.w2);
+        else if (p < o.w3) dst = const_cast<float *>(m.b2) + (p - o.b2);
+        else if (p < o.b3) dst = const_cast<float *>(m.w3) + (p - o.w3);
+        else dst = const_cast<float *>(m.b3) + (p - o.b3);
+        const float mm = ad.b1 * ad.em[p] + (1.f - ad.b1) * gr;
+        const float vv = ad.b2 * ad.ev[p] + (1.f - ad.b2) * gr * gr;
+        ad.em[p] = mm; ad.ev[p] = vv;
+        const float denom = sqrtf(vv) / ad.bc2s + ad.eps;
+        *dst = *dst - (ad.lr / ad.bc1) * (mm / denom);
+      }
+    } else {
+      stats[p - total] = t;
+    }
   }
 }
 
@@ -1215,7 +1241,8 @@ extern "C" int pds_mlp_forward(const pds_mlp *m, const float *d_x, const int64_t
   return hipGetLastError() == hipSuccess ? PDS_OK : PDS_EHIP;
 }
 
-static int launch_grad(int loss, Args &a, float *d_grads, float *d_stats, float *d_workspace, void *stream) {
+static int launch_grad(int loss, Args &a, float *d_grads, float *d_stats, float *d_workspace, const pds_adam *opt,
+                       void *stream) {
   const Offsets o = offsets(a.m);
   int blocks = grid_blocks(a.B);
   a.partials = d_workspace;
@@ -1258,28 +1285,54 @@ static int launch_grad(int loss, Args &a, float *d_grads, float *d_stats, float 
   }
 #undef PDS_MLP_LAUNCH
   const int n = o.total + kStats;
+  AdamK ad{};
+  if (opt != nullptr) {
+    ad.em = opt->d_exp_avg; ad.ev = opt->d_exp_avg_sq;
+    ad.lr = opt->lr; ad.b1 = opt->beta1; ad.b2 = opt->beta2; ad.eps = opt->eps;
+    ad.bc1 = 1.0f - powf(opt->beta1, (float)opt->step);  // as pds_adam_step
+    ad.bc2s = sqrtf(1.0f - powf(opt->beta2, (float)opt->step));
+  }
   hipLaunchKernelGGL(reduce_kernel, dim3((n + 63) / 64), dim3(1024), 0, s, (const float *)d_workspace, a.pstride,
-                     blocks, o.total, 1.0f / (float)a.B, d_grads, d_stats);
+                     blocks, o.total, 1.0f / (float)a.B, d_grads, d_stats, a.m, ad);
   return hipGetLastError() == hipSuccess ? PDS_OK : PDS_EHIP;
+}
+
+static bool adam_ok(const pds_adam *opt) {
+  return opt == nullptr || (opt->d_exp_avg && opt->d_exp_avg_sq && opt->step >= 1);
+}
+
+extern "C" int pds_ppo_policy_grad_step(const pds_mlp *m, const float *d_x, const float *d_act, const float *d_adv,
+                                        const float *d_logp_old, const float *d_log_std, int64_t B, float clip_ratio,
+                                        float *d_grads, float *d_stats, float *d_workspace, const pds_adam *opt,
+                                        void *stream) {
+  if (check(m) != PDS_OK || !d_x || !d_act || !d_adv || !d_logp_old || !d_log_std || !d_grads || !d_stats ||
+      !d_workspace || B < 1 || !adam_ok(opt))
+    return PDS_EINVAL;
+  Args a{};
+  a.m = *m; a.x = d_x; a.B = B; a.act = d_act; a.adv = d_adv; a.logp_old = d_logp_old; a.log_std = d_log_std;
+  a.clip = clip_ratio;
+  return launch_grad(LOSS_PPO, a, d_grads, d_stats, d_workspace, opt, stream);
 }
 
 extern "C" int pds_ppo_policy_grad(const pds_mlp *m, const float *d_x, const float *d_act, const float *d_adv,
                                    const float *d_logp_old, const float *d_log_std, int64_t B, float clip_ratio,
                                    float *d_grads, float *d_stats, float *d_workspace, void *stream) {
-  if (check(m) != PDS_OK || !d_x || !d_act || !d_adv || !d_logp_old || !d_log_std || !d_grads || !d_stats ||
-      !d_workspace || B < 1)
+  return pds_ppo_policy_grad_step(m, d_x, d_act, d_adv, d_logp_old, d_log_std, B, clip_ratio, d_grads, d_stats,
+                                  d_workspace, nullptr, stream);
+}
+
+extern "C" int pds_value_grad_step(const pds_mlp *m, const float *d_x, const int64_t *d_index, const float *d_target,
+                                   int64_t B, float *d_grads, float *d_stats, float *d_workspace, const pds_adam *opt,
+                                   void *stream) {
+  if (check(m) != PDS_OK || m->d_out != 1 || !d_x || !d_target || !d_grads || !d_stats || !d_workspace || B < 1 ||
+      !adam_ok(opt))
     return PDS_EINVAL;
   Args a{};
-  a.m = *m; a.x = d_x; a.B = B; a.act = d_act; a.adv = d_adv; a.logp_old = d_logp_old; a.log_std = d_log_std;
-  a.clip = clip_ratio;
-  return launch_grad(LOSS_PPO, a, d_grads, d_stats, d_workspace, stream);
+  a.m = *m; a.x = d_x; a.index = d_index; a.B = B; a.target = d_target;
+  return launch_grad(LOSS_MSE, a, d_grads, d_stats, d_workspace, opt, stream);
 }
 
 extern "C" int pds_value_grad(const pds_mlp *m, const float *d_x, const int64_t *d_index, const float *d_target,
                               int64_t B, float *d_grads, float *d_stats, float *d_workspace, void *stream) {
-  if (check(m) != PDS_OK || m->d_out != 1 || !d_x || !d_target || !d_grads || !d_stats || !d_workspace || B < 1)
-    return PDS_EINVAL;
-  Args a{};
-  a.m = *m; a.x = d_x; a.index = d_index; a.B = B; a.target = d_target;
-  return launch_grad(LOSS_MSE, a, d_grads, d_stats, d_workspace, stream);
+  return pds_value_grad_step(m, d_x, d_index, d_target, B, d_grads, d_stats, d_workspace, nullptr, stream);
 }

@@ -92,24 +92,38 @@ class FusedMLP:
             raise RuntimeError(f"pds_mlp_forward -> {rc}")
         return y
 
-    def ppo_grad(self, x, act, adv, logp_old, log_std, clip_ratio):
+    def _adam_state(self):
+        if not hasattr(self, "exp_avg"):
+            self.exp_avg = torch.zeros_like(self.flat_grad)
+            self.exp_avg_sq = torch.zeros_like(self.flat_grad)
+            self.adam_steps = 0
+
+    def _adam_arg(self, adam_lr, betas, eps):
+        """pds_adam for a gradient call that also steps (None: gradient only)"""
+        if adam_lr is None:
+            return None
+        self._adam_state()
+        self.adam_steps += 1
+        return C.byref(native.Adam(_ptr(self.exp_avg), _ptr(self.exp_avg_sq), self.adam_steps, float(adam_lr),
+                                   float(betas[0]), float(betas[1]), float(eps)))
+
+    def ppo_grad(self, x, act, adv, logp_old, log_std, clip_ratio, adam_lr=None, betas=(0.9, 0.999), eps=1e-8):
         """Fills the parameters' .grad with d loss_pi / d theta; returns the stats tensor
-        [sum(-min(..)), sum(ratio), sum(0.5 z^2), B] (device, no sync)."""
+        [sum(-min(..)), sum(ratio), sum(0.5 z^2), B] (device, no sync).  adam_lr: also take the torch.optim.Adam step
+        with this learning rate, in the same two launches (same bits as ppo_grad + adam_step)."""
         self._bind()
+        opt = self._adam_arg(adam_lr, betas, eps)
         with _on(x):
-            rc = self.lib.pds_ppo_policy_grad(C.byref(self.m), _ptr(x), _ptr(act), _ptr(adv), _ptr(logp_old), _ptr(log_std),
-                                              x.shape[0], float(clip_ratio), _ptr(self.flat_grad), _ptr(self.stats),
-                                              _ptr(self.workspace), self._stream(x))
+            rc = self.lib.pds_ppo_policy_grad_step(C.byref(self.m), _ptr(x), _ptr(act), _ptr(adv), _ptr(logp_old),
+                                                   _ptr(log_std), x.shape[0], float(clip_ratio), _ptr(self.flat_grad),
+                                                   _ptr(self.stats), _ptr(self.workspace), opt, self._stream(x))
         if rc != native.OK:
             raise RuntimeError(f"pds_ppo_policy_grad -> {rc}")
         return self.stats
 
     def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8):
         """torch.optim.Adam.step for this network's parameters from the flat gradient, in one launch."""
-        if not hasattr(self, "exp_avg"):
-            self.exp_avg = torch.zeros_like(self.flat_grad)
-            self.exp_avg_sq = torch.zeros_like(self.flat_grad)
-            self.adam_steps = 0
+        self._adam_state()
         self.adam_steps += 1
         self._bind()
         with _on(self.flat_grad):
@@ -119,13 +133,15 @@ class FusedMLP:
         if rc != native.OK:
             raise RuntimeError(f"pds_adam_step -> {rc}")
 
-    def value_grad(self, x, target, index=None):
-        """Fills .grad with d mse(net(x[index]), target[index]) / d theta; stats[0] = sum of squared errors."""
+    def value_grad(self, x, target, index=None, adam_lr=None, betas=(0.9, 0.999), eps=1e-8):
+        """Fills .grad with d mse(net(x[index]), target[index]) / d theta; stats[0] = sum of squared errors.
+        adam_lr: as in ppo_grad."""
         self._bind()
         B = x.shape[0] if index is None else index.shape[0]
+        opt = self._adam_arg(adam_lr, betas, eps)
         with _on(x):
-            rc = self.lib.pds_value_grad(C.byref(self.m), _ptr(x), _ptr(index), _ptr(target), B, _ptr(self.flat_grad),
-                                         _ptr(self.stats), _ptr(self.workspace), self._stream(x))
+            rc = self.lib.pds_value_grad_step(C.byref(self.m), _ptr(x), _ptr(index), _ptr(target), B, _ptr(self.flat_grad),
+                                              _ptr(self.stats), _ptr(self.workspace), opt, self._stream(x))
         if rc != native.OK:
             raise RuntimeError(f"pds_value_grad -> {rc}")
         return self.stats

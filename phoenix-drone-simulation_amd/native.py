@@ -36,7 +36,7 @@ EXPORTS = ["pds_version", "pds_default_config", "pds_create", "pds_destroy", "pd
            "pds_bytes_per_env_step", "pds_bytes_per_env_step_k", "pds_last_error", "pds_step_k", "pds_set_latency",
            "pds_latency_steps", "pds_philox4x32", "pds_gae", "pds_history_advance",
            "pds_mlp_param_count", "pds_mlp_workspace_floats", "pds_mlp_forward", "pds_ppo_policy_grad",
-           "pds_value_grad", "pds_gaussian_sample", "pds_gaussian_sample_dev", "pds_counter_add", "pds_permutation", "pds_rollout_record",
+           "pds_value_grad", "pds_ppo_policy_grad_step", "pds_value_grad_step", "pds_gaussian_sample", "pds_gaussian_sample_dev", "pds_counter_add", "pds_permutation", "pds_rollout_record",
            "pds_adam_step", "pds_rollout"]
 
 
@@ -46,6 +46,12 @@ class Mlp(C.Structure):
                 ("activation", C.c_int32),
                 ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
                 ("w3", C.c_void_p), ("b3", C.c_void_p)]
+
+
+class Adam(C.Structure):
+    """struct pds_adam (include/pds.h): the optimiser step that rides on a gradient call."""
+    _fields_ = [("d_exp_avg", C.c_void_p), ("d_exp_avg_sq", C.c_void_p), ("step", C.c_int64),
+                ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float)]
 
 
 class Config(C.Structure):
@@ -122,6 +128,9 @@ def load():
     lib.pds_mlp_forward.argtypes = [mp, vp, vp, i64, vp, vp, C.c_float, vp, vp]
     lib.pds_ppo_policy_grad.argtypes = [mp, vp, vp, vp, vp, vp, i64, C.c_float, vp, vp, vp, vp]
     lib.pds_value_grad.argtypes = [mp, vp, vp, vp, i64, vp, vp, vp, vp]
+    ap = C.POINTER(Adam)
+    lib.pds_ppo_policy_grad_step.argtypes = [mp, vp, vp, vp, vp, vp, i64, C.c_float, vp, vp, vp, ap, vp]
+    lib.pds_value_grad_step.argtypes = [mp, vp, vp, vp, i64, vp, vp, vp, ap, vp]
     u64 = C.c_uint64
     lib.pds_gaussian_sample.argtypes = [vp, vp, i64, i32, u64, u64, u64, i32, vp, vp, vp]
     lib.pds_gaussian_sample_dev.argtypes = [vp, vp, i64, i32, u64, vp, u64, u64, i32, vp, vp, vp]

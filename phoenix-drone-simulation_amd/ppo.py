@@ -469,6 +469,9 @@ class PPOTrainer:
             self._perm_calls += 1
             perm = random_permutation(B, self._sample_seed ^ 0x5045524D, self._perm_calls, obs.device)
             for s in range(0, mbs * self.num_mini_batches, mbs):
+                if world == 1:  # the Adam step rides on the gradient's partial-sum kernel (same bits, one launch less)
+                    self.fm_v.value_grad(obs, target_v, index=perm[s:s + mbs], adam_lr=self.vf_opt.param_groups[0]["lr"])
+                    continue
                 self.fm_v.value_grad(obs, target_v, index=perm[s:s + mbs])
                 average(self.fm_v)
                 self.fm_v.adam_step(self.vf_opt.param_groups[0]["lr"])
@@ -482,13 +485,16 @@ class PPOTrainer:
         first = None
         stop_iter = self.train_pi_iterations
         for i in range(self.train_pi_iterations):
-            stats = self.fm_pi.ppo_grad(obs, act, adv, logp_old, log_std, self.clip_ratio)
+            ride = world == 1 and not self.use_max_grad_norm  # Adam inside the gradient call (same bits)
+            stats = self.fm_pi.ppo_grad(obs, act, adv, logp_old, log_std, self.clip_ratio,
+                                        adam_lr=self.pi_opt.param_groups[0]["lr"] if ride else None)
             if first is None:
                 first = stats.clone()
-            if self.use_max_grad_norm:
-                torch.nn.utils.clip_grad_norm_(ac.pi.net.parameters(), self.max_grad_norm)
-            average(self.fm_pi)
-            self.fm_pi.adam_step(self.pi_opt.param_groups[0]["lr"])  # lr follows the LambdaLR schedule
+            if not ride:
+                if self.use_max_grad_norm:
+                    torch.nn.utils.clip_grad_norm_(ac.pi.net.parameters(), self.max_grad_norm)
+                average(self.fm_pi)
+                self.fm_pi.adam_step(self.pi_opt.param_groups[0]["lr"])  # lr follows the LambdaLR schedule
             if self.use_kl_early_stopping:
                 with torch.no_grad():  # KL(N(mu_old, s) || N(mu_new, s)) = sum (mu_old - mu_new)^2 / (2 s^2)
                     kl = (((mu_old - self.fm_pi.forward(obs)) ** 2) / (2 * torch.exp(2 * log_std))).sum(-1).mean()

@@ -274,3 +274,38 @@ def test_permutation_statistics():
     big = random_permutation(1 << 18, 5, 9, "cuda").double()
     disp = float((big - torch.arange(1 << 18, device="cuda").double()).abs().mean()) / (1 << 18)
     assert abs(disp - 1.0 / 3.0) < 0.01, disp
+
+
+@pytest.mark.parametrize("which", ["policy", "value"])
+def test_gradient_call_with_adam_step_equals_gradient_then_adam_step_bitwise(which):
+    """pds_*_grad_step (round 3): Adam applied by the partial-sum kernel -- parameters, both moment buffers and the
+    gradient after 4 steps equal, bit for bit, the route through pds_adam_step (which test_adam_... pins to torch)"""
+    import copy
+    from phoenix_drone_simulation_amd.fused import FusedMLP
+    B = 20000
+    if which == "policy":
+        net_a = _net(34, 50, 50, 4, "relu", 21)
+    else:
+        net_a = _net(34, 64, 64, 1, "tanh", 22)
+    net_b = copy.deepcopy(net_a)
+    act = "relu" if which == "policy" else "tanh"
+    fa, fb = FusedMLP(net_a, act), FusedMLP(net_b, act)
+    torch.manual_seed(3)
+    x = torch.randn(B, 34, device="cuda")
+    a4 = torch.randn(B, 4, device="cuda"); adv = torch.randn(B, device="cuda"); lp = torch.randn(B, device="cuda") - 4
+    ls = torch.full((4,), math.log(0.4), device="cuda"); tgt = torch.randn(B, device="cuda")
+    idx = torch.randperm(B, device="cuda")[:5000]
+    for it in range(4):
+        lr = 3e-4 * (it + 1)
+        if which == "policy":
+            fa.ppo_grad(x, a4, adv, lp, ls, 0.2); fa.adam_step(lr)
+            fb.ppo_grad(x, a4, adv, lp, ls, 0.2, adam_lr=lr)
+        else:
+            fa.value_grad(x, tgt, idx); fa.adam_step(lr)
+            fb.value_grad(x, tgt, idx, adam_lr=lr)
+        assert torch.equal(fa.flat_grad, fb.flat_grad), it
+    for pa, pb in zip(net_a.parameters(), net_b.parameters()):
+        assert torch.equal(pa, pb)
+    assert torch.equal(fa.exp_avg, fb.exp_avg) and torch.equal(fa.exp_avg_sq, fb.exp_avg_sq)
+    assert fa.adam_steps == fb.adam_steps == 4
+    assert not torch.equal(next(iter(net_a.parameters())), next(iter(_net(34, 50 if which == "policy" else 64, 50 if which == "policy" else 64, 4 if which == "policy" else 1, act, 21 if which == "policy" else 22).parameters())))
