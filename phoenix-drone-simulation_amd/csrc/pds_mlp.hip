@@ -523,14 +523,11 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
     constexpr int kRegs = 4 * (kNT * NIN + kNT * kNT + kNT + (GB ? 2 * kNT + 1 : 0)) + kStats;
     static_assert(2 * kRegs * 64 <= kWaves * kWaveFloats, "two register images must fit in the tile images");
     auto xfer = [&](float *slot, bool add) {
-      int r = 0;
-      auto one = [&](float &v) {
-        if (add) v += slot[r * 64 + lane]; else slot[r * 64 + lane] = v;
-        ++r;
-      };
+      int r = 0;  // 16-byte slots: one ds_read / ds_write_b128 per 4 registers, consecutive lanes 16 B apart
       auto four = [&](f32x4 &v) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { float t = v[q]; one(t); v[q] = t; }
+        float *q = slot + (r * 64 + lane) * 4;
+        if (add) v += lds4(q); else sts4(q, v);
+        ++r;
       };
 #pragma unroll
       for (int i = 0; i < kNT; ++i) {
@@ -542,7 +539,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_kernel(const Args a) {
         if (GB) { four(gb1[i]); four(gb2[i]); }
       }
       if (GB) four(gb3);
-      one(st_loss); one(st_ratio); one(st_kl); one(st_cnt);
+      f32x4 st = {st_loss, st_ratio, st_kl, st_cnt};
+      four(st);
+      st_loss = st[0]; st_ratio = st[1]; st_kl = st[2]; st_cnt = st[3];
     };
     __syncthreads();
 #pragma unroll
@@ -1042,14 +1041,11 @@ __global__ __launch_bounds__(kWaves * 64, 2) void ppo_split_kernel(const Args a)
     static_assert(2 * kRegsG * 64 <= kPairs * 2 * kSetFloats, "two G register images must fit in the tile sets");
     static_assert(2 * kRegsF * 64 <= kPairs * kPrivFloats, "two F register images must fit in the private images");
     auto xfer = [&](float *slot, bool add) {
-      int c = 0;
-      auto one = [&](float &v) {
-        if (add) v += slot[c * 64 + lane]; else slot[c * 64 + lane] = v;
-        ++c;
-      };
+      int c = 0;  // 16-byte slots (see mlp_kernel)
       auto four = [&](f32x4 &v) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { float tmp = v[q]; one(tmp); v[q] = tmp; }
+        float *q = slot + (c * 64 + lane) * 4;
+        if (add) v += lds4(q); else sts4(q, v);
+        ++c;
       };
       if (role_g) {
 #pragma unroll
@@ -1062,7 +1058,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void ppo_split_kernel(const Args a)
       } else {
 #pragma unroll
         for (int i = 0; i < kNT; ++i) four(gW3[i]);
-        one(st_loss); one(st_ratio); one(st_kl); one(st_cnt);
+        f32x4 st = {st_loss, st_ratio, st_kl, st_cnt};
+        four(st);
+        st_loss = st[0]; st_ratio = st[1]; st_kl = st[2]; st_cnt = st[3];
       }
     };
     float *red = role_g ? sets : priv;
