@@ -112,7 +112,8 @@ __host__ __device__ inline Offsets offsets(const pds_mlp &m) {
 #define PDS_SPLIT_DEBUG 0
 #endif
 #ifndef PDS_MLP_SPLIT
-#define PDS_MLP_SPLIT 1  // A/B: 0 = the default policy's PPO gradient on mlp_kernel (every wave runs every GEMM of its tiles)
+#define PDS_MLP_SPLIT 1  // weight-gradient roles of ppo_split_kernel; A/B: 2 = three waves per SIMD (measured: 454 us against 341 us at
+                         // 1 M samples -- 168 registers per wave undo F's operand prefetch), 0 = the round-2 route through mlp_kernel
 #endif
 #ifndef PDS_MLP_EDGE
 #define PDS_MLP_EDGE 1  // A/B: 0 = the fourth output tile of the 50-wide layers on the matrix cores as well
@@ -208,9 +209,9 @@ __device__ __forceinline__ f32x4 edge_cols(const float *Ws, const f32x4 (&in)[kN
 // The weight images of a block: [out][in] rows of kS floats, zero padded (W1, W2: 64 rows -- W1 may be cut to W1ROWS --,
 // W3: 16 rows).  All loads of a thread are issued before its first LDS store (nine L2 round trips in flight instead of
 // one after the other: the prologue is most of a small batch's time).
-template <int W1ROWS>
+template <int W1ROWS, int THREADS = kWaves * 64>
 __device__ __forceinline__ void stage_weights(const pds_mlp &m, float *W1s, float *W2s, float *W3s, int tid) {
-  constexpr int kThreads = kWaves * 64, kIters = (kMaxDim * kS + kThreads - 1) / kThreads;
+  constexpr int kThreads = THREADS, kIters = (kMaxDim * kS + kThreads - 1) / kThreads;
   float v1[kIters], v2[kIters], v3[kIters];
 #pragma unroll
   for (int it = 0; it < kIters; ++it) {
@@ -691,9 +692,12 @@ __device__ __forceinline__ f32x4 edge_pair(const float *wp, const f32x4 (&in)[NK
   return r;
 }
 
-template <int KJI>
-__global__ __launch_bounds__(kWaves * 64, 2) void ppo_split_kernel(const Args a) {
+// NG = 2 (not the default: slower, see PDS_MLP_SPLIT): the weight-gradient role split once more -- G1 (waves 4-7: dZ1,
+// dW1), G2 (waves 8-11: dW2) -- three waves per SIMD (12 per block, <= 168 registers each).
+template <int KJI, int NG>
+__global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const Args a) {
   constexpr int NIN = 3, KJH = 2, ACT = 0;
+  constexpr int kThreads = (1 + NG) * 256;
   __shared__ __attribute__((aligned(16))) float W1s[kW1Rows * kS];  // rows 48, 49: the vector-ALU features
   __shared__ __attribute__((aligned(16))) float W2s[kMaxDim * kS];
   __shared__ __attribute__((aligned(16))) float W3s[kTW * kS];
@@ -702,14 +706,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void ppo_split_kernel(const Args a)
   __shared__ __attribute__((aligned(16))) float sets[kPairs * 2 * kSetFloats];
   __shared__ __attribute__((aligned(16))) float priv[kPairs * kPrivFloats];
   __shared__ __attribute__((aligned(16))) float privg[kPairs * kPrivGFloats];
-  __shared__ int flags[kPairs * 4];  // per pair: full[2], empty[2]
+  __shared__ int flags[kPairs * 8];  // per pair: full[2], empty[2] (G / G1), empty2[2] (G2)
   const pds_mlp &m = a.m;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pair = wave & 3;
-  const bool role_g = wave >= kPairs;
+  const int role = wave >> 2;  // 0: F, 1: G (NG = 1) or G1, 2: G2
   const int n = lane & 15, g = lane >> 4;
-  stage_weights<kW1Rows>(m, W1s, W2s, W3s, tid);
+  stage_weights<kW1Rows, kThreads>(m, W1s, W2s, W3s, tid);
   if (tid < kMaxDim) {
     b1s[tid] = tid < m.h1 ? m.b1[tid] : 0.f;
     b2s[tid] = tid < m.h2 ? m.b2[tid] : 0.f;
@@ -719,13 +723,13 @@ __global__ __launch_bounds__(kWaves * 64, 2) void ppo_split_kernel(const Args a)
     const float ls = tid < m.d_out ? a.log_std[tid] : 0.f;
     lsg[tid] = ls;
     isg[tid] = expf(-ls);
-    flags[tid] = 0;
   }
+  if (tid < kPairs * 8) flags[tid] = 0;
   __syncthreads();
 
   const long long ntiles = (a.B + kTS - 1) / kTS;
   const long long pid = (long long)blockIdx.x * kPairs + pair, np = (long long)gridDim.x * kPairs;
-  int *full = flags + pair * 4, *empty = full + 2;
+  int *full = flags + pair * 8, *empty = full + 2, *empty2 = full + 4;
   float *pset = sets + pair * 2 * kSetFloats;
   const int r = n, h = g;  // A-operand lane roles of the weight-gradient GEMMs (k-slot (j, h) = sample 4 h + j)
   const int n3 = min(n, 3);  // column tile 3 of a 52-wide image holds columns 48..51 only
@@ -741,8 +745,32 @@ __global__ __launch_bounds__(kWaves * 64, 2) void ppo_split_kernel(const Args a)
     for (int j = 0; j < NIN; ++j) gW1[i][j] = (f32x4)(0.f);
   }
 
-  if (role_g) {
-    // ================= G: dZ1 and the two large weight-gradient GEMMs =========================================
+  if (role == 2) {
+    // ================= G2 (NG = 2): dW2 += dZ2^T H1 =========================================================
+    const int r3 = min(r, 3);
+    int k = 0;
+    for (long long t = pid; t < ntiles; t += np, ++k) {
+      const int s = k & 1;
+      const float *H1img = pset + s * kSetFloats + kTS * kSI, *dZ2img = H1img + kTS * kSI;
+      wait_ge(full + s, (k >> 1) + 1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float av[kNT], bv[kNT];
+        const int row = (4 * h + j) * kSI;
+#pragma unroll
+        for (int i = 0; i < kNT; ++i) {
+          av[i] = dZ2img[row + i * kTW + (i == kNT - 1 ? r3 : r)];
+          bv[i] = H1img[row + i * kTW + (i == kNT - 1 ? n3 : n)];
+        }
+#pragma unroll
+        for (int it = 0; it < kNT; ++it)
+#pragma unroll
+          for (int jt = 0; jt < kNT; ++jt) gW2[it][jt] = PDS_MFMA(av[it], bv[jt], gW2[it][jt]);
+      }
+      signal(empty2 + s, (k >> 1) + 1, lane);
+    }
+  } else if (role == 1) {
+    // ================= G (NG = 1) / G1: dZ1 and the weight-gradient GEMMs =========================================
     __builtin_amdgcn_s_setprio(PDS_SPLIT_GPRIO);
     float *dZ1img = privg + pair * kPrivGFloats;
     float wz1[kNT][4][kNT - 1];  // W2^T read column-wise: tile invariant, kept in registers
@@ -783,9 +811,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void ppo_split_kernel(const Args a)
             if (kt < kNT - 1 || j < KJH)
               cc[jt] = PDS_MFMA(wz1[kt][j][jt], dz2[kt][j], (kt == 0 && j == 0) ? (f32x4)(0.f) : cc[jt]);
       PDS_SSTAMP(1, 2);
-      // ---- dW2 += dZ2^T H1 (covers the result latency of dZ1) ----
+      // ---- dW2 += dZ2^T H1 (covers the result latency of dZ1; G2's job when there is one) ----
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < (NG == 1 ? 4 : 0); ++j) {
         float av[kNT], bv[kNT];
         const int row = (4 * h + j) * kSI;
 #pragma unroll
@@ -867,7 +895,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void ppo_split_kernel(const Args a)
       const int s = k & 1;
       float *Ximg = pset + s * kSetFloats, *H1img = Ximg + kTS * kSI, *dZ2img = H1img + kTS * kSI;
 #if PDS_SPLIT_DEBUG == 2
-      if (k >= 2) wait_ge(empty + s, k >> 1);
+      if (k >= 2) { wait_ge(empty + s, k >> 1); if (NG == 2) wait_ge(empty2 + s, k >> 1); }
       signal(full + s, (k >> 1) + 1, lane);
       continue;
 #endif
@@ -893,7 +921,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void ppo_split_kernel(const Args a)
           if (4 * g + q < m.d_out) c_act[q] = a.act[(s0 + n) * m.d_out + 4 * g + q];
         c_adv = a.adv[s0 + n]; c_old = a.logp_old[s0 + n];
       }
-      if (k >= 2) wait_ge(empty + s, k >> 1);  // G is done with the tile that used this set
+      if (k >= 2) {  // the weight-gradient waves are done with the tile that used this set
+        wait_ge(empty + s, k >> 1);
+        if (NG == 2) wait_ge(empty2 + s, k >> 1);
+      }
       PDS_SSTAMP(0, 1);
 #pragma unroll
       for (int kt = 0; kt < NIN; ++kt) sts4(Ximg + n * kSI + kt * kTW + 4 * g, xin[kt]);
@@ -1034,11 +1065,11 @@ __global__ __launch_bounds__(kWaves * 64, 2) void ppo_split_kernel(const Args a)
     }
   }
 
-  // ---- block sums: the 4 G waves add up (dW1, dW2), the 4 F waves (dW3, statistics); rounds 2,3 -> 0,1 and 1 -> 0
-  // of each role through LDS (the images are free now) -------------------------------------------------------------
+  // ---- block sums: the 4 waves of each role add up what that role accumulates (F: dW3, statistics; G / G1: dW1 (+ dW2);
+  // G2: dW2); rounds 2,3 -> 0,1 and 1 -> 0 through LDS (the images are free now) -------------------------------------
   {
-    constexpr int kRegsG = 4 * (kNT * NIN + kNT * kNT), kRegsF = 4 * kNT + kStats;
-    static_assert(2 * kRegsG * 64 <= kPairs * 2 * kSetFloats, "two G register images must fit in the tile sets");
+    constexpr int kRegs1 = 4 * (kNT * NIN + (NG == 1 ? kNT * kNT : 0)), kRegs2 = 4 * kNT * kNT, kRegsF = 4 * kNT + kStats;
+    static_assert(2 * (kRegs1 + (NG == 2 ? kRegs2 : 0)) * 64 <= kPairs * 2 * kSetFloats, "the register images of the weight-gradient roles must fit in the tile sets");
     static_assert(2 * kRegsF * 64 <= kPairs * kPrivFloats, "two F register images must fit in the private images");
     auto xfer = [&](float *slot, bool add) {
       int c = 0;  // 16-byte slots (see mlp_kernel)
@@ -1047,14 +1078,21 @@ __global__ __launch_bounds__(kWaves * 64, 2) void ppo_split_kernel(const Args a)
         if (add) v += lds4(q); else sts4(q, v);
         ++c;
       };
-      if (role_g) {
+      if (role == 1) {
 #pragma unroll
         for (int i = 0; i < kNT; ++i) {
 #pragma unroll
           for (int j = 0; j < NIN; ++j) four(gW1[i][j]);
+          if (NG == 1) {
+#pragma unroll
+            for (int j = 0; j < kNT; ++j) four(gW2[i][j]);
+          }
+        }
+      } else if (role == 2) {
+#pragma unroll
+        for (int i = 0; i < kNT; ++i)
 #pragma unroll
           for (int j = 0; j < kNT; ++j) four(gW2[i][j]);
-        }
       } else {
 #pragma unroll
         for (int i = 0; i < kNT; ++i) four(gW3[i]);
@@ -1063,8 +1101,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void ppo_split_kernel(const Args a)
         st_loss = st[0]; st_ratio = st[1]; st_kl = st[2]; st_cnt = st[3];
       }
     };
-    float *red = role_g ? sets : priv;
-    const int stride = (role_g ? kRegsG : kRegsF) * 64;
+    float *red = role == 0 ? priv : (role == 1 ? sets : sets + 2 * kRegs1 * 64);
+    const int stride = (role == 0 ? kRegsF : (role == 1 ? kRegs1 : kRegs2)) * 64;
     __syncthreads();
 #pragma unroll
     for (int round = 0; round < 2; ++round) {
@@ -1078,7 +1116,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void ppo_split_kernel(const Args a)
   }
   float *out = a.partials + (long long)blockIdx.x * a.pstride;
   const Offsets o = offsets(m);
-  if (role_g) {
+  if (role != 0) {
 #pragma unroll
     for (int it = 0; it < kNT; ++it) {
 #pragma unroll
@@ -1087,10 +1125,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void ppo_split_kernel(const Args a)
 #pragma unroll
         for (int jt = 0; jt < kNT; ++jt) {
           const int j = jt * kTW + n;
-          if (jt < NIN && i < m.h1 && j < m.d_in) out[o.w1 + i * m.d_in + j] = gW1[it][jt < NIN ? jt : 0][q];
-          if (jt < NIN && i < m.h1 && j == m.d_in) out[o.b1 + i] = gW1[it][jt < NIN ? jt : 0][q];
-          if (i < m.h2 && j < m.h1) out[o.w2 + i * m.h1 + j] = gW2[it][jt][q];
-          if (i < m.h2 && j == m.h1) out[o.b2 + i] = gW2[it][jt][q];
+          if (role == 1) {
+            if (jt < NIN && i < m.h1 && j < m.d_in) out[o.w1 + i * m.d_in + j] = gW1[it][jt < NIN ? jt : 0][q];
+            if (jt < NIN && i < m.h1 && j == m.d_in) out[o.b1 + i] = gW1[it][jt < NIN ? jt : 0][q];
+          }
+          if (role == (NG == 1 ? 1 : 2)) {
+            if (i < m.h2 && j < m.h1) out[o.w2 + i * m.h1 + j] = gW2[it][jt][q];
+            if (i < m.h2 && j == m.h1) out[o.b2 + i] = gW2[it][jt][q];
+          }
         }
       }
     }
@@ -1269,8 +1311,9 @@ static int launch_grad(int loss, Args &a, float *d_grads, float *d_stats, float 
     const long long tiles = (a.B + kTS - 1) / kTS;
     blocks = (int)((tiles + kPairs - 1) / kPairs < kMaxGridBlocks ? (tiles + kPairs - 1) / kPairs : kMaxGridBlocks);
     const dim3 gs(blocks);
-    if (two_input_steps(a.m)) hipLaunchKernelGGL((ppo_split_kernel<2>), gs, b, 0, s, a);
-    else hipLaunchKernelGGL((ppo_split_kernel<4>), gs, b, 0, s, a);
+    const dim3 bs((1 + PDS_MLP_SPLIT) * 256);  // PDS_MLP_SPLIT = number of weight-gradient roles
+    if (two_input_steps(a.m)) hipLaunchKernelGGL((ppo_split_kernel<2, PDS_MLP_SPLIT>), gs, bs, 0, s, a);
+    else hipLaunchKernelGGL((ppo_split_kernel<4, PDS_MLP_SPLIT>), gs, bs, 0, s, a);
   } else if (loss == LOSS_PPO && a.m.activation == 0 && !gb && !wide && two_hidden_steps(a.m)) {
     if (two_input_steps(a.m)) hipLaunchKernelGGL((mlp_kernel<LOSS_PPO, 0, 1, false, 2, 2>), g, b, 0, s, a);
     else hipLaunchKernelGGL((mlp_kernel<LOSS_PPO, 0, 1, false, 4, 2>), g, b, 0, s, a);
