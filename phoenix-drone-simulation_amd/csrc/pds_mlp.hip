@@ -99,6 +99,16 @@ __host__ __device__ inline Offsets offsets(const pds_mlp &m) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       \
   } while (0)
 
+#ifndef PDS_SPLIT_DYNPRIO
+#define PDS_SPLIT_DYNPRIO 1
+#endif
+#if PDS_SPLIT_DYNPRIO  // A/B: the forward role raises its priority for its MFMA bursts only
+#define PDS_FPRIO_MFMA() __builtin_amdgcn_s_setprio(2)
+#define PDS_FPRIO_VALU() __builtin_amdgcn_s_setprio(0)
+#else
+#define PDS_FPRIO_MFMA() do { } while (0)
+#define PDS_FPRIO_VALU() do { } while (0)
+#endif
 #ifndef PDS_SPLIT_GPRIO
 #define PDS_SPLIT_GPRIO 0
 #endif
@@ -935,6 +945,7 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
       for (int kt = 0; kt < kNT; ++kt)
 #pragma unroll
         for (int it = 0; it < kNT - 1; ++it) a2[it][kt] = lds4(w2p + it * kTW * kS + kt * kTW);
+      PDS_FPRIO_MFMA();
       // ---- layer 1: three accumulation chains alternate (tiles 0..2), each started from its bias; features 48, 49
       // on the vector ALU (packed pairs: even / odd feature slots) ----
       f32x4 h1r[kNT], h2r[kNT], cc[kNT];
@@ -947,6 +958,7 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
 #pragma unroll
           for (int it = 0; it < kNT - 1; ++it)
             if (kt < NIN - 1 || j < KJI) cc[it] = PDS_MFMA(a1[it][kt][j], xin[kt][j], cc[it]);
+      PDS_FPRIO_VALU();
       PDS_SSTAMP(0, 2);
       load_x(t + np, xraw);  // the next tile's rows: in flight during the rest of this tile
       cc[kNT - 1] = edge_pair<NIN>(e1p, xin, b1s + 48, g);
@@ -963,6 +975,7 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
         if (it < kNT - 1 || g == 0) sts4(H1img + n * kSI + it * kTW + 4 * g, v);
       }
       PDS_SSTAMP(0, 3);
+      PDS_FPRIO_MFMA();
       // ---- layer 2 ----
 #pragma unroll
       for (int it = 0; it < kNT - 1; ++it) cc[it] = lds4(b2s + it * kTW + 4 * g);
@@ -973,6 +986,7 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
 #pragma unroll
           for (int it = 0; it < kNT - 1; ++it)
             if (kt < kNT - 1 || j < KJH) cc[it] = PDS_MFMA(a2[it][kt][j], h1r[kt][j], cc[it]);
+      PDS_FPRIO_VALU();
       PDS_SSTAMP(0, 4);
       cc[kNT - 1] = edge_pair<kNT>(e2p, h1r, b2s + 48, g);
 #pragma unroll
@@ -984,6 +998,7 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
         if (it < kNT - 1 || g == 0) sts4(H2img + n * kSI + it * kTW + 4 * g, v);
       }
       PDS_SSTAMP(0, 5);
+      PDS_FPRIO_MFMA();
       // ---- layer 3: two chains (even / odd k-tiles) ----
       f32x4 y;
       {
@@ -1000,6 +1015,7 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
         }
         y = c0 + c1;
       }
+      PDS_FPRIO_VALU();
       PDS_SSTAMP(0, 6);
       // ---- loss: compute_loss_pi, algs/ppo/ppo.py:22-40 (see mlp_kernel) ----
       f32x4 dy = (f32x4)(0.f);
@@ -1037,6 +1053,7 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
 #pragma unroll
         for (int jt = 0; jt < kNT; ++jt) bv3[j][jt] = H2img[(4 * h + j) * kSI + jt * kTW + (jt == kNT - 1 ? n3 : n)];
       }
+      PDS_FPRIO_MFMA();
       // ---- dZ2^T = (W3^T dY^T) * act'(H2^T): the k-slot (step jj, lane group h) carries output 4 jj + h, so one
       // step covers the 4 action dimensions of the drone (mlp_kernel's slot order needs 4 steps for them) ----
 #pragma unroll
@@ -1051,6 +1068,7 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int jt = 0; jt < kNT; ++jt) gW3[jt] = PDS_MFMA(av3[j], bv3[j][jt], gW3[jt]);
+      PDS_FPRIO_VALU();
       PDS_SSTAMP(0, 8);
 #pragma unroll
       for (int it = 0; it < kNT; ++it) {
