@@ -1031,8 +1031,11 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
           kl += on ? 0.5f * z * z : 0.f;
           zs[q] = on ? z * is4[q] : 0.f;
         }
-        lp += __shfl_xor(lp, 16); lp += __shfl_xor(lp, 32);
-        kl += __shfl_xor(kl, 16); kl += __shfl_xor(kl, 32);
+        if (m.d_out > 4) {  // the sums over the action dimensions span two lane groups (else: group 0 holds all of them, and
+                            // the other groups' values only ever multiply their own zs = 0)
+          lp += __shfl_xor(lp, 16); lp += __shfl_xor(lp, 32);
+          kl += __shfl_xor(kl, 16); kl += __shfl_xor(kl, 32);
+        }
         const float ratio = expf(lp - c_old);
         const float lo = 1.f - a.clip, hi = 1.f + a.clip;
         const float obj = fminf(ratio * c_adv, fminf(fmaxf(ratio, lo), hi) * c_adv);
