@@ -129,6 +129,17 @@ __host__ __device__ inline Offsets offsets(const pds_mlp &m) {
 #define PDS_MLP_EDGE 1  // A/B: 0 = the fourth output tile of the 50-wide layers on the matrix cores as well
 #endif
 #define PDS_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#if PDS_SPLIT_DEBUG == 3  // profiling: the forward role WITHOUT its MFMAs -- operands stay alive, no instruction is
+                           // issued: what the rest of its instruction stream costs the pair (results invalid)
+typedef float pds_f32x4_ __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ pds_f32x4_ pds_no_mfma(float a, float b, pds_f32x4_ c) {
+  asm volatile("" : "+v"(c) : "v"(a), "v"(b));
+  return c;
+}
+#define PDS_MFMA_F(a, b, c) pds_no_mfma((a), (b), (c))
+#else
+#define PDS_MFMA_F(a, b, c) PDS_MFMA(a, b, c)
+#endif
 
 __device__ __forceinline__ f32x4 lds4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 __device__ __forceinline__ void sts4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
@@ -957,7 +968,7 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
         for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int it = 0; it < kNT - 1; ++it)
-            if (kt < NIN - 1 || j < KJI) cc[it] = PDS_MFMA(a1[it][kt][j], xin[kt][j], cc[it]);
+            if (kt < NIN - 1 || j < KJI) cc[it] = PDS_MFMA_F(a1[it][kt][j], xin[kt][j], cc[it]);
       PDS_FPRIO_VALU();
       PDS_SSTAMP(0, 2);
       load_x(t + np, xraw);  // the next tile's rows: in flight during the rest of this tile
@@ -985,7 +996,7 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
         for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int it = 0; it < kNT - 1; ++it)
-            if (kt < kNT - 1 || j < KJH) cc[it] = PDS_MFMA(a2[it][kt][j], h1r[kt][j], cc[it]);
+            if (kt < kNT - 1 || j < KJH) cc[it] = PDS_MFMA_F(a2[it][kt][j], h1r[kt][j], cc[it]);
       PDS_FPRIO_VALU();
       PDS_SSTAMP(0, 4);
       cc[kNT - 1] = edge_pair<kNT>(e2p, h1r, b2s + 48, g);
@@ -1005,13 +1016,13 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
         f32x4 c0, c1;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          c0 = PDS_MFMA(a3[0][j], h2r[0][j], j == 0 ? lds4(b3s + 4 * g) : c0);
-          c1 = PDS_MFMA(a3[1][j], h2r[1][j], j == 0 ? (f32x4)(0.f) : c1);
+          c0 = PDS_MFMA_F(a3[0][j], h2r[0][j], j == 0 ? lds4(b3s + 4 * g) : c0);
+          c1 = PDS_MFMA_F(a3[1][j], h2r[1][j], j == 0 ? (f32x4)(0.f) : c1);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          c0 = PDS_MFMA(a3[2][j], h2r[2][j], c0);
-          if (j < KJH) c1 = PDS_MFMA(a3[3][j], h2r[3][j], c1);
+          c0 = PDS_MFMA_F(a3[2][j], h2r[2][j], c0);
+          if (j < KJH) c1 = PDS_MFMA_F(a3[3][j], h2r[3][j], c1);
         }
         y = c0 + c1;
       }
@@ -1060,17 +1071,17 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
       // ---- dZ2^T = (W3^T dY^T) * act'(H2^T): the k-slot (step jj, lane group h) carries output 4 jj + h, so one
       // step covers the 4 action dimensions of the drone (mlp_kernel's slot order needs 4 steps for them) ----
 #pragma unroll
-      for (int it = 0; it < kNT; ++it) cc[it] = PDS_MFMA(wz2[it], dyb, (f32x4)(0.f));
+      for (int it = 0; it < kNT; ++it) cc[it] = PDS_MFMA_F(wz2[it], dyb, (f32x4)(0.f));
       if (m.d_out > 4) {
         const float dyb2 = dYimg[n * kSY + 4 + h];
 #pragma unroll
-        for (int it = 0; it < kNT; ++it) cc[it] = PDS_MFMA(W3s[(4 + h) * kS + it * kTW + r], dyb2, cc[it]);
+        for (int it = 0; it < kNT; ++it) cc[it] = PDS_MFMA_F(W3s[(4 + h) * kS + it * kTW + r], dyb2, cc[it]);
       }
       // ---- dW3 += dY^T H2 (its 16 MFMAs cover the result latency of dZ2) ----
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int jt = 0; jt < kNT; ++jt) gW3[jt] = PDS_MFMA(av3[j], bv3[j][jt], gW3[jt]);
+        for (int jt = 0; jt < kNT; ++jt) gW3[jt] = PDS_MFMA_F(av3[j], bv3[j][jt], gW3[jt]);
       PDS_FPRIO_VALU();
       PDS_SSTAMP(0, 8);
 #pragma unroll

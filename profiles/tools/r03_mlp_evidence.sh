@@ -5,6 +5,7 @@
 #   libpds_nosplit.so -DPDS_MLP_SPLIT=0                   (round 2 + features 48/49 on the vector ALU)
 #   libpds_split3.so  -DPDS_MLP_SPLIT=2                   (three waves per SIMD)
 #   libpds_dbg1.so / libpds_dbg2.so -DPDS_SPLIT_DEBUG=1/2 (role F alone / role G alone: timing only, results invalid)
+#   libpds_dbg3.so    -DPDS_SPLIT_DEBUG=3                  (role F without its MFMAs next to G: timing only)
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$REPO/gpurun_out/r03_mlp; mkdir -p $O
 S=$REPO/profiles/tools/scratch
@@ -13,6 +14,7 @@ python profiles/tools/mlp_bench.py 2>&1 | grep -v amdgpu > $O/mlp_bench.txt
 ( for v in r2mlp nosplit; do echo "== $v"; PDS_LIB=$S/libpds_$v.so python profiles/tools/mlp_sizes.py 2>&1 | grep "^D"; done
   echo "== wave roles (shipped)"; python profiles/tools/mlp_sizes.py 2>&1 | grep "^D"
   echo "== three waves per SIMD (-DPDS_MLP_SPLIT=2)"; PDS_LIB=$S/libpds_split3.so python profiles/tools/mlp_sizes.py 2>&1 | grep "^D 42"
+  echo "== role F without its MFMAs, next to G (PDS_SPLIT_DEBUG=3)"; PDS_LIB=$S/libpds_dbg3.so python profiles/tools/mlp_sizes.py 2>&1 | grep "^D 42" | grep -E "B +(16|524288|1048576):"
   for d in 1 2; do echo "== role $( [ $d = 1 ] && echo F || echo G ) alone (PDS_SPLIT_DEBUG=$d)"; PDS_LIB=$S/libpds_dbg$d.so python profiles/tools/mlp_sizes.py 2>&1 | grep "^D 42" | grep -E "B +(16|524288|1048576):"; done ) > $O/mlp_ab.txt 2>&1
 bash profiles/tools/pmc_mlp.sh > $O/pmc_mlp_split.txt 2>&1
 ( $S/wave_simd; $S/mfma_issue ) > $O/microbench.txt 2>&1
