@@ -766,7 +766,7 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
     for (int j = 0; j < NIN; ++j) gW1[i][j] = (f32x4)(0.f);
   }
 
-  if (role == 2) {
+  if (NG == 2 && role == 2) {
     // ================= G2 (NG = 2): dW2 += dZ2^T H1 =========================================================
     const int r3 = min(r, 3);
     int k = 0;
