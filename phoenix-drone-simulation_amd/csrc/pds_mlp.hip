@@ -99,6 +99,9 @@ __host__ __device__ inline Offsets offsets(const pds_mlp &m) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       \
   } while (0)
 
+#ifndef PDS_SPLIT_WRES
+#define PDS_SPLIT_WRES 1
+#endif
 #ifndef PDS_SPLIT_DYNPRIO
 #define PDS_SPLIT_DYNPRIO 1
 #endif
@@ -909,6 +912,19 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
     };
     const float *w1p = W1s + n * kS + 4 * g, *w2p = W2s + n * kS + 4 * g, *w3p = W3s + n * kS + 4 * g;
     const float *e1p = W1s + 48 * kS + 4 * g, *e2p = W2s + 48 * kS + 4 * g;
+#if PDS_SPLIT_WRES  // the forward GEMMs' weight operands are tile invariant: 100 registers instead of 25 b128 LDS reads per tile
+    f32x4 a1[kNT - 1][NIN], a2[kNT - 1][kNT], a3[kNT];
+#pragma unroll
+    for (int kt = 0; kt < NIN; ++kt)
+#pragma unroll
+      for (int it = 0; it < kNT - 1; ++it) a1[it][kt] = lds4(w1p + it * kTW * kS + kt * kTW);
+#pragma unroll
+    for (int kt = 0; kt < kNT; ++kt) {
+#pragma unroll
+      for (int it = 0; it < kNT - 1; ++it) a2[it][kt] = lds4(w2p + it * kTW * kS + kt * kTW);
+      a3[kt] = lds4(w3p + kt * kTW);
+    }
+#endif
     f32x4 xraw[NIN];
     load_x(pid, xraw);
     int k = 0;
@@ -924,11 +940,13 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
       const long long s0 = t * kTS;
       const bool valid = s0 + n < a.B;
       // operands of layer 1 (and of its two vector-ALU rows)
+#if !PDS_SPLIT_WRES
       f32x4 a1[kNT - 1][NIN];
 #pragma unroll
       for (int kt = 0; kt < NIN; ++kt)
 #pragma unroll
         for (int it = 0; it < kNT - 1; ++it) a1[it][kt] = lds4(w1p + it * kTW * kS + kt * kTW);
+#endif
       // no masking of the input: a sample outside the batch carries gcoef = 0 (its forward pass runs on the clamped
       // row and is discarded), and a feature slot >= d_in (a clamped re-read) meets a zero column of W1 on the way
       // forward and a discarded column of dW1 on the way back
@@ -951,11 +969,13 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
       for (int kt = 0; kt < NIN; ++kt) sts4(Ximg + n * kSI + kt * kTW + 4 * g, xin[kt]);
       if (g == 0) Ximg[n * kSI + m.d_in] = 1.f;  // the bias column of dW1 (after the row's b128 stores: LDS keeps a wave's order)
       // operands of layer 2: in flight during the MFMAs of layer 1
+#if !PDS_SPLIT_WRES
       f32x4 a2[kNT - 1][kNT];
 #pragma unroll
       for (int kt = 0; kt < kNT; ++kt)
 #pragma unroll
         for (int it = 0; it < kNT - 1; ++it) a2[it][kt] = lds4(w2p + it * kTW * kS + kt * kTW);
+#endif
       PDS_FPRIO_MFMA();
       // ---- layer 1: three accumulation chains alternate (tiles 0..2), each started from its bias; features 48, 49
       // on the vector ALU (packed pairs: even / odd feature slots) ----
@@ -974,9 +994,11 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
       load_x(t + np, xraw);  // the next tile's rows: in flight during the rest of this tile
       cc[kNT - 1] = edge_pair<NIN>(e1p, xin, b1s + 48, g);
       // operands of layer 3
+#if !PDS_SPLIT_WRES
       f32x4 a3[kNT];
 #pragma unroll
       for (int kt = 0; kt < kNT; ++kt) a3[kt] = lds4(w3p + kt * kTW);
+#endif
 #pragma unroll
       for (int it = 0; it < kNT; ++it) {
 #pragma unroll
