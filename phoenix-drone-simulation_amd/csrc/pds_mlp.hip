@@ -893,10 +893,10 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
     }
   } else {
     // ================= F: forward, loss, backward through the activations, dW3 ================================
-    // Source order = issue order here (the compiler keeps it when registers allow): the LDS operands of a GEMM are
-    // read one phase AHEAD of its MFMAs; W3^T (dZ2's operand) stays in registers.
-    // F is the longer role and its MFMAs come in bursts between vector-ALU phases: with equal priority the arbiter
-    // gives G, which always has MFMAs ready, every other slot of a burst and F stretches; with F first, G fills the gaps
+    // Source order = issue order here (the compiler keeps it when registers allow).  F's weights are tile invariant:
+    // the A operands of the three forward GEMMs (PDS_SPLIT_WRES) and W3^T (dZ2's operand) stay in registers; what is
+    // left in LDS (the two vector-ALU rows, the images) is read a phase ahead of its use.
+    // F's MFMAs come in bursts between vector-ALU phases; it raises its priority for the bursts (PDS_FPRIO_MFMA).
     __builtin_amdgcn_s_setprio(PDS_SPLIT_FPRIO);
     float *H2img = priv + pair * kPrivFloats, *dYimg = H2img + kTS * kSI;
     float wz2[kNT];
