@@ -309,3 +309,34 @@ def test_gradient_call_with_adam_step_equals_gradient_then_adam_step_bitwise(whi
     assert torch.equal(fa.exp_avg, fb.exp_avg) and torch.equal(fa.exp_avg_sq, fb.exp_avg_sq)
     assert fa.adam_steps == fb.adam_steps == 4
     assert not torch.equal(next(iter(net_a.parameters())), next(iter(_net(34, 50 if which == "policy" else 64, 50 if which == "policy" else 64, 4 if which == "policy" else 1, act, 21 if which == "policy" else 22).parameters())))
+
+
+def test_round3_entry_points_reject_bad_arguments():
+    """pds_permutation / pds_*_grad_step through the C ABI: PDS_EINVAL (not a launch) for an empty range, a missing
+    output, an optimiser block without state or with step 0"""
+    import ctypes as C
+    from phoenix_drone_simulation_amd import native
+    from phoenix_drone_simulation_amd.fused import FusedMLP, _ptr
+    lib = native.load()
+    out = torch.empty(8, dtype=torch.int64, device="cuda")
+    assert lib.pds_permutation(_ptr(out), 0, 1, 1, None) == native.EINVAL
+    assert lib.pds_permutation(None, 8, 1, 1, None) == native.EINVAL
+    assert lib.pds_permutation(_ptr(out), 8, 1, 1, None) == native.OK
+    net = _net(34, 50, 50, 4, "relu", 4)
+    fm = FusedMLP(net, "relu"); fm._bind(); fm._adam_state()
+    B = 64
+    x = torch.randn(B, 34, device="cuda"); a = torch.randn(B, 4, device="cuda")
+    adv = torch.randn(B, device="cuda"); lp = torch.randn(B, device="cuda") - 5; ls = torch.zeros(4, device="cuda")
+    before = [p.detach().clone() for p in net.parameters()]
+
+    def call(opt):
+        return lib.pds_ppo_policy_grad_step(C.byref(fm.m), _ptr(x), _ptr(a), _ptr(adv), _ptr(lp), _ptr(ls), B, 0.2,
+                                            _ptr(fm.flat_grad), _ptr(fm.stats), _ptr(fm.workspace), opt, None)
+    bad_step = native.Adam(_ptr(fm.exp_avg), _ptr(fm.exp_avg_sq), 0, 1e-3, 0.9, 0.999, 1e-8)
+    no_state = native.Adam(None, _ptr(fm.exp_avg_sq), 1, 1e-3, 0.9, 0.999, 1e-8)
+    assert call(C.byref(bad_step)) == native.EINVAL
+    assert call(C.byref(no_state)) == native.EINVAL
+    torch.cuda.synchronize()
+    for p, q in zip(net.parameters(), before):
+        assert torch.equal(p, q)  # nothing was launched
+    assert call(None) == native.OK
