@@ -158,6 +158,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--envs-per-gpu", type=int, default=None,
                     help="override the env count of the chosen config (default: the config's own, 2^20 for 0)")
+    ap.add_argument("--total-envs", type=int, default=None,
+                    help="STRONG scaling (SURVEY 8e: 2^23 total): the env count of the whole job, split into contiguous "
+                         "global-id blocks of total/N envs per GPU; the line then says \"scaling\": \"strong\"")
     ap.add_argument("--task", default="hover", choices=["hover", "circle", "takeoff"])
     ap.add_argument("--config", type=int, default=0,
                     help="0: north-star headline (Hover 2^20/GPU); 2/3/4: BASELINE.json configs[1..3]; "
@@ -227,6 +230,14 @@ def main():
         kw = dict(observation_noise=1, domain_randomization=0.10, motor_thrust_noise=0.05)
     if args.envs_per_gpu is not None:
         n = args.envs_per_gpu
+    scaling = "weak"
+    if args.total_envs is not None:  # fixed total work: rank r owns global ids [r * total / N, (r + 1) * total / N)
+        if args.envs_per_gpu is not None:
+            raise SystemExit("--total-envs and --envs-per-gpu exclude each other")
+        if args.total_envs % world:
+            raise SystemExit(f"--total-envs {args.total_envs} is not a multiple of the {world} ranks")
+        n = args.total_envs // world
+        scaling = "strong"
     env_id = {"hover": "DroneHoverSimpleEnv-v0", "circle": "DroneCircleSimpleEnv-v0",
               "takeoff": "DroneTakeOffSimpleEnv-v0"}[task]
     env = pds.make(env_id, num_envs=n, device=dev, seed=0, env_id_base=rank * n,
@@ -358,7 +369,7 @@ def main():
         line = {
             "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{env_id}, {n} envs per GPU lockstep, fp32, observation noise "
                                    f"{'on' if kw['observation_noise'] > 0 else 'off'}, thrust noise {kw['motor_thrust_noise']}, "
@@ -376,6 +387,12 @@ def main():
                          "avg_launch_ms": kernel_ms, "steps_per_launch": K, "mode": args.mode,
                          "algorithmic_bytes_per_launch": launch_bytes},
         }
+        # what the job really ran on (for reading a scaling curve: ranks, devices this process saw, the collective backend)
+        line["ranks"] = world
+        line["visible_devices"] = torch.cuda.device_count()
+        line["device_name"] = torch.cuda.get_device_name(dev)
+        line["collective_backend"] = (dist.get_backend() if world > 1 else None)
+        line["total_envs"] = total_envs
         if per_rank_ms is not None:
             line["per_rank_ms_per_step"] = per_rank_ms
         if gather_ms is not None:

@@ -489,6 +489,10 @@ def main():
     scen.append(("takeoff_obsf25", "takeoff", dict(observation_frequency=25, domain_randomization=-1), 6, 10, act_random(0.2, center=0.2), 323, False, None, False))
     scen.append(("circle_obsf50_det", "circle", dict(DET, observation_frequency=50), 8, 10, act_random(0.3), 324, False, None, False))
     scen.append(("hover_obsf33_agg3", "hover", dict(observation_frequency=33, aggregate_phy_steps=3, domain_randomization=-1), 6, 8, act_random(0.2), 325, False, None, False))
+    # sensor noise with aggregate_phy_steps > 1 on CIRCLE: the reference point is indexed by iteration // aggregate_phy_steps
+    # (circle.py:143-146), so a wrong env.step counter shows in target, reward and observation
+    scen.append(("circle_noise_agg2", "circle", dict(aggregate_phy_steps=2, domain_randomization=-1), 6, 10, act_random(0.2), 326, False, None, False))
+    scen.append(("circle_defaults_agg3", "circle", dict(aggregate_phy_steps=3), 6, 8, act_random(0.2), 327, False, None, False))
 
     only = set(args.only.split(",")) if args.only else None
     index = {}

@@ -1,5 +1,7 @@
 import importlib
 
+from ..core import Env
+
 registry = {}
 
 
@@ -12,8 +14,9 @@ def register(id, entry_point, max_episode_steps=None, **kw):
     registry[id] = _Spec(id, entry_point, max_episode_steps)
 
 
-class TimeLimit:
-    """gymnasium>=0.29 TimeLimit: truncated = elapsed_steps >= max_episode_steps."""
+class TimeLimit(Env):
+    """gymnasium>=0.29 TimeLimit (a gymnasium.Wrapper, i.e. an Env: algs/iwpg/iwpg.py:222 asserts it):
+    truncated = elapsed_steps >= max_episode_steps."""
 
     def __init__(self, env, max_episode_steps):
         self.env = env

@@ -144,6 +144,9 @@ class BulletClient:
 
     def __getattr__(self, name):
         # everything else (debug visualiser, gravity, engine params, changeDynamics ...) is a no-op
+        if name.startswith("__"):  # introspection (the reference's JSON logger probes __name__), not a Bullet call
+            raise AttributeError(name)
+
         def _noop(*a, **kw):
             return 0
         return _noop

@@ -12,7 +12,7 @@
 #include <utility>
 #include <vector>
 
-#include "pds_types.h"
+#include "pds_reset.h"  // (pds_types.h + regen_kept_obs for pds_get_state)
 
 namespace pds {
 
@@ -26,6 +26,9 @@ struct FieldArgs {
   int task;
   int set;
   int has_motor, has_dr, has_tn, has_on, ctrl;
+  int regen_obs;  // observation noise without the Kalman hold: the kept observation is regenerated unless kCtrOhBit (pds_types.h)
+  unsigned long long env_id_base;
+  uint32_t seed_lo, seed_hi;
 };
 
 __global__ __launch_bounds__(kBlock) void field_kernel(const FieldArgs a) {
@@ -84,18 +87,18 @@ __global__ __launch_bounds__(kBlock) void field_kernel(const FieldArgs a) {
         const uint32_t s_new = (uint32_t)ui[i] & 0xFFFFu;
         if (a.task == PDS_TASK_CIRCLE)  // keep ref_offset: the stored phase is (steps + ref_offset) mod num_ref_points
           off = (circle_ref_offset(c, a.k.ref_points) + s_new % (uint32_t)a.k.ref_points) % (uint32_t)a.k.ref_points;
-        a.st.ctr[i] = ctr_pack(s_new, ctr_sign(c), off, ctr_lat(c));
+        a.st.ctr[i] = ctr_pack(s_new, ctr_sign(c), off, ctr_lat(c)) | (c & kCtrOhBit);
       }
       else ui[i] = (int32_t)ctr_step(c);
       break;
     case PDS_F_QUAT_SIGN:
-      if (a.set) a.st.ctr[i] = ctr_pack(ctr_step(c), ui[i] ? 1u : 0u, ctr_off(c), ctr_lat(c));
+      if (a.set) a.st.ctr[i] = ctr_pack(ctr_step(c), ui[i] ? 1u : 0u, ctr_off(c), ctr_lat(c)) | (c & kCtrOhBit);
       else ui[i] = (int32_t)ctr_sign(c);
       break;
     case PDS_F_REF_OFFSET:
       if (a.task == PDS_TASK_CIRCLE) {
         const uint32_t P = (uint32_t)a.k.ref_points;
-        if (a.set) a.st.ctr[i] = ctr_pack(ctr_step(c), ctr_sign(c), ((uint32_t)ui[i] % P + ctr_step(c) % P) % P, ctr_lat(c));
+        if (a.set) a.st.ctr[i] = ctr_pack(ctr_step(c), ctr_sign(c), ((uint32_t)ui[i] % P + ctr_step(c) % P) % P, ctr_lat(c)) | (c & kCtrOhBit);
         else ui[i] = (int32_t)circle_ref_offset(c, a.k.ref_points);
       } else if (!a.set) {
         ui[i] = 0;
@@ -133,6 +136,17 @@ __global__ __launch_bounds__(kBlock) void field_kernel(const FieldArgs a) {
           a.st.oh0[i] = make_float4(uf[10 * i], uf[10 * i + 1], uf[10 * i + 2], uf[10 * i + 3]);
           a.st.oh1[i] = make_float4(uf[10 * i + 4], uf[10 * i + 5], uf[10 * i + 6], uf[10 * i + 7]);
           a.st.oh2[i] = make_float2(uf[10 * i + 8], uf[10 * i + 9]);
+          if (a.regen_obs) a.st.ctr[i] = c | kCtrOhBit;  // from now on it is what the next step reads
+        } else if (a.regen_obs && !ctr_oh(c)) {
+          // not in memory: what the next step will regenerate (csrc/pds_reset.h regen_kept_obs), from the same inputs
+          const WaveClock ck = a.st.clk[i / kWave];
+          const RngKey now{a.seed_lo, a.seed_hi, ck.x, ck.y};
+          const EnvRegs e{q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+          NoisyObs o;
+          regen_kept_obs(a.k, (uint32_t)(a.env_id_base + (unsigned long long)i), now, ctr_step(c) == 0u, e, o);
+          uf[10 * i] = o.x; uf[10 * i + 1] = o.y; uf[10 * i + 2] = o.z; uf[10 * i + 3] = o.qx;
+          uf[10 * i + 4] = o.qy; uf[10 * i + 5] = o.qz; uf[10 * i + 6] = o.qw; uf[10 * i + 7] = o.vx;
+          uf[10 * i + 8] = o.vy; uf[10 * i + 9] = o.vz;
         } else {
           const float4 o0 = a.st.oh0[i], o1 = a.st.oh1[i]; const float2 o2 = a.st.oh2[i];
           uf[10 * i] = o0.x; uf[10 * i + 1] = o0.y; uf[10 * i + 2] = o0.z; uf[10 * i + 3] = o0.w;
@@ -169,7 +183,7 @@ __global__ __launch_bounds__(kBlock) void field_kernel(const FieldArgs a) {
       }
       break;
     case PDS_F_ACTION_IDX:
-      if (a.set) a.st.ctr[i] = ctr_pack(ctr_step(c), ctr_sign(c), ctr_off(c), a.k.lat_steps > 0 ? (uint32_t)ui[i] % (uint32_t)a.k.lat_steps : 0u);
+      if (a.set) a.st.ctr[i] = ctr_pack(ctr_step(c), ctr_sign(c), ctr_off(c), a.k.lat_steps > 0 ? (uint32_t)ui[i] % (uint32_t)a.k.lat_steps : 0u) | (c & kCtrOhBit);
       else ui[i] = (int32_t)ctr_lat(c);
       break;
     default: break;
@@ -190,7 +204,7 @@ __global__ __launch_bounds__(256) void latency_clear_kernel(DevState st, long lo
   if (i >= n) return;
   for (int b = 0; b < rows; ++b) st.lat[(long long)b * n + i] = make_float4(0.f, 0.f, 0.f, 0.f);
   const uint32_t c = st.ctr[i];
-  st.ctr[i] = ctr_pack(ctr_step(c), ctr_sign(c), ctr_off(c), 0u);
+  st.ctr[i] = ctr_pack(ctr_step(c), ctr_sign(c), ctr_off(c), 0u) | (c & kCtrOhBit);
 }
 
 }  // namespace pds
@@ -634,7 +648,9 @@ extern "C" int pds_set_latency(pds_handle *h, double latency) {
 // read action 16 + dyn state 48 + action history 32 + counter 4; write dyn state 48
 // + newest history slot 16 + counter 4 + reward 4 + cost 4 + terminated 1 + truncated 1; obs 4*D;
 // DR params +24; motor PT1: x R+W 32 (+ A, K 32 when randomised); OU state R+W 32; gyro bias +
-// low-pass R+W 48; kept noisy observation (10 floats) R+W 80; latency ring: one row R+W per physics
+// low-pass R+W 48; kept noisy observation (10 floats) R+W 80 only with the Kalman hold (obs_rate > 1) -- otherwise it is
+// regenerated from the previous tick's Philox blocks, not kept (csrc/pds_reset.h regen_kept_obs; pds_step_with_variates
+// and the first step after an explicit reset still move those 80 B); latency ring: one row R+W per physics
 // sub-step.  (The per-tile clock word adds 0.5 B per env-step and is not counted.)
 extern "C" int pds_bytes_per_env_step(const pds_handle *h) {
   if (!h) return PDS_EINVAL;
@@ -644,7 +660,7 @@ extern "C" int pds_bytes_per_env_step(const pds_handle *h) {
   if (f.motor) b += 32;
   if (f.motor && f.dr) b += 32;
   if (f.tn) b += 32;
-  if (f.on) b += 48 + 80;
+  if (f.on) b += 48 + ((f.hold || !PDS_REGEN_OBS) ? 80 : 0);
   if (f.ctrl >= 1) b += 48;  // rate-PID integral + last error, R+W
   if (f.ctrl == 2) b += 48;  // attitude-PID integral + last error, R+W
   if (f.lat) b += 32 * h->cfg.aggregate_phy_steps;
@@ -829,6 +845,9 @@ extern "C" int pds_rollout(pds_handle *h, int T, const pds_mlp *pi, const pds_ml
     return fail(h, PDS_EINVAL, "pds_rollout: NULL pointer");
   if ((d_mean == nullptr) != (d_std == nullptr)) return fail(h, PDS_EINVAL, "pds_rollout: mean and std come together");
   if (!h->was_reset) return fail(h, PDS_EINVAL, "pds_rollout before pds_reset");
+  // the rollout bootstraps finished episodes from V(final_obs) and restarts them in place (roll_out of the reference
+  // calls env.reset() itself, algs/iwpg/iwpg.py:382-385): without auto-reset there is no final observation to evaluate
+  if (!h->cfg.auto_reset) return fail(h, PDS_EUNSUPPORTED, "pds_rollout needs a handle created with auto_reset = 1");
   const int D = h->obs_dim;
   for (const pds_mlp *m : {pi, vf})
     if (m->d_in != D || m->h1 < 1 || m->h1 > 64 || m->h2 < 1 || m->h2 > 64 || (m->activation != 0 && m->activation != 1) ||
@@ -854,7 +873,8 @@ extern "C" int pds_rollout(pds_handle *h, int T, const pds_mlp *pi, const pds_ml
   ra.obs0 = d_obs_buf;
   ra.act_buf = d_act_buf; ra.logp_buf = d_logp_buf; ra.val_buf = d_val_buf; ra.fval_buf = d_fval_buf; ra.last_val = d_last_val;
   ra.ep_ret = d_ep_ret; ra.ep_len = d_ep_len; ra.stats = d_stats;
-  const dim3 grid((unsigned)((n + kWave - 1) / kWave));
+  const long long tiles = (n + kWave - 1) / kWave;
+  const dim3 grid((unsigned)((tiles + kRolloutTiles - 1) / kRolloutTiles));  // one block per kRolloutTiles tiles
   bool ok;
   if (h->cfg.task == PDS_TASK_HOVER) ok = launch_rollout_hover(h->flags, grid, (hipStream_t)stream, ra);
   else if (h->cfg.task == PDS_TASK_CIRCLE) ok = launch_rollout_circle(h->flags, grid, (hipStream_t)stream, ra);
@@ -888,6 +908,9 @@ static int do_field(pds_handle *h, int field, void *d_ptr, int set, void *stream
   memset(&a, 0, sizeof(a));
   a.st = h->st; a.k = h->k; a.user = d_ptr; a.n = h->cfg.num_envs; a.field = field; a.task = h->cfg.task; a.set = set;
   a.has_motor = h->flags.motor; a.has_dr = h->flags.dr; a.has_tn = h->flags.tn; a.has_on = h->flags.on; a.ctrl = h->flags.ctrl;
+  a.regen_obs = PDS_REGEN_OBS && h->flags.on && !h->flags.hold;
+  a.env_id_base = (unsigned long long)h->cfg.env_id_base;
+  a.seed_lo = (uint32_t)h->cfg.seed; a.seed_hi = (uint32_t)(h->cfg.seed >> 32);
   const dim3 grid((unsigned)((a.n + kBlock - 1) / kBlock));
   hipLaunchKernelGGL(field_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, a);
   PDS_HIP(h, hipGetLastError());

@@ -254,6 +254,27 @@ PDS_DEV void sensor_observe(const Consts &k, const EnvRegs &e, const ObsNoise &n
   o.vx = vn[0]; o.vy = vn[1]; o.vz = vn[2];
 }
 
+// The noisy observation o(k) that the previous env.step (or the reset) returned, REGENERATED instead of kept in
+// memory (observation-noise variants without the Kalman hold): its position / attitude / velocity part is a pure
+// function of the true state the env had then -- which is the state the next step loads -- and of the standard
+// variates of that call, which are Philox blocks of the PREVIOUS tick: kBlkObsNoise.. for a step, the second
+// add_noise call of the reset (kBlkResetNoise + 3..5) when the env was reset in that tick (step counter == 0).  Same
+// device functions, same inputs => the same bits the previous launch wrote into the second half of its row.  (The
+// filtered gyro of o(k) is the low-pass state, which stays in memory.)  ~400 vector instructions per 64 envs for 80 B
+// per env-step less traffic: Hover 2^20 noise + DR 85.7 -> 79.9 us (profiles/r04_ab_regen.txt).
+PDS_DEV void regen_kept_obs(const Consts &k, uint32_t env_id, const RngKey &now, bool after_reset, const EnvRegs &e,
+                            NoisyObs &o) {
+  RngKey prev = now;
+  prev.tick_lo = now.tick_lo - 1u;
+  if (now.tick_lo == 0u) prev.tick_hi = now.tick_hi - 1u;
+  ObsNoise n;
+  obs_noise_philox(env_id, prev, after_reset ? kBlkResetNoise + (uint32_t)kObsCallBlocks : kBlkObsNoise, n);
+  NoiseState unused;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { unused.bias[j] = 0.f; unused.lpf[j] = 0.f; }
+  sensor_observe(k, e, n, unused, o);  // (its gyro part is dead code here)
+}
+
 // ---- observation rows ---------------------------------------------------------------------------
 // noise-free o (envs/agents.py:339-348 get_state; envs/circle.py:173-177; envs/takeoff.py:146-147)
 template <int TASK>
@@ -465,7 +486,7 @@ PDS_DEV void reset_store(const StepArgs &a, const float2 *ref_lds, long long i, 
   a.st.s2[i] = make_float4(e.yaw, e.wx, e.wy, e.wz);
   a.st.hist[0][i] = r.u0;
   a.st.hist[1][i] = r.u0;
-  a.st.ctr[i] = r.ctr;
+  a.st.ctr[i] = V::ON ? (r.ctr | kCtrOhBit) : r.ctr;  // (ON: the kept observation is written below, not regenerated)
   if (a.st.pid0 != nullptr) {  // control.reset(): envs/agents.py:379, envs/control.py:178-187, 279-287
     a.st.pid0[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     a.st.pid1[i] = make_float2(0.f, 0.f);
@@ -530,9 +551,12 @@ constexpr int kResetsPerPass = kWave / kLanesPerReset;
 
 // Philox blocks of up to kResetsPerPass queued envs (lane ids in bits 0..5 of entries[0..cnt)), computed L lanes
 // per env into `scratch` (LdsWords layout, slot s = entry s).  Wave-uniform control flow; the caller fences.
-template <class V>
+// STRIDE: U4 slots per env in `scratch` (>= scratch_blocks_used<V>(): the drain lays its scratch over the free tile with
+// kScratchBlocks, the in-register resets size theirs with the blocks the variant really uses)
+template <class V, int STRIDE = kScratchBlocks>
 PDS_DEV void fill_reset_scratch(const StepArgs &a, const RngKey &rk, const uint32_t *entries, int cnt, int lane,
                                 long long wave_base, U4 *scratch) {
+  static_assert(STRIDE >= scratch_blocks_used<V>(), "scratch slots per env");
   constexpr int NB = scratch_blocks_used<V>();
   constexpr int L = NB <= 8 ? 8 : (NB <= 16 ? 16 : 32);  // lanes per env in a Philox round
   constexpr int EPR = kWave / L;                           // envs per Philox round
@@ -547,7 +571,7 @@ PDS_DEV void fill_reset_scratch(const StepArgs &a, const RngKey &rk, const uint3
     bool need = false;
 #pragma unroll
     for (int c = 0; c < NB; ++c) need = need || (c == j && block_needed<V>(c));
-    if (on && need) scratch[slot * kScratchBlocks + j] = dw.scratch_block(j);
+    if (on && need) scratch[slot * STRIDE + j] = dw.scratch_block(j);
   }
 }
 

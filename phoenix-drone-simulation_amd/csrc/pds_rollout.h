@@ -1,20 +1,35 @@
 // pds_rollout.h -- ONE launch per rollout (gfx950): the T closed-loop steps
 //     o -> standardise -> actor MLP -> a = mu + sigma z, log p -> critic V(o) -> env.step(a) -> buffers
-// of the caller's roll_out (algs/iwpg/iwpg.py:350-385, ActorCritic.step algs/core.py:370-393) for a 64-env tile
-// per 256-thread block, the env state in registers for the whole rollout (like pds_step_k), the observation tile in
-// LDS between the env step and the networks, both networks' weights in LDS.
+// of the caller's roll_out (algs/iwpg/iwpg.py:350-385, ActorCritic.step algs/core.py:370-393), the env state in
+// registers for the whole rollout (like pds_step_k), the observation tile in LDS between the env step and the
+// networks, both networks' weights in LDS.
 //
 // Round 2 ran a rollout step as 7 launches (critic, actor, sample, env step, V(final_obs), record, + copies), replayed
 // from a hipGraph: 63 us per step at 8 192 envs, i.e. launch-bound (the env step itself is 7 us).
-// Here a block's four waves split the two network passes of its 64 envs (16 samples each on
-// v_mfma_f32_16x16x4_f32, csrc/pds_mlp_fwd.h: the code path of pds_mlp_forward, same bits), wave 0 then steps the 64
-// envs (step_once of csrc/pds_step.h: the code path of pds_step / pds_step_k, same bits), and the waves whose rows
-// hold a finished env evaluate V(final_obs) for the TimeLimit bootstrap (algs/iwpg/iwpg.py:375-385) out of an
-// LDS copy of those rows.  Two block barriers per step; no tensor of the step round-trips through HBM except
-// the rollout buffers themselves.
+// Round 3 gave every 64-env tile one 256-thread block whose four waves ran the networks, then WAITED while wave 0
+// stepped the envs, then evaluated V(final_obs): 17 us per step, 7.5 of them one wave's env step with three waves idle
+// at the barrier, and one tile per CU (101 KB of LDS, most of it the two weight images).
+//
+// Round 4 -- wave roles, no block barrier inside the loop.  A 384-thread block serves TWO tiles with ONE copy of the
+// weights:
+//   M0..M3 (network waves, 16 rows of EACH tile, v_mfma_f32_16x16x4_f32 through csrc/pds_mlp_fwd.h -- the code path of
+//           pds_mlp_forward, same bits):   per tile: wait for o(t) -> read their rows into registers -> actor -> sample ->
+//           action into LDS, SIGNAL; then, for both tiles, the critic V(o(t)) and V(final_obs) of the envs that
+//           finished in step t - 1;
+//   E0, E1 (one env wave per tile, its 64 envs in registers, step_once of csrc/pds_step.h -- the code path of pds_step /
+//           pds_step_k, same bits):        wait for the four action signals -> env.step -> o(t + 1), the finished
+//           envs' last rows and flags into LDS, SIGNAL.
+// Only the actor is on the critical path of a step (action -> env step -> next observation): the critic, the
+// TimeLimit bootstrap V(final_obs) (algs/iwpg/iwpg.py:375-385) and all buffer writes of the network waves run while
+// the env waves step.  Six waves per block leave every wave 256 registers (the env step of the noise variants needs
+// ~250; a first version with five waves per tile, ten per block, was capped at 168 and spilled 37-56 registers inside
+// the step: 21.7 us per step against 17.7 for round 3's kernel).  Hand-over through monotonic counters in LDS
+// (release / acquire, s_sleep loop; all six waves of a block are resident together, so the waits cannot deadlock);
+// every LDS image has exactly one writer role, and every reader finishes with it before it posts the signal its
+// writer waits for.
 //
 // Envs are independent, the policy is frozen during a rollout and the running observation statistics are only
-// updated after it (ppo.py), so a block needs nothing from another block for all T steps.
+// updated after it (ppo.py), so a tile needs nothing from another tile for all T steps.
 #pragma once
 #include "pds_mlp_fwd.h"
 #include "pds_step.h"
@@ -22,9 +37,10 @@
 namespace pds {
 
 #ifndef PDS_ROLLOUT_SKIP
-#define PDS_ROLLOUT_SKIP 0  // profiling builds only: 1 = no network passes, 2 = no env step, 4 = no V(final_obs)
+#define PDS_ROLLOUT_SKIP 0  // profiling builds only: 1 = no actor / critic passes, 2 = no env step, 4 = no V(final_obs)
 #endif
-constexpr int kRolloutThreads = 256;
+constexpr int kRolloutMlpWaves = 4;               // network waves per block (16 rows of every tile each)
+constexpr int kRolloutThreads = kWave * (kRolloutMlpWaves + kRolloutTiles);  // + one env wave per tile
 
 // network input of this lane: features 16 kt + 4 g + q of row `r` of an LDS image with row stride `stride`
 template <int NIN>
@@ -43,6 +59,16 @@ PDS_DEV void gather_input(const float *img, int stride, int r, int d_in, const f
   }
 }
 
+// hand-over counters (LDS, monotonic)
+PDS_DEV void rollout_wait_ge(int *flag, int need) {
+  while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < need)
+    __builtin_amdgcn_s_sleep(1);
+}
+PDS_DEV void rollout_post(int *flag, int lane) {  // +1, after every lane's LDS accesses of this phase
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 template <class V>
 __global__ __launch_bounds__(kRolloutThreads, 1) void rollout_kernel(const RolloutArgs ra) {
   using namespace pds_mlpf;
@@ -50,17 +76,18 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void rollout_kernel(const Rollo
   constexpr int TS = tile_stride<D>();
   constexpr int NIN = (D + 15) / 16;
   constexpr int RM = merged_reset_variant<V>() ? RM_MERGED : RM_INLINE;
-  constexpr int kScratchU4_ = (RM == RM_MERGED) ? kMergedScratchU4 : (inline_coop_variant<V>() ? inline_envs_per_pass<V>() * kScratchBlocks : 0);
+  constexpr int kScratchU4_ = (RM == RM_MERGED) ? kMergedScratchU4 : (inline_coop_variant<V>() ? inline_envs_per_pass<V>() * scratch_stride<V>() : 0);
   static_assert(D <= 64, "network input <= 64 features");
   __shared__ __attribute__((aligned(16))) float net_pi[kNetFloats];
   __shared__ __attribute__((aligned(16))) float net_vf[kNetFloats];
   __shared__ __attribute__((aligned(16))) float mus[64], iss[64];
-  __shared__ __attribute__((aligned(16))) float tile[kWave * TS];
-  __shared__ __attribute__((aligned(16))) float fin[kWave * D];
-  __shared__ __attribute__((aligned(16))) float4 act_lds[kWave];
-  __shared__ uint32_t done_lds[kWave];
-  __shared__ uint32_t queue[kQueueCap];
-  __shared__ U4 scratch_all[kScratchU4_ > 0 ? kScratchU4_ : 1];
+  __shared__ __attribute__((aligned(16))) float tile_all[kRolloutTiles][kWave * TS];
+  __shared__ __attribute__((aligned(16))) float fin_all[kRolloutTiles][kWave * D];
+  __shared__ __attribute__((aligned(16))) float4 act_all[kRolloutTiles][kWave];
+  __shared__ uint32_t done_all[kRolloutTiles][kWave];
+  __shared__ uint32_t queue_all[kRolloutTiles][kQueueCap];
+  __shared__ U4 scratch_all[kRolloutTiles][kScratchU4_ > 0 ? kScratchU4_ : 1];
+  __shared__ int obs_ready[kRolloutTiles], act_ready[kRolloutTiles];
 #ifdef PDS_STAMPS
   unsigned long long stamp_[kStampSlots];
 #endif
@@ -69,18 +96,21 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void rollout_kernel(const Rollo
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool is_env = wave >= kRolloutMlpWaves;
   const int n16 = lane & 15, g = lane >> 4;
   const NetLds wpi = net_lds(net_pi), wvf = net_lds(net_vf);
-  const long long t = blockIdx.x;  // one 64-env tile per block
-  const long long wave_base = t * kWave;
-  const long long rem_ = a.n - wave_base;
-  const bool active = rem_ >= kWave || lane < (int)rem_;
-  const EnvIdx ix{wave_base, active ? (uint32_t)lane : (uint32_t)rem_ - 1u};
-  const int rows = rem_ >= kWave ? kWave : (int)rem_;  // envs of this tile
+  const long long ntiles = (a.n + kWave - 1) / kWave;
+  const long long tile0 = (long long)blockIdx.x * kRolloutTiles;  // first 64-env tile of this block
   const int T = ra.T;
   const int d_out = ra.pi.d_out;
+  auto tile_rows = [&](int j) -> int {  // envs of tile j of this block (0: the last block of an odd tile count)
+    const long long tt = tile0 + j;
+    if (tt >= ntiles) return 0;
+    const long long rem = a.n - tt * kWave;
+    return rem >= kWave ? kWave : (int)rem;
+  };
 
-  // ---- prologue: networks, statistics and o(0) into LDS; env state into wave 0's registers ---------------
+  // ---- prologue: networks, statistics and o(0) into LDS; env state into the env waves' registers --------------
   stage_net(ra.pi, wpi, tid, kRolloutThreads);
   stage_net(ra.vf, wvf, tid, kRolloutThreads);
   if (tid < 64) {
@@ -88,118 +118,148 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void rollout_kernel(const Rollo
     mus[tid] = on ? ra.mean[tid] : 0.f;
     iss[tid] = on ? 1.0f / (ra.stdv[tid] + ra.eps) : 1.f;
   }
-  for (int idx = tid; idx < kWave * D; idx += kRolloutThreads) {
-    const int r = idx / D, c = idx - r * D;
-    tile[r * TS + c] = (r < rows) ? ra.obs0[(wave_base + r) * D + c] : 0.f;
+  if (tid < kRolloutTiles) { obs_ready[tid] = 0; act_ready[tid] = 0; }
+#pragma unroll
+  for (int j = 0; j < kRolloutTiles; ++j) {
+    const int rows = tile_rows(j);
+    for (int idx = tid; idx < kWave * D; idx += kRolloutThreads) {
+      const int r = idx / D, c = idx - r * D;
+      tile_all[j][r * TS + c] = (r < rows) ? ra.obs0[((tile0 + j) * kWave + r) * D + c] : 0.f;
+    }
+    if (tid < kWave) done_all[j][tid] = 0u;
   }
-  Loaded cur;
-  RngKey rk{a.seed_lo, a.seed_hi, 0u, 0u};
-  int parity = 0;
-  EnvState S;
-  float ep_ret = 0.f, ep_len = 0.f, st0 = 0.f, st1 = 0.f, st2 = 0.f;
-  if (wave == 0) {
+  unsigned long long call0 = ra.call_offset;
+  if (ra.call_base != nullptr) call0 += *ra.call_base;
+  __syncthreads();  // (the only block barrier: from here on the roles meet through the counters)
+
+  if (is_env) {
+    // ================================ env wave: one tile's 64 envs in registers =================================
+    const int grp = wave - kRolloutMlpWaves;
+    const long long t = tile0 + grp;
+    if (t >= ntiles) return;
+    const long long wave_base = t * kWave;
+    const long long rem_ = a.n - wave_base;
+    const bool active = rem_ >= kWave || lane < (int)rem_;
+    const Idx<V> ix{wave_base, active ? (uint32_t)lane : (uint32_t)rem_ - 1u};
+    float *tile = tile_all[grp], *fin = fin_all[grp];
+    Loaded cur;
+    RngKey rk{a.seed_lo, a.seed_hi, 0u, 0u};
     load_env<V>(a, ix, t, cur);
     rk.tick_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.clk.x);
     rk.tick_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.clk.y);
-    parity = __builtin_amdgcn_readfirstlane((int)cur.clk.z) & 1;
+    int parity = __builtin_amdgcn_readfirstlane((int)cur.clk.z) & 1;
+    const RngKey rk0 = rk;
+    EnvState S;
     unpack_state<V>(a.k, cur, parity, S);
-    ep_ret = *at(ra.ep_ret, ix);
-    ep_len = *at(ra.ep_len, ix);
+    init_kept_obs<V>(a, rk, ix, S);
+    float ep_ret = *at(ra.ep_ret, ix), ep_len = *at(ra.ep_len, ix), st0 = 0.f, st1 = 0.f, st2 = 0.f;
+    int qcount = 0;
+    for (int s = 0; s < T; ++s) {
+      const RolloutArgs &rl = *reinterpret_cast<const RolloutArgs *>(&reload_args<201, true>(ra.s, s));
+      const long long o1 = (long long)s * rl.s.n;
+      rollout_wait_ge(&act_ready[grp], kRolloutMlpWaves * (s + 1));  // the network waves have read o(s) and written a(s)
+      if (!(PDS_ROLLOUT_SKIP & 2)) {
+        const float4 act = act_all[grp][lane];
+        StepOut so;
+        step_once<V, kWave, RM, false>(rl.s, o1, rk, parity, nullptr, tile, nullptr, queue_all[grp], scratch_all[grp], lane,
+                                       wave_base, ix, active, act, S, qcount, fin, &so PDS_STAMP_ARG);
+        parity ^= 1;
+        rk.tick_lo += 1u;
+        if (rk.tick_lo == 0u) rk.tick_hi += 1u;
+        // pds_rollout_record (csrc/pds_train.hip record_kernel)
+        const bool dn = (so.done || so.trunc) && active;
+        const float er = ep_ret + so.reward, el = ep_len + 1.f;
+        if (dn) { st0 += er; st1 += el; st2 += 1.f; }
+        ep_ret = dn ? 0.f : er;
+        ep_len = dn ? 0.f : el;
+        done_all[grp][lane] = dn ? 1u : 0u;
+      }
+      rollout_post(&obs_ready[grp], lane);  // o(s + 1) in the tile, the finished envs' last rows in `fin`, flags
+    }
+    const RolloutArgs &rl = *reinterpret_cast<const RolloutArgs *>(&reload_args<202, true>(ra.s, T));
+    if (active) {
+      store_state<V>(rl.s, ix, parity, S, true);
+      *at(rl.ep_ret, ix) = ep_ret;
+      *at(rl.ep_len, ix) = ep_len;
+    }
+    advance_clock(rl.s.st.clk, t, rk0, parity, (uint32_t)T, lane);
+    for (int d = 32; d >= 1; d >>= 1) { st0 += __shfl_xor(st0, d); st1 += __shfl_xor(st1, d); st2 += __shfl_xor(st2, d); }
+    if (lane == 0 && st2 != 0.f) {
+      atomicAdd(rl.stats + 0, st0);
+      atomicAdd(rl.stats + 1, st1);
+      atomicAdd(rl.stats + 2, st2);
+    }
+    return;
   }
-  const RngKey rk0 = rk;
-  unsigned long long call0 = ra.call_offset;
-  if (ra.call_base != nullptr) call0 += *ra.call_base;
-  __syncthreads();
 
-  const int r16 = wave * 16 + n16;             // this lane's sample row in the tile (network phases)
-  const bool row_ok = r16 < rows;
-  const long long env16 = wave_base + r16;     // its env
-  int qcount = 0;
-  for (int s = 0; s < T; ++s) {
-    const RolloutArgs &rl = *reinterpret_cast<const RolloutArgs *>(&reload_args<201, true>(s));
+  // ================================ network waves: 16 rows of every tile each ==================================
+  const int r16 = wave * 16 + n16;  // this lane's sample row in the tiles
+  for (int s = 0; s <= T; ++s) {  // s == T: only V(o(T)) and the last step's V(final_obs)
+    const RolloutArgs &rl = *reinterpret_cast<const RolloutArgs *>(&reload_args<203, true>(ra.s, s));
     const long long o1 = (long long)s * rl.s.n;
-    // ---- networks on o(s): 16 samples per wave --------------------------------------------------------
-    if (!(PDS_ROLLOUT_SKIP & 1)) {
-      f32x4 xin[NIN];
-      gather_input<NIN>(tile, TS, r16, D, mus, iss, g, xin);
-      const f32x4 v = (rl.vf.activation == 0) ? forward16<0, NIN>(wvf, xin, n16, g) : forward16<1, NIN>(wvf, xin, n16, g);
-      const f32x4 mu = (rl.pi.activation == 0) ? forward16<0, NIN>(wpi, xin, n16, g) : forward16<1, NIN>(wpi, xin, n16, g);
-      if (g == 0) {  // lane n16 owns sample r16: outputs 0..3 of the actor, output 0 of the critic
-        // pds_gaussian_sample (csrc/pds_train.hip sample_kernel): counter = (sample id lo, id hi << 8 | block, call lo, call hi)
-        float z[4] = {0.f, 0.f, 0.f, 0.f};
-        if (!rl.deterministic) {
-          const unsigned long long gid = rl.s.env_id_base + (unsigned long long)env16;
-          const unsigned long long call = call0 + (unsigned long long)s + 1ull;
-          const U4 r = philox4x32_10((uint32_t)gid, ((uint32_t)(gid >> 32) << 8) | 0u, (uint32_t)call, (uint32_t)(call >> 32),
-                                     (uint32_t)rl.seed, (uint32_t)(rl.seed >> 32));
-          box_muller(r.x, r.y, z[0], z[1]);
-          box_muller(r.z, r.w, z[2], z[3]);
-        }
-        float av[4], lp = 0.f;
+    f32x4 xin[kRolloutTiles][NIN], xfin[kRolloutTiles][NIN];
+    bool dn[kRolloutTiles], any_dn[kRolloutTiles];
+    // ---- the critical path first: both tiles' actions -------------------------------------------------------
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float ls = (j < d_out) ? rl.log_std[j] : 0.f;
-          av[j] = fmaf(expf(ls), z[j], mu[j]);
-          if (j < d_out) lp += -0.5f * z[j] * z[j] - ls - 0.91893853320467274178f;
+    for (int j = 0; j < kRolloutTiles; ++j) {
+      const int rows = tile_rows(j);  // wave-uniform
+      dn[j] = false; any_dn[j] = false;
+      if (rows == 0) continue;
+      const bool row_ok = r16 < rows;
+      const long long env16 = (tile0 + j) * kWave + r16;
+      rollout_wait_ge(&obs_ready[j], s);  // o(s) and the outcome of step s - 1 are in LDS
+      gather_input<NIN>(tile_all[j], TS, r16, D, mus, iss, g, xin[j]);
+      dn[j] = done_all[j][r16] != 0u;                                            // (step s - 1; zeros before the first step)
+      any_dn[j] = __ballot(dn[j]) != 0ull && !(PDS_ROLLOUT_SKIP & 4);            // wave-uniform: one of this wave's 16 envs finished
+      if (any_dn[j]) gather_input<NIN>(fin_all[j], D, r16, D, mus, iss, g, xfin[j]);
+      if (s == T) continue;
+      if (!(PDS_ROLLOUT_SKIP & 1)) {
+        const f32x4 mu = (rl.pi.activation == 0) ? forward16<0, NIN>(wpi, xin[j], n16, g) : forward16<1, NIN>(wpi, xin[j], n16, g);
+        if (g == 0) {  // lane n16 owns sample r16: outputs 0..3 of the actor
+          // pds_gaussian_sample (csrc/pds_train.hip sample_kernel): counter = (sample id lo, id hi << 8 | block, call lo, call hi)
+          float z[4] = {0.f, 0.f, 0.f, 0.f};
+          if (!rl.deterministic) {
+            const unsigned long long gid = rl.s.env_id_base + (unsigned long long)env16;
+            const unsigned long long call = call0 + (unsigned long long)s + 1ull;
+            const U4 r = philox4x32_10((uint32_t)gid, ((uint32_t)(gid >> 32) << 8) | 0u, (uint32_t)call, (uint32_t)(call >> 32),
+                                       (uint32_t)rl.seed, (uint32_t)(rl.seed >> 32));
+            box_muller(r.x, r.y, z[0], z[1]);
+            box_muller(r.z, r.w, z[2], z[3]);
+          }
+          float av[4], lp = 0.f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float ls = (q < d_out) ? rl.log_std[q] : 0.f;
+            av[q] = fmaf(expf(ls), z[q], mu[q]);
+            if (q < d_out) lp += -0.5f * z[q] * z[q] - ls - 0.91893853320467274178f;
+          }
+          act_all[j][r16] = make_float4(av[0], av[1], av[2], av[3]);
+          if (row_ok) {
+            *reinterpret_cast<float4 *>(rl.act_buf + (o1 + env16) * 4) = make_float4(av[0], av[1], av[2], av[3]);
+            rl.logp_buf[o1 + env16] = lp;
+          }
         }
-        act_lds[r16] = make_float4(av[0], av[1], av[2], av[3]);
-        if (row_ok) {
-          *reinterpret_cast<float4 *>(rl.act_buf + (o1 + env16) * 4) = make_float4(av[0], av[1], av[2], av[3]);
-          rl.logp_buf[o1 + env16] = lp;
-          rl.val_buf[o1 + env16] = v[0];
+      }
+      rollout_post(&act_ready[j], lane);  // this wave is done with tile j, its `fin` and its flags of step s - 1
+    }
+    // ---- off the critical path: the env waves are stepping --------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < kRolloutTiles; ++j) {
+      const int rows = tile_rows(j);
+      if (rows == 0) continue;
+      const bool row_ok = r16 < rows;
+      const long long env16 = (tile0 + j) * kWave + r16;
+      if (!(PDS_ROLLOUT_SKIP & 1)) {
+        const f32x4 v = (rl.vf.activation == 0) ? forward16<0, NIN>(wvf, xin[j], n16, g) : forward16<1, NIN>(wvf, xin[j], n16, g);
+        if (g == 0 && row_ok) {
+          if (s < T) rl.val_buf[o1 + env16] = v[0];
+          else rl.last_val[env16] = v[0];
         }
       }
-    }
-    __syncthreads();  // actions in LDS; every wave is done reading the tile
-    // ---- env.step by wave 0 (state in registers) --------------------------------------------------------
-    if (wave == 0 && !(PDS_ROLLOUT_SKIP & 2)) {
-      const float4 act = act_lds[lane];
-      StepOut so;
-      step_once<V, kWave, RM, false>(rl.s, o1, rk, parity, nullptr, tile, nullptr, queue, scratch_all, lane, wave_base, ix, active, act,
-                                     S, qcount, fin, &so PDS_STAMP_ARG);
-      parity ^= 1;
-      rk.tick_lo += 1u;
-      if (rk.tick_lo == 0u) rk.tick_hi += 1u;
-      // pds_rollout_record (csrc/pds_train.hip record_kernel)
-      const bool dn = (so.done || so.trunc) && active;
-      const float er = ep_ret + so.reward, el = ep_len + 1.f;
-      if (dn) { st0 += er; st1 += el; st2 += 1.f; }
-      ep_ret = dn ? 0.f : er;
-      ep_len = dn ? 0.f : el;
-      done_lds[lane] = dn ? 1u : 0u;
-    }
-    __syncthreads();  // o(s + 1) in the tile, the finished envs' last rows in `fin`
-    // ---- V(final_obs) where an env finished (the other rows of fval_buf are never read: pds_gae) -----
-    if (!(PDS_ROLLOUT_SKIP & 4)) {
-      const bool dn = done_lds[r16] != 0u;
-      if (__ballot(dn) != 0ull) {  // wave-uniform: one of this wave's 16 envs finished
-        f32x4 xin[NIN];
-        gather_input<NIN>(fin, D, r16, D, mus, iss, g, xin);
-        const f32x4 v = (rl.vf.activation == 0) ? forward16<0, NIN>(wvf, xin, n16, g) : forward16<1, NIN>(wvf, xin, n16, g);
-        if (g == 0 && dn && row_ok) rl.fval_buf[o1 + env16] = v[0];
-      }
-    }
-    // (no barrier: `fin` / done_lds are rewritten by wave 0 only after the next step's first barrier)
-  }
-  // ---- epilogue: V(o(T)), env state and episode bookkeeping back to HBM -----------------------------------
-  {
-    const RolloutArgs &rl = *reinterpret_cast<const RolloutArgs *>(&reload_args<202, true>(T));
-    f32x4 xin[NIN];
-    gather_input<NIN>(tile, TS, r16, D, mus, iss, g, xin);
-    const f32x4 v = (rl.vf.activation == 0) ? forward16<0, NIN>(wvf, xin, n16, g) : forward16<1, NIN>(wvf, xin, n16, g);
-    if (g == 0 && row_ok) rl.last_val[env16] = v[0];
-    if (wave == 0) {
-      if (active) {
-        store_state<V>(rl.s, ix, parity, S, true);
-        *at(rl.ep_ret, ix) = ep_ret;
-        *at(rl.ep_len, ix) = ep_len;
-      }
-      advance_clock(rl.s.st.clk, t, rk0, parity, (uint32_t)T, lane);
-      for (int d = 32; d >= 1; d >>= 1) { st0 += __shfl_xor(st0, d); st1 += __shfl_xor(st1, d); st2 += __shfl_xor(st2, d); }
-      if (lane == 0 && st2 != 0.f) {
-        atomicAdd(rl.stats + 0, st0);
-        atomicAdd(rl.stats + 1, st1);
-        atomicAdd(rl.stats + 2, st2);
+      // V(final_obs) where an env finished in step s - 1 (the other rows of fval_buf are never read: pds_gae)
+      if (any_dn[j]) {
+        const f32x4 v = (rl.vf.activation == 0) ? forward16<0, NIN>(wvf, xfin[j], n16, g) : forward16<1, NIN>(wvf, xfin[j], n16, g);
+        if (g == 0 && dn[j] && row_ok) rl.fval_buf[o1 - rl.s.n + env16] = v[0];
       }
     }
   }

@@ -46,8 +46,36 @@ PDS_DEV void lds_store_row(float *dst, const float *src) {  // dst 16-byte align
     reinterpret_cast<float4 *>(dst)[j] = make_float4(src[4 * j], src[4 * j + 1], src[4 * j + 2], src[4 * j + 3]);
 }
 
+// Variants whose kernel arguments do not fit the SGPR file for the whole step: they re-read them (reload_args).
+template <class V>
+constexpr bool heavy_variant() { return V::MOTOR || V::DR || V::TN || V::ON || V::CTRL != 0 || V::LAT; }
+
+// Addressing form and half-tile staging are per-variant traits (round 4).  Round 3 moved every variant to the SADDR
+// form + a half tile that parks the first row half in LDS; both exist to get the heavy variants under their
+// register caps (SGPR spills, the merged reset of PT1 + DR on the half tile).  The lean variants had no spill to
+// remove and paid for it: same box, round-2 vs round-3 library, headline 55.6 -> 56.1 us, Hover 65 536 (half tile)
+// 6.98 -> 7.2 us, TakeOff + ground effect 57.8 -> 58.5 us (profiles/r03_ab_final_vs_round2.txt).  They keep the
+// round-2 forms: 64-bit per-lane addresses, and on the half tile the whole row in registers until its pass.
+#ifndef PDS_SADDR_LEAN
+#define PDS_SADDR_LEAN 0  // A/B: 1 = round-3 form for every variant
+#endif
+template <class V>
+constexpr bool saddr_variant() { return PDS_SADDR_LEAN || heavy_variant<V>(); }
+template <class V>
+constexpr bool park_variant() { return PDS_SADDR_LEAN || heavy_variant<V>(); }
+template <class V>
+using Idx = EnvIdxT<saddr_variant<V>()>;
+
+// Observation-noise variants without the Kalman hold do not keep the noisy o(k) in memory: it is regenerated
+// (regen_kept_obs, csrc/pds_reset.h) unless the env's counter word says it was stored (kCtrOhBit; PDS_REGEN_OBS in pds_types.h).
+#ifndef PDS_EXP_REGEN
+#define PDS_EXP_REGEN 0  // timing experiments only: 1 = no flagged loads, 2 = no stores for injected variates (both: invalid results in those cases)
+#endif
+template <class V>
+constexpr bool regen_obs_variant() { return PDS_REGEN_OBS && V::ON && !V::HOLD; }
+
 // Wave-cooperative copy of this wave's [rows, D] LDS tile to global memory (contiguous region).
-template <int D, int TR>
+template <int D, int TR, bool SADDR>
 PDS_DEV void flush_tile(const float *tile, float *gdst, int rows, int lane) {
   constexpr int TS = tile_stride<D>();
   // (an [N, D] slice of a [K, N, D] tensor is only 8-byte aligned when N D is not a multiple of 4)
@@ -57,11 +85,19 @@ PDS_DEV void flush_tile(const float *tile, float *gdst, int rows, int lane) {
       constexpr int NV = TR * D / 4;  // float4 count (D is even, 32*D divisible by 4)
       const float4 *src = reinterpret_cast<const float4 *>(tile);
       float4 *dst = reinterpret_cast<float4 *>(gdst);
-      const uint32_t ln = fresh<1>((uint32_t)lane);
+      if constexpr (SADDR) {
+        const uint32_t ln = fresh<1>((uint32_t)lane);
 #pragma unroll
-      for (int it = 0; it < (NV + kWave - 1) / kWave; ++it) {
-        const int idx = it * kWave + lane;
-        if (idx < NV) nt_store4(lane_ptr(dst + it * kWave, ln), src[idx]);  // (uniform base + constant, lane offset)
+        for (int it = 0; it < (NV + kWave - 1) / kWave; ++it) {
+          const int idx = it * kWave + lane;
+          if (idx < NV) nt_store4(lane_ptr(dst + it * kWave, ln), src[idx]);  // (uniform base + constant, lane offset)
+        }
+      } else {
+#pragma unroll
+        for (int it = 0; it < (NV + kWave - 1) / kWave; ++it) {
+          const int idx = it * kWave + lane;
+          if (idx < NV) nt_store4(dst + idx, src[idx]);
+        }
       }
       return;
     }
@@ -72,7 +108,7 @@ PDS_DEV void flush_tile(const float *tile, float *gdst, int rows, int lane) {
       constexpr int Q = D / 4, RP = kWave / Q, NP = (TR + RP - 1) / RP;
       const int r0 = lane / Q, c = lane - r0 * Q;
       const float4 *src = reinterpret_cast<const float4 *>(tile + r0 * TS + 4 * c);
-      float4 *dst = lane_ptr(reinterpret_cast<float4 *>(gdst), fresh<2>((uint32_t)(r0 * Q + c)));
+      float4 *dst = lane_at<SADDR, 2>(reinterpret_cast<float4 *>(gdst), (uint32_t)(r0 * Q + c));
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         if (r0 < RP && p * RP + r0 < TR) nt_store4(dst + p * RP * Q, src[p * RP * (TS / 4)]);  // (+ compile-time constant: the instruction offset)
@@ -110,7 +146,7 @@ struct Loaded {
 // u(k-1) is decided by the parity bit of the wave's clock word, which arrives with the same batch of
 // loads -- no load address depends on another load.
 template <class V>
-PDS_DEV void load_env(const StepArgs &a, const EnvIdx ix, long long tile, Loaded &L) {
+PDS_DEV void load_env(const StepArgs &a, const Idx<V> ix, long long tile, Loaded &L) {
   constexpr int kOrder = PDS_ACT_LOAD_ORDER;
   if (kOrder == 0 || kOrder == 2) L.act = nt_load4(at(a.actions, ix));  // read once per step: keep it out of the caches
   if (kOrder == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -132,7 +168,7 @@ PDS_DEV void load_env(const StepArgs &a, const EnvIdx ix, long long tile, Loaded
   if (V::CTRL == 2) { L.pid2 = *at(a.st.pid2, ix); L.pid3 = *at(a.st.pid3, ix); }
   if (V::ON) {
     L.nz0 = *at(a.st.nz0, ix); L.nz1 = *at(a.st.nz1, ix);
-    L.oh0 = *at(a.st.oh0, ix); L.oh1 = *at(a.st.oh1, ix); L.oh2 = *at(a.st.oh2, ix);
+    if (!regen_obs_variant<V>()) { L.oh0 = *at(a.st.oh0, ix); L.oh1 = *at(a.st.oh1, ix); L.oh2 = *at(a.st.oh2, ix); }
   }
   if (kOrder == 1) L.act = nt_load4(at(a.actions, ix));
 }
@@ -174,8 +210,9 @@ PDS_DEV void unpack_state(const Consts &k, const Loaded &cur, int parity, EnvSta
   if (V::ON) {
     S.ns.bias[0] = cur.nz0.x; S.ns.bias[1] = cur.nz0.y; S.ns.bias[2] = cur.nz0.z;
     S.ns.lpf[0] = cur.nz0.w; S.ns.lpf[1] = cur.nz1.x; S.ns.lpf[2] = cur.nz1.y;
-    S.oh = NoisyObs{cur.oh0.x, cur.oh0.y, cur.oh0.z, cur.oh0.w, cur.oh1.x, cur.oh1.y, cur.oh1.z,
-                    cur.oh1.w, cur.oh2.x, cur.oh2.y};
+    if (!regen_obs_variant<V>())
+      S.oh = NoisyObs{cur.oh0.x, cur.oh0.y, cur.oh0.z, cur.oh0.w, cur.oh1.x, cur.oh1.y, cur.oh1.z,
+                      cur.oh1.w, cur.oh2.x, cur.oh2.y};
   }
 #pragma unroll
   for (int j = 0; j < 3; ++j) { S.ps.rate_int[j] = S.ps.rate_err[j] = S.ps.att_int[j] = S.ps.att_err[j] = 0.f; }
@@ -191,14 +228,32 @@ PDS_DEV void unpack_state(const Consts &k, const Loaded &cur, int parity, EnvSta
                 cur.q2.x, cur.q2.y, cur.q2.z, cur.q2.w};
 }
 
+// S.oh of a freshly loaded env (regen_obs_variant: see there): regenerated, or -- rarely: the first step after an
+// explicit reset, injected variates or pds_set_state -- read from oh0-2 by the lanes whose counter word says so.
+template <class V>
+PDS_DEV void init_kept_obs(const StepArgs &a, const RngKey &rk, const Idx<V> ix, EnvState &S) {
+  if constexpr (regen_obs_variant<V>()) {
+    const uint32_t env_id = (uint32_t)(a.env_id_base + (unsigned long long)ix.wb) + ix.lc;
+    regen_kept_obs(a.k, env_id, rk, ctr_step(S.ctr) == 0u, S.e, S.oh);
+    const bool stored = ctr_oh(S.ctr) != 0u;
+    if (!(PDS_EXP_REGEN & 1) && __ballot(stored) != 0ull) {  // wave-uniform
+      if (stored) {
+        const float4 o0 = *at(a.st.oh0, ix), o1 = *at(a.st.oh1, ix);
+        const float2 o2 = *at(a.st.oh2, ix);
+        S.oh = NoisyObs{o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w, o2.x, o2.y};
+      }
+    }
+  }
+}
+
 // Coalesced 16 B/lane stores of the env state.  `new_parity` = parity of the action ring AFTER the
 // stored step: slot new_parity holds u(k-1) = S.h1.  The single-step kernel leaves the other slot
 // alone (it already holds S.h2) unless the env was reset in registers (`both`); the K-step kernel
 // rewrites both slots and the randomised parameters.
 template <class V>
-PDS_DEV void store_state(const StepArgs &a, const EnvIdx i_, int new_parity, const EnvState &S, bool both) {
+PDS_DEV void store_state(const StepArgs &a, const Idx<V> i_, int new_parity, const EnvState &S, bool both) {
   const EnvRegs &e = S.e;
-  EnvIdx i = fresh<3>(i_);
+  Idx<V> i = fresh<3>(i_);
   st_store4(at(a.st.s0, i), make_float4(e.px, e.py, e.pz, e.vx));
   st_store4(at(a.st.s1, i), make_float4(e.vy, e.vz, e.roll, e.pitch));
   st_store4(at(a.st.s2, i), make_float4(e.yaw, e.wx, e.wy, e.wz));
@@ -217,9 +272,11 @@ PDS_DEV void store_state(const StepArgs &a, const EnvIdx i_, int new_parity, con
   if (V::ON) {
     *at(a.st.nz0, i) = make_float4(S.ns.bias[0], S.ns.bias[1], S.ns.bias[2], S.ns.lpf[0]);
     *at(a.st.nz1, i) = make_float2(S.ns.lpf[1], S.ns.lpf[2]);
-    *at(a.st.oh0, i) = make_float4(S.oh.x, S.oh.y, S.oh.z, S.oh.qx);
-    *at(a.st.oh1, i) = make_float4(S.oh.qy, S.oh.qz, S.oh.qw, S.oh.vx);
-    *at(a.st.oh2, i) = make_float2(S.oh.vy, S.oh.vz);
+    if (!regen_obs_variant<V>() || (!(PDS_EXP_REGEN & 2) && a.noise != nullptr)) {  // (injected variates cannot be replayed: S.ctr carries kCtrOhBit)
+      *at(a.st.oh0, i) = make_float4(S.oh.x, S.oh.y, S.oh.z, S.oh.qx);
+      *at(a.st.oh1, i) = make_float4(S.oh.qy, S.oh.qz, S.oh.qw, S.oh.vx);
+      *at(a.st.oh2, i) = make_float2(S.oh.vy, S.oh.vz);
+    }
   }
   if (both) {  // written only by resets (no write-after-write with this step's stores)
     i = fresh<4>(i_);
@@ -326,7 +383,7 @@ struct SubNoise {
 };
 
 template <class V>
-PDS_DEV void sub_noise(const StepArgs &a, const RngKey &rk, uint32_t env_id, const EnvIdx ix, int sub, SubNoise &n) {
+PDS_DEV void sub_noise(const StepArgs &a, const RngKey &rk, uint32_t env_id, const Idx<V> ix, int sub, SubNoise &n) {
   if (a.noise != nullptr) {  // injected (parity tests): one PDS_NOISE_FLOATS block per physics sub-step
     const float *p = a.noise + (ix.global() * a.k.agg + sub) * PDS_NOISE_FLOATS;
 #pragma unroll
@@ -385,10 +442,6 @@ PDS_DEV void sub_noise(const StepArgs &a, const RngKey &rk, uint32_t env_id, con
   }
 }
 
-// Variants whose kernel arguments do not fit the SGPR file for the whole step: they re-read them (reload_args).
-template <class V>
-constexpr bool heavy_variant() { return V::MOTOR || V::DR || V::TN || V::ON || V::CTRL != 0 || V::LAT; }
-
 // How an env that finished is reset inside the step (all three produce the same bits):
 //  RM_MERGED   before the wave stores, 8 lanes per finished env, results through ds_bpermute
 //              (reset_in_registers): state and observation leave through the ordinary coalesced stores;
@@ -426,9 +479,21 @@ constexpr bool inline_coop_variant() { return V::TASK != PDS_TASK_TAKEOFF; }
 // envs per pass: the scratch of the noise-free latency variants has to leave room for 3 blocks per CU
 template <class V>
 constexpr int inline_envs_per_pass() {
-  // 8 where the LDS budget of 3 blocks per CU allows it (Hover's 34-float noisy rows), 4 for the padded 40-float rows
-  // of Circle (8 cost it the third block per CU: 104.7 vs 91.8 us) and for the 22-block latency variants
-  return (V::ON && !V::LAT && tile_stride<V::D>() == V::D) ? kResetsPerPass : kResetsPerPass / 2;
+  // 4 envs per pass (a wave holds 1.3 finished envs on average when it holds any): round 3 used 8 for Hover's 34-float
+  // noisy rows because 3 blocks per CU still fitted; round 4 wants FOUR blocks per CU there (four_block_variant)
+  return kResetsPerPass / 2;
+}
+// U4 slots per env of the in-register resets' scratch: the blocks the variant uses (15 with observation noise, 22 with
+// the latency rows), not the 22 of the general layout
+template <class V>
+constexpr int scratch_stride() { return scratch_blocks_used<V>(); }
+// Hover with observation noise (D = 34: an 8.7 KB tile per wave): since the kept observation is regenerated instead
+// of loaded (regen_obs_variant) these kernels need 107-127 VGPRs, so FOUR blocks per CU fit the register file -- and the
+// LDS, with the scratch above: 4 x (8704 + 4 x 15 x 16 + 256) = 39 680 B per block.  Not with PT1 + DR (127-139 VGPRs:
+// spills under the 128 cap), the PID modes or the latency ring; Circle / TakeOff rows (44 / 52 floats) do not fit 40 KB.
+template <class V>
+constexpr bool four_block_variant() {
+  return regen_obs_variant<V>() && V::TASK == PDS_TASK_HOVER && !(V::MOTOR && V::DR) && V::CTRL == 0 && !V::LAT;
 }
 
 // What a caller that goes on with the step's results in registers gets back (csrc/pds_rollout.h).
@@ -441,7 +506,7 @@ struct StepOut {
 // rows that go to final_obs); `so` (optional): reward / flags of this lane's env.
 template <class V, int TR, int RM, bool STORE>
 PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, int parity, const float2 *ref_lds,
-                       float *tile, float *park, uint32_t *queue, U4 *scratch, int lane, long long wave_base, const EnvIdx ix,
+                       float *tile, float *park, uint32_t *queue, U4 *scratch, int lane, long long wave_base, const Idx<V> ix,
                        bool active, const float4 act, EnvState &S, int &qcount, float *fin_lds, StepOut *so
 #ifdef PDS_STAMPS
                        , unsigned long long *stamp_
@@ -456,17 +521,21 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
   static_assert(RM != RM_INLINE || TR == kWave, "inline reset: full tile only");
   static_assert(RM != RM_DEFERRED || STORE, "deferred drain: the state must be in HBM before it");
   const Consts &k = a.k;
+  const StepArgs &a_in = a;  // (the late phases shadow `a` with the re-read view)
   // Full tile: the row is built in place in LDS.  Half tile (the wave stages and flushes its 64 rows in two passes
   // of 32): the FIRST half of the row -- o(k), known before the physics -- goes straight to LDS as well, into the
   // tile for lanes 0-31 and into a parking area for lanes 32-63, so that only the second half (o(k+1), written last)
   // waits in registers for its pass: 20-24 VGPRs instead of a whole 40-48 float row held across the step.  That is
   // what lets the PT1 + DR variants reset in registers on the half tile (round 2: 61 spilled VGPRs, deferred drain).
+  // The lean variants (park_variant<V>() false) keep the round-2 form of the half tile: the whole row in registers
+  // until its pass (it costs them spills but no LDS round trip on the latency-bound 65 536-env launch: 6.98 vs 7.2 us).
   constexpr int HW = O + 4;           // floats per row half (D == 2 HW)
   constexpr int PS = park_stride<HW>();
-  constexpr bool VEC1 = (TR == kWave) ? VEC : (TS != D);  // first half as float4 (rows 16-byte aligned in both places)
-  float rowbuf[(TR == kWave) ? 1 : HW];
-  float *row = (TR == kWave) ? tile + lane * TS : (lane < TR ? tile + lane * TS : park + (lane - TR) * PS);
-  float *row2 = (TR == kWave) ? row + HW : rowbuf;
+  constexpr bool PARK = (TR != kWave) && park_variant<V>();
+  constexpr bool VEC1 = (TR == kWave) ? VEC : (PARK && TS != D);  // first half as float4 (rows 16-byte aligned in both places)
+  float rowbuf[(TR == kWave) ? 1 : (PARK ? HW : D)];
+  float *row = (TR == kWave) ? tile + lane * TS : (PARK ? (lane < TR ? tile + lane * TS : park + (lane - TR) * PS) : rowbuf);
+  float *row2 = (TR == kWave) ? row + HW : (PARK ? rowbuf : rowbuf + HW);
   const uint32_t env_id = (uint32_t)(a.env_id_base + (unsigned long long)ix.wb) + ix.lc;  // (uniform part in SGPRs)
   const float4 h1 = S.h1, h2 = S.h2;
   const uint32_t ctr = S.ctr;
@@ -583,7 +652,9 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
     e.wx += dt * (t0 * inv_Jx); e.wy += dt * (t1 * inv_Jy); e.wz += dt * (t2 * inv_Jz);  // :172,176
     e.px += dt * e.vx; e.py += dt * e.vy; e.pz += dt * e.vz;                             // :177
     e.roll += dt * e.wx; e.pitch += dt * e.wy; e.yaw += dt * e.wz;                       // :178
-    q = quat_from_euler(e.roll, e.pitch, e.yaw);                                         // :179
+    // :179 -- with observation noise nothing reads the TRUE quaternion after the last sub-step (the observation carries
+    // Q(noisy rpy), the next env.step rebuilds Q(rpy) from the stored angles): skip its three sincos there
+    if (!V::ON || sub + 1 < k.agg) q = quat_from_euler(e.roll, e.pitch, e.yaw);
     e.pz = fmaxf(e.pz, 0.f);                                                             // :182
     // envs/base.py:464: compute_observation() whose result is dropped still advances the gyro
     // bias random walk and the low-pass filter
@@ -674,6 +745,7 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
   }
 
   S.ctr = ctr_pack((uint32_t)(step + 1), 0u, (uint32_t)phase1, lat_idx);
+  if (regen_obs_variant<V>() && a.noise != nullptr) S.ctr |= kCtrOhBit;  // o(k+1) from injected variates: kept in oh0-2
   S.h2 = h1;   // u(k-1) becomes u(k-2)
   S.h1 = act;  // -> the ring slot that held u(k-2)
   // ---- auto-reset.  ~2 % of the envs finish per step under random actions, i.e. 3 of 4 waves
@@ -690,7 +762,7 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
       qcount = __popcll(reset_mask);
       if (need_reset) queue[pos] = (uint32_t)lane | ((uint32_t)ref_offset << 6);
     } else if constexpr (RM == RM_MERGED) {
-      const StepArgs &a = reload_args<101, heavy_variant<V>()>((int)o1);  // (shadows the parameter: see "coalesced stores" below)
+      const StepArgs &a = reload_args<101, heavy_variant<V>()>(a_in, (int)o1);  // (shadows the parameter: see "coalesced stores" below)
       const int count = __popcll(reset_mask);
       if (need_reset) queue[pos] = (uint32_t)lane;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -712,10 +784,8 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
   // ---- coalesced stores ----------------------------------------------------------------------
   // From here on the kernel arguments are read through a second, opaque view (reload_args): the pointers and
   // constants of the first half do not stay live in SGPRs across the step.
-  const StepArgs &a_early = a;
-  (void)a_early;
   {
-  const StepArgs &a = reload_args<102, heavy_variant<V>()>((int)o1);  // (o1: renewed per iteration of the K-step loop)
+  const StepArgs &a = reload_args<102, heavy_variant<V>()>(a_in, (int)o1);  // (o1: renewed per iteration of the K-step loop)
   const Consts &k = a.k;
   if (active) {
     // (RM_INLINE: a finished env's lane stores the FRESH state from inside the reset below, nothing here: no
@@ -724,7 +794,7 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
     if constexpr (STORE && RM == RM_INLINE) {
       if (!need_reset) store_state<V>(a, ix, parity ^ 1, S, false);
     }
-    const EnvIdx jx = fresh<5>(ix);
+    const Idx<V> jx = fresh<5>(ix);
     nt_store(at(a.reward + o1, jx), reward);
     nt_store(at(a.cost + o1, jx), cost);
     nt_store(at(a.term + o1, jx), (uint8_t)(done ? 1 : 0));
@@ -738,21 +808,30 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
     if (TR != kWave) {
       if ((lane / TR) == pass) {
         float *dst = tile + (lane % TR) * TS;
-        if (pass == 1) {  // the parked first half of lanes 32-63 moves into the (flushed) tile
-          const float *src = park + (lane - TR) * PS;
-          if constexpr (TS != D) {
+        if constexpr (PARK) {
+          if (pass == 1) {  // the parked first half of lanes 32-63 moves into the (flushed) tile
+            const float *src = park + (lane - TR) * PS;
+            if constexpr (TS != D) {
 #pragma unroll
-            for (int j = 0; j < HW / 4; ++j) reinterpret_cast<float4 *>(dst)[j] = reinterpret_cast<const float4 *>(src)[j];
+              for (int j = 0; j < HW / 4; ++j) reinterpret_cast<float4 *>(dst)[j] = reinterpret_cast<const float4 *>(src)[j];
+            } else {
+#pragma unroll
+              for (int j = 0; j < HW; ++j) dst[j] = src[j];
+            }
+          }
+          if constexpr (TS != D) {
+            lds_store_row<HW>(dst + HW, rowbuf);
           } else {
 #pragma unroll
-            for (int j = 0; j < HW; ++j) dst[j] = src[j];
+            for (int j = 0; j < HW; ++j) dst[HW + j] = rowbuf[j];
           }
-        }
-        if constexpr (TS != D) {
-          lds_store_row<HW>(dst + HW, rowbuf);
-        } else {
+        } else {  // whole row from registers
+          if constexpr (TS != D) {
+            lds_store_row<D>(dst, rowbuf);
+          } else {
 #pragma unroll
-          for (int j = 0; j < HW; ++j) dst[HW + j] = rowbuf[j];
+            for (int j = 0; j < D; ++j) dst[j] = rowbuf[j];
+          }
         }
       }
     }
@@ -769,7 +848,7 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
       // non-temporal like the other streamed outputs (same box: 57.7 vs 58.4 us on Hover 2^20)
       if (lane < D) {
         const float v = tile[(src_lane % TR) * TS + lane];
-        if (a.final_obs != nullptr) nt_store(lane_ptr(a.final_obs + (o1 + wave_base + src_lane) * D, fresh<6>((uint32_t)lane)), v);
+        if (a.final_obs != nullptr) nt_store(lane_at<saddr_variant<V>(), 6>(a.final_obs + (o1 + wave_base + src_lane) * D, (uint32_t)lane), v);
         if (fin_lds != nullptr) fin_lds[src_lane * D + lane] = v;
       }
     }
@@ -793,7 +872,7 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
             // registers are dead by now, so the result does not have to be merged into them (the K-step kernel's
             // form below costs 9-88 spilled VGPRs under the single-step kernel's 168-register cap)
             EnvState F;
-            F.e = r.e; F.ctr = r.ctr; F.h1 = r.u0; F.h2 = r.u0;
+            F.e = r.e; F.ctr = r.ctr | ((regen_obs_variant<V>() && a.noise != nullptr) ? kCtrOhBit : 0u); F.h1 = r.u0; F.h2 = r.u0;
             F.xm[0] = r.mx.x; F.xm[1] = r.mx.y; F.xm[2] = r.mx.z; F.xm[3] = r.mx.w;
             F.par = r.par;
 #pragma unroll
@@ -854,11 +933,11 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
           for (int base = 0; base < count; base += IE) {
             const int cnt = min(IE, count - base);  // wave-uniform
-            fill_reset_scratch<V>(a, rk, queue + base, cnt, lane, wave_base, scratch);
+            fill_reset_scratch<V, scratch_stride<V>()>(a, rk, queue + base, cnt, lane, wave_base, scratch);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (need_reset && pos >= base && pos < base + cnt) evaluate(LdsWords{scratch + (pos - base) * kScratchBlocks});
+            if (need_reset && pos >= base && pos < base + cnt) evaluate(LdsWords{scratch + (pos - base) * scratch_stride<V>()});
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();  // the scratch is refilled by the next pass
           }
@@ -878,7 +957,7 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
     }
     const long long left = rem - pass * TR;
     if (left > 0)
-      flush_tile<D, TR>(tile, a.obs + (o1 + wave_base + pass * TR) * D, left >= TR ? TR : (int)left, lane);
+      flush_tile<D, TR, saddr_variant<V>()>(tile, a.obs + (o1 + wave_base + pass * TR) * D, left >= TR ? TR : (int)left, lane);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();  // the tile is rewritten by the next pass / the reset drain / the next step
   }
@@ -901,7 +980,7 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
 #define PDS_MIN_WAVES_LEAN 4
 #endif
 #ifndef PDS_MIN_WAVES
-#define PDS_MIN_WAVES (V::ON ? 3 : PDS_MIN_WAVES_LEAN)
+#define PDS_MIN_WAVES (V::ON ? (four_block_variant<V>() ? 4 : 3) : PDS_MIN_WAVES_LEAN)
 #endif
 
 // Auto-reset in registers before the stores, or deferred drain after them.  Measured on one MI355X
@@ -970,15 +1049,15 @@ PDS_DEV void prefetch_kernargs() {
 #endif
 #define PDS_WAVE_LDS(V, TR, RM)                                                                        \
   __shared__ __attribute__((aligned(16))) float tile_all[(kBlock / kWave) * TR * tile_stride<V::D>()]; \
-  constexpr int kParkFloats_ = (TR == kWave) ? 0 : (kWave - TR) * park_stride<V::O + 4>();             \
+  constexpr int kParkFloats_ = (TR == kWave || !park_variant<V>()) ? 0 : (kWave - TR) * park_stride<V::O + 4>(); \
   __shared__ __attribute__((aligned(16))) float park_all[kParkFloats_ > 0 ? (kBlock / kWave) * kParkFloats_ : 4]; \
   const float2 *ref_lds = nullptr; /* (the Circle table of rounds 1-2: the reference point is evaluated now) */ \
   __shared__ uint32_t queue_all[(kBlock / kWave) * kQueueCap];                                        \
-  constexpr int kScratchU4_ = (RM == RM_MERGED) ? kMergedScratchU4 : ((RM == RM_INLINE && inline_coop_variant<V>()) ? inline_envs_per_pass<V>() * kScratchBlocks : 0); \
+  constexpr int kScratchU4_ = (RM == RM_MERGED) ? kMergedScratchU4 : ((RM == RM_INLINE && inline_coop_variant<V>()) ? inline_envs_per_pass<V>() * scratch_stride<V>() : 0); \
   __shared__ U4 scratch_all[kScratchU4_ > 0 ? (kBlock / kWave) * kScratchU4_ : 1];                     \
   const int tid = threadIdx.x;                                                                         \
   const int lane = tid & (kWave - 1);                                                                  \
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); /* wave-uniform: everything derived from it lives in SGPRs */ \
+  const int wave = saddr_variant<V>() ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6); /* SADDR form: wave-uniform, everything derived from it lives in SGPRs */ \
   U4 *scratch = scratch_all + wave * kScratchU4_;                                                      \
   uint32_t *queue = queue_all + wave * kQueueCap;                                                      \
   float *tile = tile_all + wave * (TR * tile_stride<V::D>());                                          \
@@ -998,7 +1077,7 @@ PDS_DEV void prefetch_kernargs() {
   const long long rem_ = a.n - wave_base; /* envs of this tile and beyond: > 0, wave-uniform */         \
   const bool active = rem_ >= kWave || lane < (int)rem_;                                               \
   /* tail lanes recompute the last env, stores masked */                                               \
-  const EnvIdx ix{wave_base, active ? (uint32_t)lane : (uint32_t)rem_ - 1u};
+  const Idx<V> ix{wave_base, active ? (uint32_t)lane : (uint32_t)rem_ - 1u};
 
 #ifdef PDS_STAMPS
 #define PDS_STAMP_ARG , stamp_
@@ -1045,14 +1124,15 @@ __global__ __launch_bounds__(kBlock, (PDS_MIN_WAVES) * (256 / kBlock)) void step
   parity = __builtin_amdgcn_readfirstlane((int)cur.clk.z) & 1;
   EnvState S;
   unpack_state<V>(a.k, cur, parity, S);
+  init_kept_obs<V>(a, rk, ix, S);
   int qcount = 0;  // wave-uniform
   step_once<V, TR, RM, true>(a, 0ll, rk, parity, ref_lds, tile, park, queue, scratch, lane, wave_base, ix, active, cur.act, S, qcount, nullptr, nullptr PDS_STAMP_ARG);
   if (RM == RM_DEFERRED && qcount > 0) {
     const float own_w[3] = {S.e.wx, S.e.wy, S.e.wz};
-    drain_reset_queue<V>(reload_args<104, heavy_variant<V>()>(), rk, ref_lds, queue, qcount, lane, wave_base, tile, own_w, S.ns.bias);
+    drain_reset_queue<V>(reload_args<104, heavy_variant<V>()>(a), rk, ref_lds, queue, qcount, lane, wave_base, tile, own_w, S.ns.bias);
   }
   PDS_STAMP(6);
-  advance_clock(reload_args<105, heavy_variant<V>()>().st.clk, t, rk, parity ^ 1, 1u, lane);
+  advance_clock(reload_args<105, heavy_variant<V>()>(a).st.clk, t, rk, parity ^ 1, 1u, lane);
   PDS_STAMP_FLUSH;
 }
 
@@ -1086,13 +1166,14 @@ __global__ __launch_bounds__(kBlock, (PDS_STEPK_MIN_WAVES) * (256 / kBlock)) voi
   const RngKey rk0 = rk;
   EnvState S;
   unpack_state<V>(a.k, cur, parity, S);
+  init_kept_obs<V>(a, rk, ix, S);
   const int K = a.k_steps;
   float4 act = cur.act;  // actions[0]
   int qcount = 0;
   for (int s = 0; s < K; ++s) {
     // a fresh view of the kernel arguments per iteration: what the loop body needs is re-read (scalar-cache
     // hits) instead of being hoisted out of the loop into SGPRs that do not exist (41-79 spills in round 2)
-    const StepArgs &al = reload_args<106, heavy_variant<V>()>(s);
+    const StepArgs &al = reload_args<106, heavy_variant<V>()>(a, s);
     float4 act_next = act;
     if (s + 1 < K) act_next = nt_load4(at(al.actions + (long long)(s + 1) * al.n, ix));  // in flight during step s
     step_once<V, TR, RM, false>(al, (long long)s * al.n, rk, parity, ref_lds, tile, park, queue, scratch, lane, wave_base, ix, active, act, S, qcount, nullptr, nullptr PDS_STAMP_ARG);
@@ -1101,7 +1182,7 @@ __global__ __launch_bounds__(kBlock, (PDS_STEPK_MIN_WAVES) * (256 / kBlock)) voi
     rk.tick_lo += 1u;
     if (rk.tick_lo == 0u) rk.tick_hi += 1u;
   }
-  const StepArgs &az = reload_args<107, heavy_variant<V>()>();
+  const StepArgs &az = reload_args<107, heavy_variant<V>()>(a);
   if (active) store_state<V>(az, ix, parity, S, true);
   advance_clock(az.st.clk, t, rk0, parity, (uint32_t)K, lane);
 }

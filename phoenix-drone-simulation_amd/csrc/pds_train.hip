@@ -111,23 +111,25 @@ __device__ __forceinline__ uint32_t feistel_round(uint32_t r, uint32_t key) {
 }
 __global__ __launch_bounds__(256) void permutation_kernel(long long *out, long long n, int half_bits, uint64_t seed,
                                                           uint64_t call) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  // (the round keys are the same for every thread: grid-stride loop, at most 2^22 threads evaluate the two blocks)
   const pds::U4 k0 = pds::philox4x32_10(0u, 0x7065726du, (uint32_t)call, (uint32_t)(call >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
   const pds::U4 k1 = pds::philox4x32_10(1u, 0x7065726du, (uint32_t)call, (uint32_t)(call >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
   const uint32_t key[6] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y};
   const uint32_t mask = half_bits >= 32 ? 0xFFFFFFFFu : ((1u << half_bits) - 1u);
-  unsigned long long x = (unsigned long long)i;
-  do {
-    uint32_t L = (uint32_t)(x >> half_bits), R = (uint32_t)x & mask;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    unsigned long long x = (unsigned long long)i;
+    do {
+      uint32_t L = (uint32_t)(x >> half_bits), R = (uint32_t)x & mask;
 #pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      const uint32_t t = L ^ (feistel_round(R, key[r]) & mask);
-      L = R; R = t;
-    }
-    x = ((unsigned long long)L << half_bits) | R;
-  } while (x >= (unsigned long long)n);
-  out[i] = (long long)x;
+      for (int r = 0; r < 6; ++r) {
+        const uint32_t t = L ^ (feistel_round(R, key[r]) & mask);
+        L = R; R = t;
+      }
+      x = ((unsigned long long)L << half_bits) | R;
+    } while (x >= (unsigned long long)n);
+    out[i] = (long long)x;
+  }
 }
 
 }  // namespace pds_train_detail
@@ -155,7 +157,8 @@ extern "C" int pds_permutation(int64_t *d_out, int64_t n, uint64_t seed, uint64_
   int bits = 1;
   while (bits < 63 && (1ll << bits) < n) ++bits;
   const int half_bits = (bits + 1) / 2;  // the Feistel domain: 2^(2 half_bits) >= n, < 4 n
-  const long long blocks = (n + 255) / 256;
+  long long blocks = (n + 255) / 256;
+  if (blocks > (1ll << 14)) blocks = 1ll << 14;  // grid-stride beyond 2^22 elements (no 32-bit grid overflow for any n)
   hipLaunchKernelGGL(pds_train_detail::permutation_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                      (long long *)d_out, (long long)n, half_bits, seed, call);
   return hipGetLastError() == hipSuccess ? PDS_OK : PDS_EHIP;

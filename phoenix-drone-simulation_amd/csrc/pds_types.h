@@ -1,6 +1,7 @@
 // pds_types.h -- data layout shared by the kernels and the host side of libpds_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "../../include/pds.h"
@@ -34,7 +35,7 @@ constexpr int kMaxLatSteps = PDS_MAX_LATENCY_STEPS;  // rows of the latency acti
 
 // ---- packing of the per-env counter word --------------------------------------------------------
 // bits 0..15 env.step calls since reset | bit 16 quaternion == -Q(rpy) | bits 17..25 Circle ref_offset
-// | bits 26..28 action_idx of the latency ring (envs/agents.py:183,273).
+// | bits 26..28 action_idx of the latency ring (envs/agents.py:183,273) | bit 29 kCtrOhBit (below).
 // Circle keeps the PHASE (env.step calls + ref_offset) mod num_ref_points in bits 17..25, i.e. the index
 // of the current reference point (envs/circle.py:130): it advances by one per step with a wrap, so the
 // step needs no modulo; ref_offset itself is recovered where it is asked for (circle_ref_offset).
@@ -45,6 +46,16 @@ PDS_DEV uint32_t ctr_step(uint32_t c) { return c & 0xFFFFu; }
 PDS_DEV uint32_t ctr_sign(uint32_t c) { return (c >> 16) & 1u; }
 PDS_DEV uint32_t ctr_off(uint32_t c) { return (c >> 17) & 0x1FFu; }
 PDS_DEV uint32_t ctr_lat(uint32_t c) { return (c >> 26) & 0x7u; }
+// bit 29 (observation-noise variants without the Kalman hold): "the kept noisy observation o(k) of this env is in
+// oh0-2".  Clear = it is REGENERATED from the stored true state and the previous tick's Philox blocks (round 4: the
+// Philox-driven step neither reads nor writes oh0-2, -80 B per env-step); set by whatever produced o(k) from draws that
+// Philox cannot replay or on a state that may since have been edited: pds_reset / pds_reset_from_samples,
+// pds_step_with_variates, pds_set_state(NOISY_OBS), the deferred-drain resets.
+#ifndef PDS_REGEN_OBS
+#define PDS_REGEN_OBS 1  // A/B: 0 = the kept observation always lives in oh0-2 (rounds 1-3)
+#endif
+constexpr uint32_t kCtrOhBit = 1u << 29;
+PDS_DEV uint32_t ctr_oh(uint32_t c) { return (c >> 29) & 1u; }
 PDS_DEV uint32_t circle_ref_offset(uint32_t c, int ref_points) {  // not on the hot path
   const int d = (int)ctr_off(c) - (int)(ctr_step(c) % (uint32_t)ref_points);
   return (uint32_t)(d < 0 ? d + ref_points : d);
@@ -57,11 +68,29 @@ PDS_DEV uint32_t circle_ref_offset(uint32_t c, int ref_points) {  // not on the 
 // offset VGPR per element size is shared by all arrays, and no 64-bit vector address (2 VGPRs + a
 // v_lshl_add_u64 each) is formed per stream.  `lc` is the lane, clamped to the last env of the batch for the
 // lanes past the end (they recompute that env; their stores are masked).
-struct EnvIdx {
+// Round 4: the form is a per-variant trait (saddr_variant<V>(), csrc/pds_step.h).  The lean variants -- no PT1 / DR /
+// noise / PID / latency: the headline, configs 2 and 4 -- had no spilled register with the plain 64-bit per-lane
+// addresses of rounds 1-2 and ran 0.5-1 % faster with them on the same box (profiles/r03_ab_final_vs_round2.txt);
+// EnvIdxT<false> is that form: `array + (wb + lc)`, one 64-bit vector address per stream.
+template <bool SADDR>
+struct EnvIdxT {
   long long wb;  // first env of the tile (wave-uniform)
   uint32_t lc;   // lane within the tile, clamped
   PDS_DEV long long global() const { return wb + (long long)lc; }
 };
+// 64-bit form: the env index is formed ONCE and made opaque, so that every stream's address is one shift-add on it
+// (array + (gi << 4)); left to itself the compiler re-associates to (array + (wb << 4)) + (lc << 4) -- two 64-bit adds
+// per stream, ~17 more vector instructions in front of the kernel's first loads (the round-2 kernels had the single
+// form; same-box A/B of the headline: profiles/r04_ab_lib_r2.txt).
+template <>
+struct EnvIdxT<false> {
+  long long wb;
+  uint32_t lc;
+  long long gi;
+  PDS_DEV EnvIdxT(long long wb_, uint32_t lc_) : wb(wb_), lc(lc_), gi(wb_ + (long long)lc_) { asm("" : "+v"(gi)); }
+  PDS_DEV long long global() const { return gi; }
+};
+typedef EnvIdxT<true> EnvIdx;
 template <class T>
 PDS_DEV T *lane_ptr(T *uniform_base, uint32_t index) {  // uniform_base + index, with a 32-bit byte offset
   return reinterpret_cast<T *>(reinterpret_cast<char *>(uniform_base) + index * (uint32_t)sizeof(T));
@@ -71,7 +100,9 @@ PDS_DEV const T *lane_ptr(const T *uniform_base, uint32_t index) {
   return reinterpret_cast<const T *>(reinterpret_cast<const char *>(uniform_base) + index * (uint32_t)sizeof(T));
 }
 template <class T>
-PDS_DEV T *at(T *array, const EnvIdx x) { return lane_ptr(array + x.wb, x.lc); }
+PDS_DEV T *at(T *array, const EnvIdxT<true> x) { return lane_ptr(array + x.wb, x.lc); }
+template <class T>
+PDS_DEV T *at(T *array, const EnvIdxT<false> x) { return array + x.global(); }
 // The instruction selector matches the SADDR form per BASIC BLOCK: it has to see the zero-extension of the
 // 32-bit offset next to the access.  An offset that was extended in an earlier block (common subexpression
 // with the loads at kernel entry) arrives as a 64-bit register and the access falls back to a 64-bit vector
@@ -84,9 +115,17 @@ PDS_DEV uint32_t fresh(uint32_t lane_index) {
   return lane_index;
 }
 template <int ID>
-PDS_DEV EnvIdx fresh(EnvIdx x) {
+PDS_DEV EnvIdxT<true> fresh(EnvIdxT<true> x) {
   x.lc = fresh<ID>(x.lc);
   return x;
+}
+template <int ID>
+PDS_DEV EnvIdxT<false> fresh(EnvIdxT<false> x) { return x; }  // 64-bit vector addresses: nothing to re-derive
+// lane-indexed access into a wave-uniform region (observation tile flush, final_obs rows)
+template <bool SADDR, int ID, class T>
+PDS_DEV T *lane_at(T *uniform_base, uint32_t lane_index) {
+  if constexpr (SADDR) return lane_ptr(uniform_base, fresh<ID>(lane_index));
+  else return uniform_base + lane_index;
 }
 
 // ---- per-wave clock word (device memory) ----------------------------------------------------------
@@ -179,10 +218,14 @@ struct StepArgs {
 // counter when the view has to be renewed per iteration (otherwise the asm is loop-invariant and hoisted).
 // ENABLE = false: the lean variants (no PT1 / DR / noise / PID / latency) fit the SGPR file as they are, and on
 // a latency-bound launch (65 536 envs: one wave per SIMD) every extra scalar-load round trip shows: 7.2 vs 7.0 us.
+// `passed`: the arguments as the caller holds them -- returned as they are when the re-read is off, so a caller that
+// hands step_once a StepArgs that is NOT the head of the kernarg segment is only wrong for ENABLE = true, which is
+// why every kernel that reaches step_once / drain_reset_queue has the StepArgs as its FIRST kernel argument (RolloutArgs.s:
+// static_assert below).
 template <int ID, bool ENABLE = true>
-PDS_DEV const StepArgs &reload_args(int tag = 0) {
+PDS_DEV const StepArgs &reload_args(const StepArgs &passed, int tag = 0) {
+  if (!ENABLE || !PDS_RELOAD_ARGS) return passed;
   auto kp = __builtin_amdgcn_kernarg_segment_ptr();
-  if (!ENABLE || !PDS_RELOAD_ARGS) return *(const StepArgs *)kp;  // the compiler sees the same pointer and keeps the early loads' values
   asm("" : "+s"(kp) : "n"(ID), "s"(tag));
   return *(const StepArgs *)kp;  // (C cast: address space 4 -> generic; the loads are inferred back to scalar loads)
 }
@@ -259,13 +302,18 @@ PDS_DEV void default_params(const Consts &k, Params &p) {
 // Reference trajectories: envs/circle.py:45-56, envs/takeoff.py:43-47 (z = k/300).  The circle
 // (0.25 (1 - cos th_t), 0.25 sin th_t, 1), th_t = 2 pi t / P, is evaluated, not looked up (round 3): the table of rounds
 // 1-2 cost every block a global-memory round trip and a barrier before its first instruction of the step, and
-// 2.4 KB of LDS; ~27 vector instructions per point with the step's own sincos (abs error 1e-7 x 0.25; the angle
-// from a two-float 2 pi / P so that t x it is exact to 1e-8 rad).  `ref_lds` is unused.
+// 2.4 KB of LDS; ~27 vector instructions per point with the step's own sincos (abs error 1e-7 x 0.25).  The angle
+// t x (2 pi / P) is formed from a two-float 2 pi / P with the rounding error of the leading product recovered by an
+// fma (p = t hi; err = fma(t, hi, -p) exactly; th = p + (t lo + err)): th is the correctly rounded float of the exact
+// angle up to 1 ulp (2.4e-7 rad near 2 pi), i.e. a target error of <= 0.25 x (2.4e-7 + 1e-7) = 9e-8 m against the
+// reference's float64 table (tests/test_gpu_properties.py compares all t < ref_points).  `ref_lds` is unused.
 template <int TASK>
 PDS_DEV void target_at(const Consts &k, const float2 *ref_lds, int t, float &tx, float &ty, float &tz) {
   if (TASK == PDS_TASK_CIRCLE) {
     const float tf = (float)t;
-    const float th = fmaf(tf, k.ref_dth_lo, tf * k.ref_dth_hi);
+    const float p = __fmul_rn(tf, k.ref_dth_hi);          // (pinned: not contracted with the fma below)
+    const float err = fmaf(tf, k.ref_dth_hi, -p);         // exact rounding error of p
+    const float th = p + fmaf(tf, k.ref_dth_lo, err);
     float sn, cs;
     fast_sincos(th, sn, cs);
     tx = 0.25f * (1.0f - cs); ty = 0.25f * sn; tz = 1.0f;
@@ -294,6 +342,7 @@ struct LaunchFlags {
 enum LaunchKind { kLaunchStep = 0, kLaunchStepK = 1, kLaunchReset = 2 };
 // one translation unit per (task, family) keeps the build parallel: pds_task_*.hip
 // Arguments of the fused rollout (csrc/pds_rollout.h).
+constexpr int kRolloutTiles = 2;  // 64-env tiles per block of the fused rollout (they share the weight images in LDS)
 struct RolloutArgs {
   StepArgs s;  // FIRST member (reload_args reads the kernarg segment as a StepArgs); reward / term / trunc / cost point
                // at the [T, N] rollout buffers, obs at obs_buf + N D (step t writes o(t + 1) into row t + 1)
@@ -309,6 +358,8 @@ struct RolloutArgs {
   float *act_buf, *logp_buf, *val_buf, *fval_buf, *last_val;
   float *ep_ret, *ep_len, *stats;
 };
+
+static_assert(offsetof(RolloutArgs, s) == 0, "reload_args() reads the head of the kernarg segment as a StepArgs");
 
 bool launch_rollout_hover(const LaunchFlags &f, dim3 grid, hipStream_t s, const RolloutArgs &ra);
 bool launch_rollout_circle(const LaunchFlags &f, dim3 grid, hipStream_t s, const RolloutArgs &ra);

@@ -216,7 +216,7 @@ class PPOTrainer:
                  train_v_iterations=5, num_mini_batches=16, target_kl=0.01, use_kl_early_stopping=False,
                  use_linear_lr_decay=True, use_exploration_noise_anneal=True, use_reward_scaling=True,
                  use_standardized_obs=True, use_max_grad_norm=False, max_grad_norm=0.5, ac_kwargs=None,
-                 seed=0, fused=None, graph_rollout=None, fused_rollout=None):
+                 seed=0, fused=None, graph_rollout=None, fused_rollout=None, reset_each_rollout=False):
         self.env, self.T, self.N = env, int(rollout_len), env.num_envs
         self.epochs, self.gamma, self.lam, self.clip_ratio = epochs, gamma, lam, clip_ratio
         self.entropy_coef = entropy_coef if use_entropy else 0.0
@@ -277,12 +277,25 @@ class PPOTrainer:
         self.ep_ret = torch.zeros(N, **f)
         self.ep_len = torch.zeros(N, **f)
         self.obs, _ = env.reset()
+        # reset_each_rollout: IWPGAlgorithm.roll_out starts every epoch with `o, _ = self.env.reset()` and drops the
+        # episode that the previous epoch cut (algs/iwpg/iwpg.py:352-353, 382-385).  With thousands of lockstep envs
+        # that would throw away the unfinished episode of every env each epoch, so the default is to carry on
+        # (the cut path is bootstrapped with V either way); True mirrors the reference, e.g. for the learning-curve
+        # comparison against its own trainer (tests/test_trainer.py, tests/golden/learning_curve.json).
+        self.reset_each_rollout = bool(reset_each_rollout)
+        if self.reset_each_rollout:
+            graph_rollout = False  # (a captured rollout holds the address of the previous observation)
+            self.graph_rollout = False
         self.epoch = 0
         self.log = []
 
     def roll_out(self):
         """algs/iwpg/iwpg.py:350-385 over all envs at once.  Returns per-epoch episode statistics."""
         self.ac.train()
+        if self.reset_each_rollout and self.epoch > 0:
+            self.obs, _ = self.env.reset()
+            self.ep_ret.zero_()
+            self.ep_len.zero_()
         if self.fused and self.fused_rollout is not False and getattr(self.env, "observation_history_size", 2) == 2:
             try:
                 return self._roll_out_fused()

@@ -86,3 +86,33 @@ def test_bench_diagnostic_modes(mode, steps, warmup):
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "30", "--warmup", "5", "--envs-per-gpu", "65536",
                           "--mode", mode, "--no-cpu-baseline", "--no-traffic"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert bad.returncode != 0 and "multiples" in (bad.stderr + bad.stdout)
+
+
+def test_bench_total_envs_is_strong_scaling_same_device():
+    """`--total-envs` splits a fixed job into contiguous global-id blocks (SURVEY 8e strong scaling): two ranks on one
+    device (gloo control plane) each take half, the line says so."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "4",
+           "--total-envs", "131072", "--same-device", "--no-cpu-baseline", "--no-traffic"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["scaling"] == "strong" and d["n_gpus"] == 2 and d["ranks"] == 2
+    assert d["config"]["envs_per_gpu"] == 65536 and d["total_envs"] == 131072
+    assert d["visible_devices"] >= 1 and d["collective_backend"] == "gloo"
+
+
+@pytest.mark.skipif(__import__("torch").cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI)")
+def test_bench_two_gpus_rccl_allgather_for_real():
+    """config (5) in small: two ranks on two devices, RCCL all-gather of the observations (bench.py checks the
+    gathered rows against the owners' blocks before it times the exchange).  Skipped on the 1-GPU test boxes."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "4",
+           "--envs-per-gpu", "65536", "--allgather-obs", "rccl", "--no-cpu-baseline", "--no-traffic"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["collective_backend"] == "nccl" and d["visible_devices"] >= 2
+    assert d["allgather_ms"] > 0 and d["scaling"] == "weak"

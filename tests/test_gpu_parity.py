@@ -2,8 +2,10 @@
  (a) the golden vectors generated from the reference itself (tests/golden/, float64 numpy), and
  (b) the float32 CPU oracle on identical seeds for the in-kernel Philox reset path.
 
-Tolerance (north_star): 1e-6 relative fp32 for a single step from identical state, plus 2e-6
-absolute for near-cancelling quantities (equal-thrust torques are amplified by dt/J ~ 600).
+Tolerance (north_star): 1e-6 relative + 1e-7 absolute fp32 for a single step from identical
+state on every field; the stated exceptions (body rates + 2e-6, quaternion and target - position with the
+propagated relative bar of their inputs) are defined in golden_util.py and measured in
+profiles/r04_parity_margins.txt.
 """
 import numpy as np
 import pytest
@@ -13,7 +15,7 @@ import golden_util as gu
 
 pytestmark = pytest.mark.gpu
 
-RTOL, ATOL = 1e-6, 2e-6
+RTOL, ATOL = gu.RTOL, gu.ATOL
 
 DET_SCENARIOS = [n for n in gu.scenario_names() if not gu.noisy(gu.Golden(n))]
 
@@ -95,7 +97,6 @@ def test_single_step_vs_reference(name):
     observation, reward, termination, truncation and cost."""
     g = gu.Golden(name)
     pre, acts, exp = _gather_single_steps(g)
-    RTOL, ATOL = gu.tolerances(name)
     B = acts.shape[0]
     agg = int(g.kwargs.get("aggregate_phy_steps", 1))
     env = _make(g, B, auto_reset=False)
@@ -104,16 +105,17 @@ def test_single_step_vs_reference(name):
     _inject(env, pre, agg)
     obs, rew, term, trunc, info = env.step(torch.tensor(acts, dtype=torch.float32))
     torch.cuda.synchronize()
-    gu.assert_close(obs.cpu().numpy(), exp["obs"], RTOL, ATOL, name + " obs")
-    gu.assert_close(rew.cpu().numpy(), exp["reward"], RTOL, 10 * ATOL, name + " reward")
+    W_ATOL = gu.rate_atol(name)
+    gu.assert_close(obs.cpu().numpy(), exp["obs"], RTOL, gu.obs_atol(g, name, exp["obs"], pre["rpy"], exp["rpy"]), name + " obs")
+    gu.assert_close(rew.cpu().numpy(), exp["reward"], RTOL, ATOL, name + " reward")
     assert np.array_equal(term.cpu().numpy(), exp["terminated"].astype(bool)), name
     assert np.array_equal(trunc.cpu().numpy(), exp["truncated"].astype(bool)), name
     assert np.array_equal(info["cost"].cpu().numpy(), exp["cost"].astype(np.float32)), name
     gu.assert_close(env.get_state("pos").cpu().numpy(), exp["xyz"], RTOL, ATOL, name + " pos")
     gu.assert_close(env.get_state("rpy").cpu().numpy(), exp["rpy"], RTOL, ATOL, name + " rpy")
     gu.assert_close(env.get_state("vel").cpu().numpy(), exp["xyz_dot"], RTOL, ATOL, name + " vel")
-    gu.assert_close(env.get_state("omega").cpu().numpy(), exp["rpy_dot"], RTOL, ATOL, name + " omega")
-    gu.assert_close(env.get_state("quat").cpu().numpy(), exp["quat"], RTOL, ATOL, name + " quat")
+    gu.assert_close(env.get_state("omega").cpu().numpy(), exp["rpy_dot"], RTOL, W_ATOL, name + " omega")
+    gu.assert_close(env.get_state("quat").cpu().numpy(), exp["quat"], RTOL, gu.quat_atol(exp["rpy"]), name + " quat")
     if g.motor:
         gu.assert_close(env.get_state("motor_x").cpu().numpy(), exp["x"], RTOL, ATOL, name + " motor x")
     if env.latency_steps > 0:  # the delayed-action ring after the step (envs/agents.py:270-273)
@@ -150,11 +152,15 @@ def test_reset_from_reference_draws(name):
     env = _make(g, g.E, auto_reset=False)
     obs, _ = env.reset_from_samples(_samples_from_golden(g))
     torch.cuda.synchronize()
-    gu.assert_close(obs.cpu().numpy(), g["reset_obs"], RTOL, ATOL, name + " reset obs")
+    gu.assert_close(obs.cpu().numpy(), g["reset_obs"], RTOL, gu.obs_atol(g, name, g["reset_obs"], g["sample_rpy"], g["sample_rpy"]), name + " reset obs")
     gu.assert_close(env.get_state("pos").cpu().numpy(), g["reset_xyz"], RTOL, ATOL, name + " pos")
-    gu.assert_close(env.get_state("rpy").cpu().numpy(), g["reset_rpy"], RTOL, ATOL, name + " rpy")
-    gu.assert_close(env.get_state("quat").cpu().numpy(), g["reset_quat"], RTOL, ATOL, name + " quat")
-    gu.assert_close(env.get_state("omega").cpu().numpy(), g["reset_rpy_dot"], RTOL, ATOL, name + " omega")
+    # rpy = Euler(Q(sampled rpy)): the yaw comes back WRAPPED, i.e. as the small difference of the sampled yaw (up to
+    # 2 pi, injected as float32: half an ulp is 2.4e-7) and a multiple of 2 pi -- its bar is 1e-6 of the sampled angle
+    rpy_atol = ATOL + RTOL * np.abs(np.asarray(g["sample_rpy"], dtype=np.float64))
+    gu.assert_close(env.get_state("rpy").cpu().numpy(), g["reset_rpy"], RTOL, rpy_atol, name + " rpy")
+    gu.assert_close(env.get_state("quat").cpu().numpy(), g["reset_quat"], RTOL, gu.quat_atol(g["sample_rpy"]), name + " quat")
+    # R^T (R^T omega_sampled): two 3-term sums of products of up to 3.5 rad/s that can nearly cancel -- the body-rate bar
+    gu.assert_close(env.get_state("omega").cpu().numpy(), g["reset_rpy_dot"], RTOL, gu.rate_atol(name), name + " omega")
     gu.assert_close(env.get_state("vel").cpu().numpy(), g["reset_xyz_dot"], RTOL, ATOL, name + " vel")
     assert np.array_equal(env.get_state("ref_offset").cpu().numpy()[:, 0], g["reset_ref_offset"])
     if g.motor:
@@ -181,11 +187,11 @@ def test_edge_resets_with_init_overrides(name):
         over = {k: [float(v) for v in g[k][ep]] for k in ("init_xyz", "init_rpy", "init_xyz_dot", "init_rpy_dot")}
         env = _make(g, 1, auto_reset=False, **over)
         obs, _ = env.reset()
-        gu.assert_close(obs.cpu().numpy()[0], g["reset_obs"][ep], RTOL, ATOL, f"{name} ep{ep} reset obs")
+        gu.assert_close(obs.cpu().numpy()[0], g["reset_obs"][ep], RTOL, gu.obs_atol(g, name, g["reset_obs"][ep][None], g["reset_rpy"][ep][None], g["reset_rpy"][ep][None])[0], f"{name} ep{ep} reset obs")
         for t in range(g.n_valid(ep)):
             o, r, term, trunc, info = env.step(torch.tensor(g["actions"][ep, t][None], dtype=torch.float32))
             w = f"{name} ep{ep} t{t}"
-            tol = ATOL * (t + 1) * 4  # closed loop over <= 4 steps
+            tol = 2e-6 * (t + 1) * 4  # closed loop over <= 4 steps
             gu.assert_close(o.cpu().numpy()[0], g["obs"][ep, t], RTOL * 10, tol, w + " obs")
             assert bool(term[0]) == bool(g["terminated"][ep, t]), w
             assert float(info["cost"][0]) == g["cost"][ep, t], w

@@ -392,3 +392,30 @@ def test_history_kernel_equals_the_torch_composition(task, H, auto_reset, noise)
         hist = want
     assert (not auto_reset) or finished > N // 2
     env.close()
+
+
+@pytest.mark.parametrize("freq", [100, 50, 77])
+def test_circle_reference_point_evaluated_in_kernel_equals_the_float64_table(freq):
+    """envs/circle.py:45-56 builds the reference trajectory as a float64 table; the kernel EVALUATES point t
+    (csrc/pds_types.h target_at: angle from a two-float 2 pi / P, the step's sincos).  Every index t < P: the
+    target behind the observation's `target - xyz` columns of both history halves == the table to 1.5e-7 m
+    (bound 9e-8 of the evaluation + the float32 rounding of the subtraction and of this test's re-addition)."""
+    import phoenix_drone_simulation_amd as pds
+    P = 3 * freq  # circle_time x observation_frequency (circle.py:47-49)
+    env = pds.make(ENV_ID["circle"], num_envs=P, seed=1, auto_reset=False, enable_reset_distribution=False,
+                   observation_frequency=freq, **{k: v for k, v in DET.items()})
+    env.reset()
+    env.set_state("ref_offset", np.arange(P, dtype=np.int32))
+    p0 = env.get_state("pos").cpu().numpy().astype(np.float64)
+    obs, *_ = env.step(torch.zeros(P, 4))
+    p1 = env.get_state("pos").cpu().numpy().astype(np.float64)
+    o = obs.cpu().numpy().astype(np.float64)
+    half = o.shape[1] // 2
+    th = 2 * np.pi * np.arange(2 * P) / P
+    table = np.stack([0.25 * (1 - np.cos(th)), 0.25 * np.sin(th), np.ones(2 * P)], 1)  # circle.py:50-55 (periodic)
+    t = np.arange(P)
+    first = o[:, 13:16] + p0           # o(k): target of index (0 + ref_offset) % P
+    second = o[:, half + 13:half + 16] + p1  # o(k+1): index (1 + ref_offset) % P
+    assert np.abs(first - table[t]).max() < 1.5e-7, np.abs(first - table[t]).max()
+    assert np.abs(second - table[t + 1]).max() < 1.5e-7, np.abs(second - table[t + 1]).max()
+    env.close()

@@ -358,3 +358,54 @@ def test_fused_rollout_refuses_what_it_is_not_built_for_and_the_trainer_falls_ba
     with pytest.raises(NotImplementedError):
         PPOTrainer(env, rollout_len=4, epochs=2, seed=5, fused=True, fused_rollout=True).roll_out()
     env.close()
+
+
+@pytest.mark.gpu
+def test_ppo_learning_curve_inside_the_reference_trainers_seed_band():
+    """End-to-end pin of the caller ("Hover return vs epochs"): tests/golden/learning_curve.json
+    holds the per-epoch log of the REFERENCE's own ProximalPolicyOptimizationAlgorithm.learn() (algs/ppo/ppo.py:50-63,
+    algs/iwpg/iwpg.py:259-485, defaults algs/ppo/defaults.py:6-19) on its own DroneHoverSimpleEnv-v0 with the env's
+    default sensor noise / domain randomisation / thrust noise: 6 seeds x 40 epochs x 32 000 steps
+    (oracle/refgen/gen_golden_learning.py, 28 minutes per seed).  PPOTrainer on the HIP envs runs the same
+    configuration -- 32 000 steps per epoch (8 envs x 4 000 steps: episodes follow each other in an env as they do in
+    the reference's single env), 40 epochs (the exploration-noise and learning-rate schedules span exactly them), the
+    same hyper-parameters, env.reset() at the start of every rollout like IWPGAlgorithm.roll_out -- under its own
+    randomness (Philox envs, torch initialisation), 4 seeds, ~2 s each.
+    Band: for every epoch, the mean over the HIP seeds of EpRet/Mean and of EpLen/Mean must lie inside
+    [min over the reference seeds - sigma, max over the reference seeds + sigma], sigma = the reference seeds' standard
+    deviation at that epoch (EpLen: 1.3 - 12 steps, EpRet: 0.4 - 15).  The curve is distinctive: episode length 10 -> 90
+    by epoch 12, back to 68 by epoch 19 while the exploration noise anneals, up to 95 by epoch 40; measured
+    side by side in profiles/r04_learning_curve.txt."""
+    import json
+    import phoenix_drone_simulation_amd as pds
+    from phoenix_drone_simulation_amd.ppo import PPOTrainer
+    ref = json.load(open(os.path.join(os.path.dirname(GOLD), "learning_curve.json")))
+    E, spe = ref["epochs"], ref["steps_per_epoch"]
+    assert (E, spe, ref["env_id"]) == (40, 32000, "DroneHoverSimpleEnv-v0") and len(ref["seeds"]) >= 3
+    hyper = ref["hyper"]  # what the reference ran with == PPOTrainer's defaults
+    kw = dict(gamma=hyper["gamma"], lam=hyper["lam"], pi_lr=hyper["pi_lr"], vf_lr=hyper["vf_lr"],
+              train_pi_iterations=hyper["train_pi_iterations"], train_v_iterations=hyper["train_v_iterations"],
+              num_mini_batches=hyper["num_mini_batches"], use_kl_early_stopping=hyper["use_kl_early_stopping"],
+              use_linear_lr_decay=hyper["use_linear_lr_decay"], use_exploration_noise_anneal=hyper["use_exploration_noise_anneal"],
+              use_reward_scaling=hyper["use_reward_scaling"], use_standardized_obs=hyper["use_standardized_obs"],
+              use_max_grad_norm=hyper["use_max_grad_norm"], use_entropy=hyper["use_entropy"])
+    num_envs = 8
+    curves = {"EpRet/Mean": [], "EpLen/Mean": []}
+    for seed in (100, 101, 102, 103):
+        env = pds.make(ref["env_id"], num_envs=num_envs, seed=seed)
+        assert env.obs_dim == ref["obs_dim"]
+        tr = PPOTrainer(env, rollout_len=spe // num_envs, epochs=E, seed=seed, reset_each_rollout=True, **kw)
+        tr.learn()
+        curves["EpRet/Mean"].append([r["ep_ret"] for r in tr.log])
+        curves["EpLen/Mean"].append([r["ep_len"] for r in tr.log])
+        env.close()
+    for key, mine in curves.items():
+        r = np.array([ref["curves"][str(s)][key] for s in ref["seeds"]])
+        m = np.mean(np.array(mine), axis=0)
+        sigma = r.std(axis=0)
+        lo, hi = r.min(axis=0) - sigma, r.max(axis=0) + sigma
+        bad = np.nonzero((m < lo) | (m > hi))[0]
+        assert bad.size == 0, (key, [(int(e) + 1, float(m[e]), float(lo[e]), float(hi[e])) for e in bad])
+    # ... and it is the reference's curve, not just a wide band: rise, dip while the noise anneals, rise
+    ln = np.mean(np.array(curves["EpLen/Mean"]), axis=0)
+    assert ln[:3].mean() < 16 and ln[9:13].mean() > 70 and ln[17:21].mean() < ln[9:13].mean() - 5 and ln[35:].mean() > ln[17:21].mean() + 10
