@@ -879,7 +879,7 @@ extern "C" int pds_rollout(pds_handle *h, int T, const pds_mlp *pi, const pds_ml
   if (h->cfg.task == PDS_TASK_HOVER) ok = launch_rollout_hover(h->flags, grid, (hipStream_t)stream, ra);
   else if (h->cfg.task == PDS_TASK_CIRCLE) ok = launch_rollout_circle(h->flags, grid, (hipStream_t)stream, ra);
   else ok = launch_rollout_takeoff(h->flags, grid, (hipStream_t)stream, ra);
-  if (!ok) return fail(h, PDS_EUNSUPPORTED, "pds_rollout: built for control_mode PWM without latency / hold / ground effect, "
+  if (!ok) return fail(h, PDS_EUNSUPPORTED, "pds_rollout: built without Kalman hold / ground effect, latency with control_mode PWM only, "
                                             "with {no, all of} domain randomisation + thrust noise + observation noise");
   PDS_HIP(h, hipGetLastError());
   h->tick += (uint64_t)T;

@@ -146,7 +146,8 @@ PDS_DEV U4 philox4x32_7(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint
 }
 
 PDS_DEV float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
-PDS_DEV float urange(uint32_t x, float lo, float hi) { return lo + (hi - lo) * u01(x); }
+PDS_DEV float urange_u(float u, float lo, float hi) { return lo + (hi - lo) * u; }  // u in [0, 1)
+PDS_DEV float urange(uint32_t x, float lo, float hi) { return urange_u(u01(x), lo, hi); }
 // Box-Muller on two Philox words, evaluated with the hardware transcendental units (v_log_f32,
 // v_sqrt_f32, v_sin_f32 / v_cos_f32 take their argument in revolutions): abs error ~1e-6 in z,
 // which is noise on a random variate.  The oracle restates the same formula with libm.

@@ -67,7 +67,9 @@ __device__ __forceinline__ void stage_net(const pds_mlp &m, const NetLds &n, int
 
 // Z^T tiles `it`, `it + 1` (16 output features x 16 samples each) = W[16 it .. +32][:] * In^T; In^T as NK register
 // tiles in the C/D layout (pds_mlp.hip gemm_wt2): two accumulation chains alternate.
-template <int NK>
+// LASTJ: k-steps of the LAST k-tile that carry data (pds_mlp.hip gemm_wt: step j of k-tile kt holds features
+// 16 kt + 4 h + j; with 50 hidden units or 34 inputs only j < 2 do) -- the skipped steps would add +0 * x.
+template <int NK, int LASTJ = 4>
 __device__ __forceinline__ void gemm_wt2(const float *Ws, int it, const f32x4 (&in)[NK], int n, int g, f32x4 &c0, f32x4 &c1) {
   c0 = (f32x4)(0.f);
   c1 = (f32x4)(0.f);
@@ -77,12 +79,14 @@ __device__ __forceinline__ void gemm_wt2(const float *Ws, int it, const f32x4 (&
     const f32x4 a0 = lds4(wp + kt * kTW), a1 = lds4(wp + kTW * kS + kt * kTW);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      c0 = PDS_MLPF_MFMA(a0[j], in[kt][j], c0);
-      c1 = PDS_MLPF_MFMA(a1[j], in[kt][j], c1);
+      if (kt < NK - 1 || j < LASTJ) {
+        c0 = PDS_MLPF_MFMA(a0[j], in[kt][j], c0);
+        c1 = PDS_MLPF_MFMA(a1[j], in[kt][j], c1);
+      }
     }
   }
 }
-template <int NK>
+template <int NK, int LASTJ = 4>
 __device__ __forceinline__ f32x4 gemm_wt(const float *Ws, int it, const f32x4 (&in)[NK], int n, int g) {
   f32x4 c = (f32x4)(0.f);
   const float *wp = Ws + (it * kTW + n) * kS + 4 * g;
@@ -90,19 +94,21 @@ __device__ __forceinline__ f32x4 gemm_wt(const float *Ws, int it, const f32x4 (&
   for (int kt = 0; kt < NK; ++kt) {
     const f32x4 a = lds4(wp + kt * kTW);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) c = PDS_MLPF_MFMA(a[j], in[kt][j], c);
+    for (int j = 0; j < 4; ++j)
+      if (kt < NK - 1 || j < LASTJ) c = PDS_MLPF_MFMA(a[j], in[kt][j], c);
   }
   return c;
 }
 
 // y^T = W3 act(W2 act(W1 x^T + b1) + b2) + b3 for the wave's 16 samples.  Lane (n = lane & 15, g = lane >> 4) passes
 // features 16 kt + 4 g + q of sample n in xin[kt][q] (already standardised, padding features 0) and receives
-// outputs 4 g + q of sample n (rows >= d_out: 0 + 0).
-template <int ACT, int NIN>
+// outputs 4 g + q of sample n (rows >= d_out: 0 + 0).  KJI / KJH: data-carrying k-steps of the last input / hidden
+// k-tile (4 = all; 2 for 34 inputs / 50 hidden units: the all-padding steps are not issued, same bits).
+template <int ACT, int NIN, int KJI = 4, int KJH = 4>
 __device__ __forceinline__ f32x4 forward16(const NetLds &w, const f32x4 (&xin)[NIN], int n, int g) {
   f32x4 h1r[kNT], h2r[kNT], cc[kNT];
 #pragma unroll
-  for (int it = 0; it < kNT; it += 2) gemm_wt2<NIN>(w.W1, it, xin, n, g, cc[it], cc[it + 1]);
+  for (int it = 0; it < kNT; it += 2) gemm_wt2<NIN, KJI>(w.W1, it, xin, n, g, cc[it], cc[it + 1]);
 #pragma unroll
   for (int it = 0; it < kNT; ++it) {
     const f32x4 b = lds4(w.b1 + it * kTW + 4 * g);
@@ -110,16 +116,109 @@ __device__ __forceinline__ f32x4 forward16(const NetLds &w, const f32x4 (&xin)[N
     for (int q = 0; q < 4; ++q) h1r[it][q] = act_fn<ACT>(cc[it][q] + b[q]);
   }
 #pragma unroll
-  for (int it = 0; it < kNT; it += 2) gemm_wt2<kNT>(w.W2, it, h1r, n, g, cc[it], cc[it + 1]);
+  for (int it = 0; it < kNT; it += 2) gemm_wt2<kNT, KJH>(w.W2, it, h1r, n, g, cc[it], cc[it + 1]);
 #pragma unroll
   for (int it = 0; it < kNT; ++it) {
     const f32x4 b = lds4(w.b2 + it * kTW + 4 * g);
 #pragma unroll
     for (int q = 0; q < 4; ++q) h2r[it][q] = act_fn<ACT>(cc[it][q] + b[q]);
   }
-  const f32x4 c = gemm_wt<kNT>(w.W3, 0, h2r, n, g);
+  const f32x4 c = gemm_wt<kNT, KJH>(w.W3, 0, h2r, n, g);
   const f32x4 b = lds4(w.b3 + 4 * g);
   return c + b;
+}
+
+// The same pass with the network's A operands (4 consecutive floats of a weight row per (output tile, k-tile): the
+// ds_read_b128 of gemm_wt) held in REGISTERS: a wave that evaluates the same network step after step (the actor of the
+// fused rollout, on the critical path of every step) reads them from LDS once -- the GEMMs become pure MFMA chains
+// instead of read -> wait -> 2 MFMAs.  (NIN + 4) x 4 + 4 f32x4 = 128-144 registers.  Same operation order, same bits.
+template <int NIN>
+struct NetRegs {
+  f32x4 w1[kNT][NIN], w2[kNT][kNT], w3[kNT];  // (the biases stay in LDS: 36 more registers spill the rollout's network waves)
+};
+template <int NIN>
+__device__ __forceinline__ void load_net_regs(const NetLds &w, int n, int g, NetRegs<NIN> &r) {
+#pragma unroll
+  for (int it = 0; it < kNT; ++it) {
+#pragma unroll
+    for (int kt = 0; kt < NIN; ++kt) r.w1[it][kt] = lds4(w.W1 + (it * kTW + n) * kS + 4 * g + kt * kTW);
+#pragma unroll
+    for (int kt = 0; kt < kNT; ++kt) r.w2[it][kt] = lds4(w.W2 + (it * kTW + n) * kS + 4 * g + kt * kTW);
+    r.w3[it] = lds4(w.W3 + n * kS + 4 * g + it * kTW);
+  }
+}
+template <int ACT, int NIN, int KJI, int KJH>
+__device__ __forceinline__ f32x4 forward16_regs(const NetRegs<NIN> &r, const NetLds &w, const f32x4 (&xin)[NIN], int n, int g) {
+  f32x4 h1r[kNT], h2r[kNT], cc[kNT];
+#pragma unroll
+  for (int it = 0; it < kNT; it += 2) {  // (gemm_wt2: two accumulation chains alternate)
+    f32x4 c0 = (f32x4)(0.f), c1 = (f32x4)(0.f);
+#pragma unroll
+    for (int kt = 0; kt < NIN; ++kt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (kt < NIN - 1 || j < KJI) {
+          c0 = PDS_MLPF_MFMA(r.w1[it][kt][j], xin[kt][j], c0);
+          c1 = PDS_MLPF_MFMA(r.w1[it + 1][kt][j], xin[kt][j], c1);
+        }
+    cc[it] = c0; cc[it + 1] = c1;
+  }
+#pragma unroll
+  for (int it = 0; it < kNT; ++it) {
+    const f32x4 b = lds4(w.b1 + it * kTW + 4 * g);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) h1r[it][q] = act_fn<ACT>(cc[it][q] + b[q]);
+  }
+#pragma unroll
+  for (int it = 0; it < kNT; it += 2) {
+    f32x4 c0 = (f32x4)(0.f), c1 = (f32x4)(0.f);
+#pragma unroll
+    for (int kt = 0; kt < kNT; ++kt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (kt < kNT - 1 || j < KJH) {
+          c0 = PDS_MLPF_MFMA(r.w2[it][kt][j], h1r[kt][j], c0);
+          c1 = PDS_MLPF_MFMA(r.w2[it + 1][kt][j], h1r[kt][j], c1);
+        }
+    cc[it] = c0; cc[it + 1] = c1;
+  }
+#pragma unroll
+  for (int it = 0; it < kNT; ++it) {
+    const f32x4 b = lds4(w.b2 + it * kTW + 4 * g);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) h2r[it][q] = act_fn<ACT>(cc[it][q] + b[q]);
+  }
+  f32x4 c = (f32x4)(0.f);
+#pragma unroll
+  for (int kt = 0; kt < kNT; ++kt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (kt < kNT - 1 || j < KJH) c = PDS_MLPF_MFMA(r.w3[kt][j], h2r[kt][j], c);
+  return c + lds4(w.b3 + 4 * g);
+}
+template <int ACT, int NIN>
+__device__ __forceinline__ f32x4 forward16_regs_shape(const NetRegs<NIN> &r, const NetLds &w, const pds_mlp &m, const f32x4 (&xin)[NIN], int n, int g);
+
+// run-time shape -> the instantiation with the fewest k-steps (data steps of the last k-tile of a dimension `dim`
+// that spans `tiles` 16-wide tiles; 4 when the tile is full or the dimension ends in an earlier tile)
+__device__ __forceinline__ int last_tile_steps(int dim, int tiles) {
+  const int rest = dim - 16 * (tiles - 1);  // features in the last tile
+  return (rest >= 1 && rest <= 2) ? 2 : 4;  // (1-2 features: lane group 0, steps 0-1; 3-4 would be 4 steps: 4 h + j < rest)
+}
+template <int ACT, int NIN>
+__device__ __forceinline__ f32x4 forward16_shape(const NetLds &w, const pds_mlp &m, const f32x4 (&xin)[NIN], int n, int g) {
+  const bool ki2 = last_tile_steps(m.d_in, NIN) == 2;
+  const bool kh2 = m.h1 == m.h2 && last_tile_steps(m.h1, kNT) == 2;
+  if (kh2) return ki2 ? forward16<ACT, NIN, 2, 2>(w, xin, n, g) : forward16<ACT, NIN, 4, 2>(w, xin, n, g);
+  return ki2 ? forward16<ACT, NIN, 2, 4>(w, xin, n, g) : forward16<ACT, NIN, 4, 4>(w, xin, n, g);
+}
+
+template <int ACT, int NIN>
+__device__ __forceinline__ f32x4 forward16_regs_shape(const NetRegs<NIN> &r, const NetLds &w, const pds_mlp &m, const f32x4 (&xin)[NIN], int n, int g) {
+  const bool ki2 = last_tile_steps(m.d_in, NIN) == 2;
+  const bool kh2 = m.h1 == m.h2 && last_tile_steps(m.h1, kNT) == 2;
+  if (kh2) return ki2 ? forward16_regs<ACT, NIN, 2, 2>(r, w, xin, n, g) : forward16_regs<ACT, NIN, 4, 2>(r, w, xin, n, g);
+  return ki2 ? forward16_regs<ACT, NIN, 2, 4>(r, w, xin, n, g) : forward16_regs<ACT, NIN, 4, 4>(r, w, xin, n, g);
 }
 
 }  // namespace pds_mlpf

@@ -26,6 +26,30 @@ constexpr int kResetNoiseBlocks = 2 * kObsCallBlocks;  // two add_noise calls
 constexpr int kLatRowBlocks = kMaxLatSteps - 1;        // one block (4 normals) per extra action-buffer row
 constexpr int kScratchBlocks = kResetBlocks + kResetNoiseBlocks + kLatRowBlocks;
 
+// The standard variates of one Philox block, by the block's role.  One set of conversion functions serves every
+// source below, so a reset draws the same floats whether its blocks are converted by the resetting thread or, side by
+// side, by the lanes that computed them (LdsVariates).
+PDS_DEV void words_to_uniforms4(const U4 &w, float (&u)[4]) {  // 24-bit uniforms in [0, 1)
+  u[0] = u01(w.x); u[1] = u01(w.y); u[2] = u01(w.z); u[3] = u01(w.w);
+}
+PDS_DEV void words_to_normals4(const U4 &w, float (&z)[4]) {   // two full-precision Box-Muller pairs
+  box_muller(w.x, w.y, z[0], z[1]);
+  box_muller(w.z, w.w, z[2], z[3]);
+}
+// block b (0..2) of one add_noise call: words 0..8 of the call -> 18 normals (one Box-Muller pair per word), words
+// 9..11 -> 6 uniforms (16 bits each); f[2 i], f[2 i + 1] = the pair of word i of the block
+PDS_DEV void words_to_noise8(const U4 &w, int b, float (&f)[8]) {
+  const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float z0, z1;
+    box_muller_word(ww[i], z0, z1);
+    const bool uni = b == 2 && i > 0;
+    f[2 * i] = uni ? u01_lo16(ww[i]) : z0;
+    f[2 * i + 1] = uni ? u01_hi16(ww[i]) : z1;
+  }
+}
+
 struct DirectWords {
   uint32_t env_id, tick_lo, tick_hi, seed_lo, seed_hi;
   PDS_DEV DirectWords(uint32_t id, const RngKey &r) : env_id(id), tick_lo(r.tick_lo), tick_hi(r.tick_hi), seed_lo(r.seed_lo), seed_hi(r.seed_hi) {}
@@ -41,13 +65,50 @@ struct DirectWords {
                                   : kBlkLatRows + (uint32_t)(j - kResetBlocks - kResetNoiseBlocks));
     return philox4x32_10_or_7(env_id, tick_lo, tick_hi, blk, seed_lo, seed_hi, noise);
   }
+  PDS_DEV void uniforms4(uint32_t b, float (&u)[4]) const { words_to_uniforms4(reset_block(b), u); }
+  PDS_DEV U4 raw4(uint32_t b) const { return reset_block(b); }
+  PDS_DEV void normals4(uint32_t b, float (&z)[4]) const { words_to_normals4(reset_block(b), z); }
+  PDS_DEV void lat_normals4(uint32_t r, float (&z)[4]) const { words_to_normals4(lat_block(r), z); }
+  PDS_DEV void noise8(uint32_t nb, float (&f)[8]) const { words_to_noise8(noise_block(nb), (int)(nb % (uint32_t)kObsCallBlocks), f); }
 };
 struct LdsWords {
   const U4 *slot;  // [kScratchBlocks]
   PDS_DEV U4 reset_block(uint32_t b) const { return slot[b]; }
   PDS_DEV U4 noise_block(uint32_t b) const { return slot[kResetBlocks + b]; }
   PDS_DEV U4 lat_block(uint32_t r) const { return slot[kResetBlocks + kResetNoiseBlocks + r]; }
+  PDS_DEV void uniforms4(uint32_t b, float (&u)[4]) const { words_to_uniforms4(reset_block(b), u); }
+  PDS_DEV U4 raw4(uint32_t b) const { return reset_block(b); }
+  PDS_DEV void normals4(uint32_t b, float (&z)[4]) const { words_to_normals4(reset_block(b), z); }
+  PDS_DEV void lat_normals4(uint32_t r, float (&z)[4]) const { words_to_normals4(lat_block(r), z); }
+  PDS_DEV void noise8(uint32_t nb, float (&f)[8]) const { words_to_noise8(noise_block(nb), (int)(nb % (uint32_t)kObsCallBlocks), f); }
 };
+// Round 4: the blocks of a reset already CONVERTED, by the lanes that computed them (fill_reset_variates): the thread
+// that evaluates the reset reads floats.  Per env: reset blocks 0..8 four floats each (block 6 -- it carries the
+// integer draw of ref_offset -- as raw words), the six noise blocks eight floats each, the latency rows four each.
+constexpr int kVarResetFloats = 4 * kResetBlocks;
+constexpr int kVarNoiseFloats = 8 * kResetNoiseBlocks;
+struct LdsVariates {
+  const float *p;
+  PDS_DEV void uniforms4(uint32_t b, float (&u)[4]) const {
+    const float4 v = *reinterpret_cast<const float4 *>(p + 4 * b);
+    u[0] = v.x; u[1] = v.y; u[2] = v.z; u[3] = v.w;
+  }
+  PDS_DEV U4 raw4(uint32_t b) const {
+    const uint4 v = *reinterpret_cast<const uint4 *>(p + 4 * b);
+    return U4{v.x, v.y, v.z, v.w};
+  }
+  PDS_DEV void normals4(uint32_t b, float (&z)[4]) const { uniforms4(b, z); }
+  PDS_DEV void lat_normals4(uint32_t r, float (&z)[4]) const {
+    const float4 v = *reinterpret_cast<const float4 *>(p + kVarResetFloats + kVarNoiseFloats + 4 * r);
+    z[0] = v.x; z[1] = v.y; z[2] = v.z; z[3] = v.w;
+  }
+  PDS_DEV void noise8(uint32_t nb, float (&f)[8]) const {
+    const float4 a = *reinterpret_cast<const float4 *>(p + kVarResetFloats + 8 * nb);
+    const float4 b = *reinterpret_cast<const float4 *>(p + kVarResetFloats + 8 * nb + 4);
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+  }
+};
+constexpr int kRawWordsBlock = 6;  // ref_offset = mulhi(word 3, num_ref_points): kept as integers
 
 // number of leading scratch slots a variant can touch (bounds the cooperative fill loop)
 template <class V>
@@ -81,42 +142,37 @@ PDS_DEV void sample_philox(const Consts &k, const SRC &src, Sample &s) {
   } else {
     pos_lim = 0.25f; rp_lim = 0.f; yaw_lim = kPi; vel_lim = 0.f; w_lim = 0.f; wz_lim = 0.f;
   }
-  const U4 r0 = src.reset_block(0u);
-  const U4 r1 = src.reset_block(1u);
-  s.pos[0] = urange(r0.x, -pos_lim, pos_lim);
-  s.pos[1] = urange(r0.y, -pos_lim, pos_lim);
-  s.pos[2] = (TASK == PDS_TASK_TAKEOFF) ? 0.f : urange(r0.z, -pos_lim, pos_lim);
-  s.rpy[0] = urange(r0.w, -rp_lim, rp_lim);
-  s.rpy[1] = urange(r1.x, -rp_lim, rp_lim);
-  s.rpy[2] = urange(r1.y, -yaw_lim, yaw_lim);
-  s.vel[0] = urange(r1.z, -vel_lim, vel_lim);
-  s.vel[1] = urange(r1.w, -vel_lim, vel_lim);
+  float u0[4], u1[4];
+  src.uniforms4(0u, u0);
+  src.uniforms4(1u, u1);
+  s.pos[0] = urange_u(u0[0], -pos_lim, pos_lim);
+  s.pos[1] = urange_u(u0[1], -pos_lim, pos_lim);
+  s.pos[2] = (TASK == PDS_TASK_TAKEOFF) ? 0.f : urange_u(u0[2], -pos_lim, pos_lim);
+  s.rpy[0] = urange_u(u0[3], -rp_lim, rp_lim);
+  s.rpy[1] = urange_u(u1[0], -rp_lim, rp_lim);
+  s.rpy[2] = urange_u(u1[1], -yaw_lim, yaw_lim);
+  s.vel[0] = urange_u(u1[2], -vel_lim, vel_lim);
+  s.vel[1] = urange_u(u1[3], -vel_lim, vel_lim);
   if (TASK != PDS_TASK_TAKEOFF) {
-    const U4 r2 = src.reset_block(2u);
-    const U4 r3 = src.reset_block(3u);
-    const U4 r4 = src.reset_block(4u);
-    s.vel[2] = urange(r2.x, -vel_lim, vel_lim);
-    s.w[0] = urange(r2.y, -w_lim, w_lim);
-    s.w[1] = urange(r2.z, -w_lim, w_lim);
-    s.w[2] = urange(r2.w, -wz_lim, wz_lim);
-    float z[8];
-    box_muller(r3.x, r3.y, z[0], z[1]);
-    box_muller(r3.z, r3.w, z[2], z[3]);
-    box_muller(r4.x, r4.y, z[4], z[5]);
-    box_muller(r4.z, r4.w, z[6], z[7]);
+    float u2[4], z3[4], z4[4];
+    src.uniforms4(2u, u2);
+    src.normals4(3u, z3);
+    src.normals4(4u, z4);
+    s.vel[2] = urange_u(u2[0], -vel_lim, vel_lim);
+    s.w[0] = urange_u(u2[1], -w_lim, w_lim);
+    s.w[1] = urange_u(u2[2], -w_lim, w_lim);
+    s.w[2] = urange_u(u2[3], -wz_lim, wz_lim);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      s.mx[i] = k.hover_x + 0.02f * z[i];
-      s.act[i] = k.hover_action + 0.02f * z[4 + i];
+      s.mx[i] = k.hover_x + 0.02f * z3[i];
+      s.act[i] = k.hover_action + 0.02f * z4[i];
     }
     if constexpr (V::LAT) {  // the other rows of np.random.normal(HOVER_ACTION, 0.02, (buf_size, 4)), hover.py:226-228
 #pragma unroll
       for (int r = 0; r < kMaxLatSteps - 1; ++r) {
         if (r < k.lat_steps - 1) {
-          const U4 w = src.lat_block((uint32_t)r);
           float y[4];
-          box_muller(w.x, w.y, y[0], y[1]);
-          box_muller(w.z, w.w, y[2], y[3]);
+          src.lat_normals4((uint32_t)r, y);
 #pragma unroll
           for (int i = 0; i < 4; ++i) s.abuf[r][i] = k.hover_action + 0.02f * y[i];
         }
@@ -130,23 +186,25 @@ PDS_DEV void sample_philox(const Consts &k, const SRC &src, Sample &s) {
   s.ref_offset = 0;
   if (V::DR || TASK == PDS_TASK_CIRCLE) {
     const float f = k.dr;
-    const U4 r5 = src.reset_block(5u);
-    const U4 r6 = src.reset_block(6u);
-#define PDS_DRV(x, d) urange((x), (d) - f * (d), (d) + f * (d))
-    s.dt = PDS_DRV(r5.x, k.dt_nom);
-    s.m = PDS_DRV(r5.y, k.M_nom);
-    s.J[0] = PDS_DRV(r5.z, k.Jx_nom);
-    s.J[1] = PDS_DRV(r5.w, k.Jy_nom);
-    s.J[2] = PDS_DRV(r6.x, k.Jz_nom);
-    s.ftf1 = PDS_DRV(r6.z, k.ftf1_nom);
+    float u5[4];
+    src.uniforms4(5u, u5);
+    const U4 r6 = src.raw4((uint32_t)kRawWordsBlock);
+#define PDS_DRV(u, d) urange_u((u), (d) - f * (d), (d) + f * (d))
+    s.dt = PDS_DRV(u5[0], k.dt_nom);
+    s.m = PDS_DRV(u5[1], k.M_nom);
+    s.J[0] = PDS_DRV(u5[2], k.Jx_nom);
+    s.J[1] = PDS_DRV(u5[3], k.Jy_nom);
+    s.J[2] = PDS_DRV(u01(r6.x), k.Jz_nom);
+    s.ftf1 = PDS_DRV(u01(r6.z), k.ftf1_nom);
     s.ref_offset = (int)__umulhi(r6.w, (uint32_t)k.ref_points);  // randint(0, num_ref_points), circle.py:225
     if (V::MOTOR && V::DR) {
-      const U4 r7 = src.reset_block(7u);
-      const U4 r8 = src.reset_block(8u);
-      s.T[0] = PDS_DRV(r7.x, k.mtc); s.T[1] = PDS_DRV(r7.y, k.mtc);
-      s.T[2] = PDS_DRV(r7.z, k.mtc); s.T[3] = PDS_DRV(r7.w, k.mtc);
-      s.t2w[0] = PDS_DRV(r8.x, k.t2w); s.t2w[1] = PDS_DRV(r8.y, k.t2w);
-      s.t2w[2] = PDS_DRV(r8.z, k.t2w); s.t2w[3] = PDS_DRV(r8.w, k.t2w);
+      float u7[4], u8[4];
+      src.uniforms4(7u, u7);
+      src.uniforms4(8u, u8);
+      s.T[0] = PDS_DRV(u7[0], k.mtc); s.T[1] = PDS_DRV(u7[1], k.mtc);
+      s.T[2] = PDS_DRV(u7[2], k.mtc); s.T[3] = PDS_DRV(u7[3], k.mtc);
+      s.t2w[0] = PDS_DRV(u8[0], k.t2w); s.t2w[1] = PDS_DRV(u8[1], k.t2w);
+      s.t2w[2] = PDS_DRV(u8[2], k.t2w); s.t2w[3] = PDS_DRV(u8[3], k.t2w);
     }
 #undef PDS_DRV
   }
@@ -177,39 +235,36 @@ PDS_DEV void sample_load(const float *row, Sample &s) {
 // ---- sensor noise -------------------------------------------------------------------------------
 // 24 standard variates of one add_noise call from three Philox blocks: words 0..8 -> 18 normals
 // (one Box-Muller pair per word), words 9..11 -> 6 uniforms (16 bits each).
-PDS_DEV void obs_noise_from_words(const uint32_t w[12], ObsNoise &n) {
+// (f0, f1, f2: the three blocks of the call as words_to_noise8 converts them)
+PDS_DEV void obs_noise_from_blocks(const float (&f0)[8], const float (&f1)[8], const float (&f2)[8], ObsNoise &n) {
   float z[18];
 #pragma unroll
-  for (int p = 0; p < 9; ++p) box_muller_word(w[p], z[2 * p], z[2 * p + 1]);
+  for (int i = 0; i < 8; ++i) { z[i] = f0[i]; z[8 + i] = f1[i]; }
+  z[16] = f2[0]; z[17] = f2[1];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     n.pos_z[i] = z[i]; n.vel_z[i] = z[3 + i]; n.bias_z[i] = z[6 + i];
     n.rw_z[i] = z[9 + i]; n.to_z[i] = z[12 + i]; n.th_z[i] = z[15 + i];
   }
-  n.pos_u[0] = u01_lo16(w[9]);  n.pos_u[1] = u01_hi16(w[9]);
-  n.pos_u[2] = u01_lo16(w[10]); n.th_u[0] = u01_hi16(w[10]);
-  n.th_u[1] = u01_lo16(w[11]);  n.th_u[2] = u01_hi16(w[11]);
+  n.pos_u[0] = f2[2]; n.pos_u[1] = f2[3];
+  n.pos_u[2] = f2[4]; n.th_u[0] = f2[5];
+  n.th_u[1] = f2[6]; n.th_u[2] = f2[7];
 }
 
 PDS_DEV void obs_noise_philox(uint32_t env_id, const RngKey &a, uint32_t blk0, ObsNoise &n) {
-  uint32_t w[12];
+  float f[kObsCallBlocks][8];
 #pragma unroll
-  for (int b = 0; b < kObsCallBlocks; ++b) {
-    const U4 r = philox4x32_7(env_id, a.tick_lo, a.tick_hi, blk0 + (uint32_t)b, a.seed_lo, a.seed_hi);
-    w[4 * b] = r.x; w[4 * b + 1] = r.y; w[4 * b + 2] = r.z; w[4 * b + 3] = r.w;
-  }
-  obs_noise_from_words(w, n);
+  for (int b = 0; b < kObsCallBlocks; ++b)
+    words_to_noise8(philox4x32_7(env_id, a.tick_lo, a.tick_hi, blk0 + (uint32_t)b, a.seed_lo, a.seed_hi), b, f[b]);
+  obs_noise_from_blocks(f[0], f[1], f[2], n);
 }
 
 template <class SRC>
 PDS_DEV void obs_noise_reset(const SRC &src, int call, ObsNoise &n) {
-  uint32_t w[12];
+  float f[kObsCallBlocks][8];
 #pragma unroll
-  for (int b = 0; b < kObsCallBlocks; ++b) {
-    const U4 r = src.noise_block((uint32_t)(kObsCallBlocks * call + b));
-    w[4 * b] = r.x; w[4 * b + 1] = r.y; w[4 * b + 2] = r.z; w[4 * b + 3] = r.w;
-  }
-  obs_noise_from_words(w, n);
+  for (int b = 0; b < kObsCallBlocks; ++b) src.noise8((uint32_t)(kObsCallBlocks * call + b), f[b]);
+  obs_noise_from_blocks(f[0], f[1], f[2], n);
 }
 
 PDS_DEV void obs_noise_load(const float *p, ObsNoise &n) {
@@ -572,6 +627,63 @@ PDS_DEV void fill_reset_scratch(const StepArgs &a, const RngKey &rk, const uint3
 #pragma unroll
     for (int c = 0; c < NB; ++c) need = need || (c == j && block_needed<V>(c));
     if (on && need) scratch[slot * STRIDE + j] = dw.scratch_block(j);
+  }
+}
+
+// Floats per env of the converted scratch (LdsVariates layout)
+template <class V>
+constexpr int variates_floats() {
+  return V::LAT ? kVarResetFloats + kVarNoiseFloats + 4 * kLatRowBlocks : (V::ON ? kVarResetFloats + kVarNoiseFloats : kVarResetFloats);
+}
+
+// fill_reset_scratch + conversion: lane j of an env's group computes Philox block j AND turns its four words into the
+// standard variates of the block's role (words_to_*), so that the one or two lanes that evaluate the reset read floats
+// instead of running ~20 Box-Muller pairs and ~30 uniform conversions in a row (~260 of the ~1100 vector instructions
+// of a reset with observation noise).  `var`: [envs of the pass][variates_floats<V>()].
+template <class V>
+PDS_DEV void fill_reset_variates(const StepArgs &a, const RngKey &rk, const uint32_t *entries, int cnt, int lane,
+                                 long long wave_base, float *var) {
+  constexpr int NB = scratch_blocks_used<V>();
+  constexpr int L = NB <= 8 ? 8 : (NB <= 16 ? 16 : 32);  // lanes per env in a Philox round
+  constexpr int EPR = kWave / L;                           // envs per Philox round
+  constexpr int VF = variates_floats<V>();
+  const int g = lane / L, j = lane % L;
+  for (int sub = 0; sub < cnt; sub += EPR) {
+    const int slot = sub + g;  // env of the pass this lane computes a block for
+    const bool on = slot < cnt;
+    uint32_t ent = 0;
+    if (on) ent = entries[slot];
+    const uint32_t env_id = (uint32_t)(a.env_id_base + (unsigned long long)(wave_base + (long long)(ent & 63u)));
+    const DirectWords dw(env_id, rk);
+    bool need = false;
+#pragma unroll
+    for (int c = 0; c < NB; ++c) need = need || (c == j && block_needed<V>(c));
+    if (on && need) {
+      const U4 w = dw.scratch_block(j);
+      float *dst = var + slot * VF;
+      if (j < kResetBlocks) {
+        float f[4];
+        if (j == 3 || j == 4) {
+          words_to_normals4(w, f);
+        } else if (j == kRawWordsBlock) {
+          f[0] = __uint_as_float(w.x); f[1] = __uint_as_float(w.y); f[2] = __uint_as_float(w.z); f[3] = __uint_as_float(w.w);
+        } else {
+          words_to_uniforms4(w, f);
+        }
+        *reinterpret_cast<float4 *>(dst + 4 * j) = make_float4(f[0], f[1], f[2], f[3]);
+      } else if (j < kResetBlocks + kResetNoiseBlocks) {
+        const int nb = j - kResetBlocks;
+        float f[8];
+        words_to_noise8(w, nb % kObsCallBlocks, f);
+        *reinterpret_cast<float4 *>(dst + kVarResetFloats + 8 * nb) = make_float4(f[0], f[1], f[2], f[3]);
+        *reinterpret_cast<float4 *>(dst + kVarResetFloats + 8 * nb + 4) = make_float4(f[4], f[5], f[6], f[7]);
+      } else {
+        float f[4];
+        words_to_normals4(w, f);
+        *reinterpret_cast<float4 *>(dst + kVarResetFloats + kVarNoiseFloats + 4 * (j - kResetBlocks - kResetNoiseBlocks)) =
+            make_float4(f[0], f[1], f[2], f[3]);
+      }
+    }
   }
 }
 

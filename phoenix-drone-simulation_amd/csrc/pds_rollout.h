@@ -10,23 +10,27 @@
 // stepped the envs, then evaluated V(final_obs): 17 us per step, 7.5 of them one wave's env step with three waves idle
 // at the barrier, and one tile per CU (101 KB of LDS, most of it the two weight images).
 //
-// Round 4 -- wave roles, no block barrier inside the loop.  A 384-thread block serves TWO tiles with ONE copy of the
-// weights:
-//   M0..M3 (network waves, 16 rows of EACH tile, v_mfma_f32_16x16x4_f32 through csrc/pds_mlp_fwd.h -- the code path of
-//           pds_mlp_forward, same bits):   per tile: wait for o(t) -> read their rows into registers -> actor -> sample ->
-//           action into LDS, SIGNAL; then, for both tiles, the critic V(o(t)) and V(final_obs) of the envs that
+// Round 4 -- wave roles, no block barrier inside the loop.  320 threads per tile:
+//   M0..M3 (network waves, rows 16 w .. 16 w + 15, v_mfma_f32_16x16x4_f32 through csrc/pds_mlp_fwd.h -- the code path of
+//           pds_mlp_forward, same bits):   wait for o(t) -> read their rows into registers -> actor -> sample ->
+//           action into LDS, SIGNAL; then, while the env wave steps: the critic V(o(t)) and V(final_obs) of the envs that
 //           finished in step t - 1;
-//   E0, E1 (one env wave per tile, its 64 envs in registers, step_once of csrc/pds_step.h -- the code path of pds_step /
+//   E      (wave 4: the 64 envs of the tile in registers, step_once of csrc/pds_step.h -- the code path of pds_step /
 //           pds_step_k, same bits):        wait for the four action signals -> env.step -> o(t + 1), the finished
 //           envs' last rows and flags into LDS, SIGNAL.
-// Only the actor is on the critical path of a step (action -> env step -> next observation): the critic, the
-// TimeLimit bootstrap V(final_obs) (algs/iwpg/iwpg.py:375-385) and all buffer writes of the network waves run while
-// the env waves step.  Six waves per block leave every wave 256 registers (the env step of the noise variants needs
-// ~250; a first version with five waves per tile, ten per block, was capped at 168 and spilled 37-56 registers inside
-// the step: 21.7 us per step against 17.7 for round 3's kernel).  Hand-over through monotonic counters in LDS
-// (release / acquire, s_sleep loop; all six waves of a block are resident together, so the waits cannot deadlock);
-// every LDS image has exactly one writer role, and every reader finishes with it before it posts the signal its
-// writer waits for.
+// Only the actor is on the critical path of a step (action -> env step -> next observation); the critic, the TimeLimit
+// bootstrap V(final_obs) (algs/iwpg/iwpg.py:375-385), the action-noise draws of the NEXT step and all buffer writes of
+// the network waves run while the env wave steps.  Measured and kept out: the critic as one pds_mlp_forward over
+// obs_buf after the kernel (0.97 vs 0.91 ms at 8 192 x 64), the actor's weight operands resident in registers
+// (forward16_regs of csrc/pds_mlp_fwd.h: no change, 14.0 us per step either way -- the pass is a dependent chain of
+// 110 MFMAs + epilogues, not LDS-bound).
+// Waves w and w + 4 of a block share a SIMD (profiles/r03_mlp_microbench.txt), and a wave that
+// streams MFMAs halves the vector-ALU rate of its SIMD-mate (a first version with two tiles per block, every env wave
+// next to a busy network wave: 23 us per step against 17.7 for round 3's kernel), so M0 -- the env wave's mate -- only
+// works while E waits: its rows' critic pass is taken by M1, their V(final_obs) by M2.
+// Hand-over through monotonic counters in LDS (release / acquire, s_sleep loop; all five waves of a block are resident
+// together, so the waits cannot deadlock); every LDS image has exactly one writer role, and every reader finishes with
+// it before it posts the signal its writer waits for.
 //
 // Envs are independent, the policy is frozen during a rollout and the running observation statistics are only
 // updated after it (ppo.py), so a tile needs nothing from another tile for all T steps.
@@ -39,8 +43,9 @@ namespace pds {
 #ifndef PDS_ROLLOUT_SKIP
 #define PDS_ROLLOUT_SKIP 0  // profiling builds only: 1 = no actor / critic passes, 2 = no env step, 4 = no V(final_obs)
 #endif
-constexpr int kRolloutMlpWaves = 4;               // network waves per block (16 rows of every tile each)
-constexpr int kRolloutThreads = kWave * (kRolloutMlpWaves + kRolloutTiles);  // + one env wave per tile
+constexpr int kRolloutMlpWaves = 4;               // network waves per block (16 rows of the tile each)
+constexpr int kRolloutThreads = kWave * (kRolloutMlpWaves + 1);  // + the env wave
+static_assert(kRolloutTiles == 1, "one tile per block (pds_api.hip sizes the grid with kRolloutTiles)");
 
 // network input of this lane: features 16 kt + 4 g + q of row `r` of an LDS image with row stride `stride`
 template <int NIN>
@@ -159,9 +164,14 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void rollout_kernel(const Rollo
       const long long o1 = (long long)s * rl.s.n;
       rollout_wait_ge(&act_ready[grp], kRolloutMlpWaves * (s + 1));  // the network waves have read o(s) and written a(s)
       if (!(PDS_ROLLOUT_SKIP & 2)) {
-        const float4 act = act_all[grp][lane];
+        // (opaque per-iteration copies of the seed and the lane index: see step_k_kernel -- their loop-invariant
+        //  derivatives would otherwise be formed in the loop header and spilled)
+        RngKey rks = rk;
+        int lane_s = lane;
+        if (PDS_STEPK_OPAQUE_KEY) asm volatile("" : "+s"(rks.seed_lo), "+s"(rks.seed_hi), "+v"(lane_s));
+        const float4 act = act_all[grp][lane_s];
         StepOut so;
-        step_once<V, kWave, RM, false>(rl.s, o1, rk, parity, nullptr, tile, nullptr, queue_all[grp], scratch_all[grp], lane,
+        step_once<V, kWave, RM, false>(rl.s, o1, rks, parity, nullptr, tile, nullptr, queue_all[grp], scratch_all[grp], lane_s,
                                        wave_base, ix, active, act, S, qcount, fin, &so PDS_STAMP_ARG);
         parity ^= 1;
         rk.tick_lo += 1u;
@@ -192,89 +202,107 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void rollout_kernel(const Rollo
     return;
   }
 
-  // ================================ network waves: 16 rows of every tile each ==================================
-  const int r16 = wave * 16 + n16;  // this lane's sample row in the tiles
+  // ================================ network waves: 16 rows of the tile each ====================================
+  // rows 16 w .. 16 w + 15 are wave w's; the critic of wave 0's rows runs on wave 1 and their V(final_obs) on wave 2
+  // (wave 0 shares its SIMD with the env wave: it only works while that one waits).
+  constexpr int j = 0;
+  const int rows = tile_rows(j);
+  const int own = wave * 16 + n16;  // this lane's sample row
+  const bool own_ok = own < rows, r0_ok = n16 < rows;
+  const long long env_own = tile0 * kWave + own, env_r0 = tile0 * kWave + n16;
   for (int s = 0; s <= T; ++s) {  // s == T: only V(o(T)) and the last step's V(final_obs)
     const RolloutArgs &rl = *reinterpret_cast<const RolloutArgs *>(&reload_args<203, true>(ra.s, s));
     const long long o1 = (long long)s * rl.s.n;
-    f32x4 xin[kRolloutTiles][NIN], xfin[kRolloutTiles][NIN];
-    bool dn[kRolloutTiles], any_dn[kRolloutTiles];
-    // ---- the critical path first: both tiles' actions -------------------------------------------------------
+    f32x4 x_own[NIN], x_r0[NIN], f_own[NIN], f_r0[NIN];
+    // the action noise of step s depends on (env, call) only: drawn while the env wave is still stepping
+    // pds_gaussian_sample (csrc/pds_train.hip sample_kernel): counter = (sample id lo, id hi << 8 | block, call lo, call hi)
+    float z[4] = {0.f, 0.f, 0.f, 0.f}, sig[4], lsd[4];
+    if (s < T && g == 0) {
+      if (!rl.deterministic) {
+        const unsigned long long gid = rl.s.env_id_base + (unsigned long long)env_own;
+        const unsigned long long call = call0 + (unsigned long long)s + 1ull;
+        const U4 r = philox4x32_10((uint32_t)gid, ((uint32_t)(gid >> 32) << 8) | 0u, (uint32_t)call, (uint32_t)(call >> 32),
+                                   (uint32_t)rl.seed, (uint32_t)(rl.seed >> 32));
+        box_muller(r.x, r.y, z[0], z[1]);
+        box_muller(r.z, r.w, z[2], z[3]);
+      }
 #pragma unroll
-    for (int j = 0; j < kRolloutTiles; ++j) {
-      const int rows = tile_rows(j);  // wave-uniform
-      dn[j] = false; any_dn[j] = false;
-      if (rows == 0) continue;
-      const bool row_ok = r16 < rows;
-      const long long env16 = (tile0 + j) * kWave + r16;
-      rollout_wait_ge(&obs_ready[j], s);  // o(s) and the outcome of step s - 1 are in LDS
-      gather_input<NIN>(tile_all[j], TS, r16, D, mus, iss, g, xin[j]);
-      dn[j] = done_all[j][r16] != 0u;                                            // (step s - 1; zeros before the first step)
-      any_dn[j] = __ballot(dn[j]) != 0ull && !(PDS_ROLLOUT_SKIP & 4);            // wave-uniform: one of this wave's 16 envs finished
-      if (any_dn[j]) gather_input<NIN>(fin_all[j], D, r16, D, mus, iss, g, xfin[j]);
-      if (s == T) continue;
+      for (int q = 0; q < 4; ++q) {
+        lsd[q] = (q < d_out) ? rl.log_std[q] : 0.f;
+        sig[q] = expf(lsd[q]);
+      }
+    }
+    rollout_wait_ge(&obs_ready[j], s);  // o(s) and the outcome of step s - 1 are in LDS
+    gather_input<NIN>(tile_all[j], TS, own, D, mus, iss, g, x_own);
+    if (wave == 1) gather_input<NIN>(tile_all[j], TS, n16, D, mus, iss, g, x_r0);
+    const bool skip_fin = (PDS_ROLLOUT_SKIP & 4) != 0;
+    const bool dn_own = done_all[j][own] != 0u;                                   // (step s - 1; zeros before the first step)
+    const bool any_own = wave != 0 && __ballot(dn_own) != 0ull && !skip_fin;      // wave-uniform: one of these 16 envs finished
+    const bool dn_r0 = done_all[j][n16] != 0u;
+    const bool any_r0 = wave == 2 && __ballot(dn_r0) != 0ull && !skip_fin;
+    if (any_own) gather_input<NIN>(fin_all[j], D, own, D, mus, iss, g, f_own);
+    if (any_r0) gather_input<NIN>(fin_all[j], D, n16, D, mus, iss, g, f_r0);
+    if (s < T) {
       if (!(PDS_ROLLOUT_SKIP & 1)) {
-        const f32x4 mu = (rl.pi.activation == 0) ? forward16<0, NIN>(wpi, xin[j], n16, g) : forward16<1, NIN>(wpi, xin[j], n16, g);
-        if (g == 0) {  // lane n16 owns sample r16: outputs 0..3 of the actor
-          // pds_gaussian_sample (csrc/pds_train.hip sample_kernel): counter = (sample id lo, id hi << 8 | block, call lo, call hi)
-          float z[4] = {0.f, 0.f, 0.f, 0.f};
-          if (!rl.deterministic) {
-            const unsigned long long gid = rl.s.env_id_base + (unsigned long long)env16;
-            const unsigned long long call = call0 + (unsigned long long)s + 1ull;
-            const U4 r = philox4x32_10((uint32_t)gid, ((uint32_t)(gid >> 32) << 8) | 0u, (uint32_t)call, (uint32_t)(call >> 32),
-                                       (uint32_t)rl.seed, (uint32_t)(rl.seed >> 32));
-            box_muller(r.x, r.y, z[0], z[1]);
-            box_muller(r.z, r.w, z[2], z[3]);
-          }
+        const f32x4 mu = (rl.pi.activation == 0) ? forward16_shape<0, NIN>(wpi, rl.pi, x_own, n16, g) : forward16_shape<1, NIN>(wpi, rl.pi, x_own, n16, g);
+        if (g == 0) {  // lane n16 owns sample `own`: outputs 0..3 of the actor
           float av[4], lp = 0.f;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const float ls = (q < d_out) ? rl.log_std[q] : 0.f;
-            av[q] = fmaf(expf(ls), z[q], mu[q]);
-            if (q < d_out) lp += -0.5f * z[q] * z[q] - ls - 0.91893853320467274178f;
+            av[q] = fmaf(sig[q], z[q], mu[q]);
+            if (q < d_out) lp += -0.5f * z[q] * z[q] - lsd[q] - 0.91893853320467274178f;
           }
-          act_all[j][r16] = make_float4(av[0], av[1], av[2], av[3]);
-          if (row_ok) {
-            *reinterpret_cast<float4 *>(rl.act_buf + (o1 + env16) * 4) = make_float4(av[0], av[1], av[2], av[3]);
-            rl.logp_buf[o1 + env16] = lp;
+          act_all[j][own] = make_float4(av[0], av[1], av[2], av[3]);
+          if (own_ok) {
+            *reinterpret_cast<float4 *>(rl.act_buf + (o1 + env_own) * 4) = make_float4(av[0], av[1], av[2], av[3]);
+            rl.logp_buf[o1 + env_own] = lp;
           }
         }
       }
-      rollout_post(&act_ready[j], lane);  // this wave is done with tile j, its `fin` and its flags of step s - 1
+      rollout_post(&act_ready[j], lane);  // this wave is done with the tile, `fin` and the flags of step s - 1
     }
-    // ---- off the critical path: the env waves are stepping --------------------------------------------------
-#pragma unroll
-    for (int j = 0; j < kRolloutTiles; ++j) {
-      const int rows = tile_rows(j);
-      if (rows == 0) continue;
-      const bool row_ok = r16 < rows;
-      const long long env16 = (tile0 + j) * kWave + r16;
-      if (!(PDS_ROLLOUT_SKIP & 1)) {
-        const f32x4 v = (rl.vf.activation == 0) ? forward16<0, NIN>(wvf, xin[j], n16, g) : forward16<1, NIN>(wvf, xin[j], n16, g);
-        if (g == 0 && row_ok) {
-          if (s < T) rl.val_buf[o1 + env16] = v[0];
-          else rl.last_val[env16] = v[0];
-        }
+    // ---- off the critical path: the env wave is stepping (wave 0, its SIMD-mate, stays quiet) ------------------
+    auto critic = [&](const f32x4 (&x)[NIN]) -> float {
+      const f32x4 v = (rl.vf.activation == 0) ? forward16_shape<0, NIN>(wvf, rl.vf, x, n16, g) : forward16_shape<1, NIN>(wvf, rl.vf, x, n16, g);
+      return v[0];
+    };
+    if (wave != 0 && !(PDS_ROLLOUT_SKIP & 1)) {
+      const float v = critic(x_own);
+      if (g == 0 && own_ok) {
+        if (s < T) rl.val_buf[o1 + env_own] = v;
+        else rl.last_val[env_own] = v;
       }
-      // V(final_obs) where an env finished in step s - 1 (the other rows of fval_buf are never read: pds_gae)
-      if (any_dn[j]) {
-        const f32x4 v = (rl.vf.activation == 0) ? forward16<0, NIN>(wvf, xfin[j], n16, g) : forward16<1, NIN>(wvf, xfin[j], n16, g);
-        if (g == 0 && dn[j] && row_ok) rl.fval_buf[o1 - rl.s.n + env16] = v[0];
+    }
+    if (wave == 1 && !(PDS_ROLLOUT_SKIP & 1)) {
+      const float v = critic(x_r0);
+      if (g == 0 && r0_ok) {
+        if (s < T) rl.val_buf[o1 + env_r0] = v;
+        else rl.last_val[env_r0] = v;
       }
+    }
+    // V(final_obs) where an env finished in step s - 1 (the other rows of fval_buf are never read: pds_gae)
+    if (any_own) {
+      const float v = critic(f_own);
+      if (g == 0 && dn_own && own_ok) rl.fval_buf[o1 - rl.s.n + env_own] = v;
+    }
+    if (any_r0) {
+      const float v = critic(f_r0);
+      if (g == 0 && dn_r0 && r0_ok) rl.fval_buf[o1 - rl.s.n + env_r0] = v;
     }
   }
 }
 
-// The variants the fused rollout is built for: control_mode PWM, no latency, no Kalman hold, no ground effect;
-// {lean, reference default (DR + thrust noise + observation noise)} x {with, without motor dynamics}.
-template <int TASK>
-inline bool launch_rollout_task(const LaunchFlags &f, dim3 grid, hipStream_t s, const RolloutArgs &ra) {
-  if (f.ctrl != 0 || f.lat || f.hold || f.ge) return false;
+// The variants the fused rollout is built for: {lean, reference default (DR + thrust noise + observation noise)} x
+// {with, without motor dynamics} for control_mode PWM, for the PID control modes (what the reference's exp-07 trains:
+// experiments/07_control_structure_hypothesis/run_control_structures.py:53-61, envs/control.py:120-287) and for the
+// latency ring with control_mode PWM (envs/agents.py:267-276); no Kalman hold, no ground effect.
+template <int TASK, int CTRL, bool LAT>
+inline bool launch_rollout_family(const LaunchFlags &f, dim3 grid, hipStream_t s, const RolloutArgs &ra) {
   const bool lean = !f.dr && !f.tn && !f.on, full = f.dr && f.tn && f.on;
   if (!lean && !full) return false;
-  if (TASK == PDS_TASK_TAKEOFF && f.motor) return false;
-#define PDS_ROLLOUT_LAUNCH(M, X) hipLaunchKernelGGL((rollout_kernel<Variant<TASK, M, X, false, X, X, 0, false, false>>), grid, dim3(kRolloutThreads), 0, s, ra)
-  if constexpr (TASK == PDS_TASK_TAKEOFF) {
+  if (TASK == PDS_TASK_TAKEOFF && f.motor && !LAT) return false;
+#define PDS_ROLLOUT_LAUNCH(M, X) hipLaunchKernelGGL((rollout_kernel<Variant<TASK, M, X, false, X, X, CTRL, LAT, false>>), grid, dim3(kRolloutThreads), 0, s, ra)
+  if constexpr (TASK == PDS_TASK_TAKEOFF && !LAT) {
     if (full) PDS_ROLLOUT_LAUNCH(false, true); else PDS_ROLLOUT_LAUNCH(false, false);
   } else {
     if (f.motor) { if (full) PDS_ROLLOUT_LAUNCH(true, true); else PDS_ROLLOUT_LAUNCH(true, false); }
@@ -282,6 +310,17 @@ inline bool launch_rollout_task(const LaunchFlags &f, dim3 grid, hipStream_t s, 
   }
 #undef PDS_ROLLOUT_LAUNCH
   return true;
+}
+template <int TASK>
+inline bool launch_rollout_task(const LaunchFlags &f, dim3 grid, hipStream_t s, const RolloutArgs &ra) {
+  if (f.hold || f.ge) return false;
+  if (f.lat) return f.ctrl == 0 ? launch_rollout_family<TASK, 0, true>(f, grid, s, ra) : false;
+  if (f.ctrl == 0) return launch_rollout_family<TASK, 0, false>(f, grid, s, ra);
+  if constexpr (TASK != PDS_TASK_TAKEOFF) {  // TakeOff fixes control_mode = 'PWM' (envs/takeoff.py:225)
+    if (f.ctrl == 1) return launch_rollout_family<TASK, 1, false>(f, grid, s, ra);
+    return launch_rollout_family<TASK, 2, false>(f, grid, s, ra);
+  }
+  return false;
 }
 
 }  // namespace pds

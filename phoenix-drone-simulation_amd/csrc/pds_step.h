@@ -68,9 +68,6 @@ using Idx = EnvIdxT<saddr_variant<V>()>;
 
 // Observation-noise variants without the Kalman hold do not keep the noisy o(k) in memory: it is regenerated
 // (regen_kept_obs, csrc/pds_reset.h) unless the env's counter word says it was stored (kCtrOhBit; PDS_REGEN_OBS in pds_types.h).
-#ifndef PDS_EXP_REGEN
-#define PDS_EXP_REGEN 0  // timing experiments only: 1 = no flagged loads, 2 = no stores for injected variates (both: invalid results in those cases)
-#endif
 template <class V>
 constexpr bool regen_obs_variant() { return PDS_REGEN_OBS && V::ON && !V::HOLD; }
 
@@ -236,7 +233,7 @@ PDS_DEV void init_kept_obs(const StepArgs &a, const RngKey &rk, const Idx<V> ix,
     const uint32_t env_id = (uint32_t)(a.env_id_base + (unsigned long long)ix.wb) + ix.lc;
     regen_kept_obs(a.k, env_id, rk, ctr_step(S.ctr) == 0u, S.e, S.oh);
     const bool stored = ctr_oh(S.ctr) != 0u;
-    if (!(PDS_EXP_REGEN & 1) && __ballot(stored) != 0ull) {  // wave-uniform
+    if (__ballot(stored) != 0ull) {  // wave-uniform
       if (stored) {
         const float4 o0 = *at(a.st.oh0, ix), o1 = *at(a.st.oh1, ix);
         const float2 o2 = *at(a.st.oh2, ix);
@@ -272,7 +269,7 @@ PDS_DEV void store_state(const StepArgs &a, const Idx<V> i_, int new_parity, con
   if (V::ON) {
     *at(a.st.nz0, i) = make_float4(S.ns.bias[0], S.ns.bias[1], S.ns.bias[2], S.ns.lpf[0]);
     *at(a.st.nz1, i) = make_float2(S.ns.lpf[1], S.ns.lpf[2]);
-    if (!regen_obs_variant<V>() || (!(PDS_EXP_REGEN & 2) && a.noise != nullptr)) {  // (injected variates cannot be replayed: S.ctr carries kCtrOhBit)
+    if (!regen_obs_variant<V>() || a.noise != nullptr) {  // (injected variates cannot be replayed: S.ctr carries kCtrOhBit)
       *at(a.st.oh0, i) = make_float4(S.oh.x, S.oh.y, S.oh.z, S.oh.qx);
       *at(a.st.oh1, i) = make_float4(S.oh.qy, S.oh.qz, S.oh.qw, S.oh.vx);
       *at(a.st.oh2, i) = make_float2(S.oh.vy, S.oh.vz);
@@ -479,17 +476,17 @@ constexpr bool inline_coop_variant() { return V::TASK != PDS_TASK_TAKEOFF; }
 // envs per pass: the scratch of the noise-free latency variants has to leave room for 3 blocks per CU
 template <class V>
 constexpr int inline_envs_per_pass() {
-  // 4 envs per pass (a wave holds 1.3 finished envs on average when it holds any): round 3 used 8 for Hover's 34-float
-  // noisy rows because 3 blocks per CU still fitted; round 4 wants FOUR blocks per CU there (four_block_variant)
-  return kResetsPerPass / 2;
+  // a wave holds 1.3 finished envs on average when it holds any.  Round 3 used 8 per pass for Hover's 34-float noisy rows
+  // because 3 blocks per CU still fitted; round 4 wants FOUR blocks per CU there (four_block_variant), with a scratch of
+  // CONVERTED variates (336 B per env): 3 envs per pass -- 4 x (8704 + 3 x 336 + 256) = 39 872 B per block
+  return (V::ON && !V::LAT && V::TASK == PDS_TASK_HOVER) ? 3 : kResetsPerPass / 2;
 }
-// U4 slots per env of the in-register resets' scratch: the blocks the variant uses (15 with observation noise, 22 with
-// the latency rows), not the 22 of the general layout
+// U4 slots per env of the in-register resets' scratch (LdsVariates layout: floats, see fill_reset_variates)
 template <class V>
-constexpr int scratch_stride() { return scratch_blocks_used<V>(); }
+constexpr int scratch_stride() { return (variates_floats<V>() + 3) / 4; }
 // Hover with observation noise (D = 34: an 8.7 KB tile per wave): since the kept observation is regenerated instead
 // of loaded (regen_obs_variant) these kernels need 107-127 VGPRs, so FOUR blocks per CU fit the register file -- and the
-// LDS, with the scratch above: 4 x (8704 + 4 x 15 x 16 + 256) = 39 680 B per block.  Not with PT1 + DR (127-139 VGPRs:
+// LDS, with the scratch above: 39 872 B per block.  Not with PT1 + DR (127-139 VGPRs:
 // spills under the 128 cap), the PID modes or the latency ring; Circle / TakeOff rows (44 / 52 floats) do not fit 40 KB.
 template <class V>
 constexpr bool four_block_variant() {
@@ -933,11 +930,12 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
           for (int base = 0; base < count; base += IE) {
             const int cnt = min(IE, count - base);  // wave-uniform
-            fill_reset_scratch<V, scratch_stride<V>()>(a, rk, queue + base, cnt, lane, wave_base, scratch);
+            fill_reset_variates<V>(a, rk, queue + base, cnt, lane, wave_base, reinterpret_cast<float *>(scratch));
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (need_reset && pos >= base && pos < base + cnt) evaluate(LdsWords{scratch + (pos - base) * scratch_stride<V>()});
+            if (need_reset && pos >= base && pos < base + cnt)
+              evaluate(LdsVariates{reinterpret_cast<const float *>(scratch) + (pos - base) * variates_floats<V>()});
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();  // the scratch is refilled by the next pass
           }
@@ -1144,6 +1142,9 @@ __global__ __launch_bounds__(kBlock, (PDS_MIN_WAVES) * (256 / kBlock)) void step
 // Same box, 2^20 envs, K = 8, us per env-step, 3 vs 2: Hover noise + DR 86.1 vs 80.1, + PT1 102.2 vs 83.9, latency
 // ring 116.7 vs 88.7, Circle default 85.3 vs 77.1; TakeOff (hardly any resets) 49.2 vs 53.2 and the noise-free
 // variants 47.4 vs 46.5 / 49.0 vs 49.5 keep 3 (profiles/r02_variant_timings_stepk_minwaves.txt).
+#ifndef PDS_STEPK_OPAQUE_KEY
+#define PDS_STEPK_OPAQUE_KEY 1  // A/B: 0 = round-3 form (key schedule hoisted out of the K loop and spilled)
+#endif
 #ifndef PDS_STEPK_MIN_WAVES
 #define PDS_STEPK_MIN_WAVES ((V::ON && V::TASK != PDS_TASK_TAKEOFF) ? 2 : 3)
 #endif
@@ -1173,10 +1174,20 @@ __global__ __launch_bounds__(kBlock, (PDS_STEPK_MIN_WAVES) * (256 / kBlock)) voi
   for (int s = 0; s < K; ++s) {
     // a fresh view of the kernel arguments per iteration: what the loop body needs is re-read (scalar-cache
     // hits) instead of being hoisted out of the loop into SGPRs that do not exist (41-79 spills in round 2)
-    const StepArgs &al = reload_args<106, heavy_variant<V>()>(a, s);
+    const StepArgs &al = reload_args<106, PDS_STEPK_OPAQUE_KEY || heavy_variant<V>()>(a, s);
+    // ... and the Philox key: the 2 x 10 round keys (seed + r x Weyl constant) are loop-invariant, so the compiler forms
+    // them in the loop header and -- with the 102 SGPRs taken -- spills them to VGPR lanes there and reads them back in
+    // every round of every Philox call of every iteration (2-45 spilled SGPRs per step_k kernel in round 3).  An opaque
+    // copy of the seed per iteration makes the schedule part of the iteration: ~20 scalar adds, live only where used.
+    RngKey rks = rk;
+    if (PDS_STEPK_OPAQUE_KEY) asm volatile("" : "+s"(rks.seed_lo), "+s"(rks.seed_hi));
+    // ... and the lane index: every lane predicate of the body (tile flush bounds, row ownership, `lane < D`) is
+    // loop-invariant too and would be kept as a 64-bit mask in an SGPR pair from the loop header on
+    int lane_s = lane;
+    if (PDS_STEPK_OPAQUE_KEY) asm volatile("" : "+v"(lane_s));
     float4 act_next = act;
     if (s + 1 < K) act_next = nt_load4(at(al.actions + (long long)(s + 1) * al.n, ix));  // in flight during step s
-    step_once<V, TR, RM, false>(al, (long long)s * al.n, rk, parity, ref_lds, tile, park, queue, scratch, lane, wave_base, ix, active, act, S, qcount, nullptr, nullptr PDS_STAMP_ARG);
+    step_once<V, TR, RM, false>(al, (long long)s * al.n, rks, parity, ref_lds, tile, park, queue, scratch, lane_s, wave_base, ix, active, act, S, qcount, nullptr, nullptr PDS_STAMP_ARG);
     act = act_next;
     parity ^= 1;
     rk.tick_lo += 1u;

@@ -308,6 +308,12 @@ def test_graph_captured_rollout_equals_eager_rollout_bitwise():
     ("DroneHoverSimpleEnv-v0", dict(), 1000),                                   # reference defaults, ragged last tile
     ("DroneCircleSimpleEnv-v0", dict(use_motor_dynamics=True), 256),            # PT1 + DR + noise
     ("DroneTakeOffSimpleEnv-v0", dict(), 192),
+    # round 4: the PID control modes (what the reference's exp-07 trains, 4 / 8 physics sub-steps) and the latency ring
+    ("DroneHoverSimpleEnv-v0", dict(control_mode="AttitudeRate", aggregate_phy_steps=4), 320),
+    ("DroneCircleSimpleEnv-v0", dict(control_mode="Attitude", aggregate_phy_steps=2, use_motor_dynamics=True), 192),
+    ("DroneHoverSimpleEnv-v0", dict(use_latency=True, latency=0.02), 256),
+    ("DroneHoverSimpleEnv-v0", dict(observation_noise=-1, domain_randomization=-1, motor_thrust_noise=0, use_latency=True,
+                                    latency=0.035, control_mode="PWM"), 130),
 ])
 def test_fused_rollout_equals_per_step_rollout_bitwise(task, kw, n):
     """pds_rollout (ONE launch for the T closed-loop steps: both networks on the matrix cores, Gaussian sampling, env
@@ -351,7 +357,7 @@ def test_fused_rollout_equals_per_step_rollout_bitwise(task, kw, n):
 def test_fused_rollout_refuses_what_it_is_not_built_for_and_the_trainer_falls_back():
     import phoenix_drone_simulation_amd as pds
     from phoenix_drone_simulation_amd.ppo import PPOTrainer
-    env = pds.make("DroneHoverSimpleEnv-v0", num_envs=128, seed=3, control_mode="AttitudeRate")
+    env = pds.make("DroneHoverSimpleEnv-v0", num_envs=128, seed=3, observation_frequency=50)  # Kalman hold: no rollout kernel
     tr = PPOTrainer(env, rollout_len=4, epochs=2, seed=5, fused=True)
     tr.roll_out()
     assert tr.fused_rollout is False  # PDS_EUNSUPPORTED -> per-step kernels
