@@ -132,6 +132,14 @@ __host__ __device__ inline Offsets offsets(const pds_mlp &m) {
 #define PDS_MLP_EDGE 1  // A/B: 0 = the fourth output tile of the 50-wide layers on the matrix cores as well
 #endif
 #define PDS_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+// v_mfma_f32_4x4x1_16b_f32: 16 independent 4 x 4 outer products per instruction (block b = lane / 4: D_b[i][j] += A_b[i] B_b[j],
+// lane 4 b + i supplies A_b[i], lane 4 b + j supplies B_b[j] and holds D_b[0..3][j] in its four registers), 8 cycles
+// against 32 for a 16x16x4 tile at the same flop rate: the right shape for a 4-row or 4-column STRIP of a weight
+// gradient (rank-1 update per sample), where a 16-row tile would carry 2 useful rows.
+#define PDS_MFMA44(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
+#ifndef PDS_MLP_STRIPS
+#define PDS_MLP_STRIPS 1  // round 4, ppo_split_kernel: rows / columns 48..51 of dW2, rows 48..51 of dW1 and the whole dW3 as 4x4x1 strips; A/B: 0
+#endif
 #if PDS_SPLIT_DEBUG == 3  // profiling: the forward role WITHOUT its MFMAs -- operands stay alive, no instruction is
                            // issued: what the rest of its instruction stream costs the pair (results invalid)
 typedef float pds_f32x4_ __attribute__((ext_vector_type(4)));
@@ -769,6 +777,17 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
     for (int j = 0; j < NIN; ++j) gW1[i][j] = (f32x4)(0.f);
   }
 
+  // Round 4 (NG = 1): the edge of the 50-wide layers as 4x4x1 strips.  50 = 3 x 16 + 2, so row tile 3 / column tile 3 of
+  // dW2 and row tile 3 of dW1 were 16-wide tiles with 2 (3 with the bias column) useful rows or columns: 7 of dW2's 16
+  // tiles and 3 of dW1's 12, 40 of G's 154 MFMAs per 16 samples.  Now: gW2r = rows 48..51 x all columns (lane l: column
+  // l), gW2c = all rows x columns 48..51 (lane l: rows 4 (l / 4) .. + 3, column 48 + l % 4), gW1r = rows 48..51 of dW1
+  // x all input columns; 16 rank-1 updates (one per sample) of 8 cycles each per strip instead of 4 k-steps x 32 cycles
+  // per tile.  The full tiles cover rows / columns 0..47.  dW3 (4 x 50) is one such strip on F's side (gW3s).
+  constexpr bool STRIP = PDS_MLP_STRIPS != 0 && NG == 1;
+  constexpr int NTF = STRIP ? kNT - 1 : kNT;  // full 16-wide tiles per hidden dimension
+  f32x4 gW2r = (f32x4)(0.f), gW2c = (f32x4)(0.f), gW1r = (f32x4)(0.f), gW3s = (f32x4)(0.f), gW3s2 = (f32x4)(0.f);
+  const int lc = lane < kSI ? lane : kSI - 1;  // column of a 52-wide image row (lanes 52..63: clamped, their results are dropped)
+
   if (NG == 2 && role == 2) {
     // ================= G2 (NG = 2): dW2 += dZ2^T H1 =========================================================
     const int r3 = min(r, 3);
@@ -841,14 +860,23 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
         float av[kNT], bv[kNT];
         const int row = (4 * h + j) * kSI;
 #pragma unroll
-        for (int i = 0; i < kNT; ++i) {
+        for (int i = 0; i < NTF; ++i) {
           av[i] = dZ2img[row + i * kTW + (i == kNT - 1 ? r3 : r)];
           bv[i] = H1img[row + i * kTW + (i == kNT - 1 ? n3 : n)];
         }
 #pragma unroll
-        for (int it = 0; it < kNT; ++it)
+        for (int it = 0; it < NTF; ++it)
 #pragma unroll
-          for (int jt = 0; jt < kNT; ++jt) gW2[it][jt] = PDS_MFMA(av[it], bv[jt], gW2[it][jt]);
+          for (int jt = 0; jt < NTF; ++jt) gW2[it][jt] = PDS_MFMA(av[it], bv[jt], gW2[it][jt]);
+      }
+      if constexpr (STRIP) {  // rows and columns 48..51 of dW2: one rank-1 update per sample and strip
+#pragma unroll
+        for (int sm = 0; sm < kTS; ++sm) {
+          const float dzr = dZ2img[sm * kSI + 48 + (lane & 3)], dzc = dZ2img[sm * kSI + lc];
+          const float h1r_ = H1img[sm * kSI + lc], h1c = H1img[sm * kSI + 48 + (lane & 3)];
+          gW2r = PDS_MFMA44(dzr, h1r_, gW2r);
+          gW2c = PDS_MFMA44(dzc, h1c, gW2c);
+        }
       }
       PDS_SSTAMP(1, 3);
       {
@@ -878,13 +906,17 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
         float av[kNT], bv[NIN];
         const int row = (4 * h + j) * kSI;
 #pragma unroll
-        for (int i = 0; i < kNT; ++i) av[i] = dZ1img[row + i * kTW + (i == kNT - 1 ? r3 : r)];
+        for (int i = 0; i < NTF; ++i) av[i] = dZ1img[row + i * kTW + (i == kNT - 1 ? r3 : r)];
 #pragma unroll
         for (int i = 0; i < NIN; ++i) bv[i] = Ximg[row + i * kTW + n];
 #pragma unroll
-        for (int it = 0; it < kNT; ++it)
+        for (int it = 0; it < NTF; ++it)
 #pragma unroll
           for (int kt = 0; kt < NIN; ++kt) gW1[it][kt] = PDS_MFMA(av[it], bv[kt], gW1[it][kt]);
+      }
+      if constexpr (STRIP) {  // rows 48..51 of dW1
+#pragma unroll
+        for (int sm = 0; sm < kTS; ++sm) gW1r = PDS_MFMA44(dZ1img[sm * kSI + 48 + (lane & 3)], Ximg[sm * kSI + lc], gW1r);
       }
       PDS_SSTAMP(1, 5);
 #endif
@@ -1083,11 +1115,17 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
       // operands of dZ2 (B: one dword of dY) and of dW3
       const float dyb = dYimg[n * kSY + h];
       float av3[4], bv3[4][kNT];
+      float sa3[kTS], sb3[kTS];  // STRIP: dY[sample][lane % 4], H2[sample][lane]
+      if constexpr (STRIP) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        av3[j] = dYimg[(4 * h + j) * kSY + r];
+        for (int sm = 0; sm < kTS; ++sm) { sa3[sm] = dYimg[sm * kSY + (lane & 3)]; sb3[sm] = H2img[sm * kSI + lc]; }
+      } else {
 #pragma unroll
-        for (int jt = 0; jt < kNT; ++jt) bv3[j][jt] = H2img[(4 * h + j) * kSI + jt * kTW + (jt == kNT - 1 ? n3 : n)];
+        for (int j = 0; j < 4; ++j) {
+          av3[j] = dYimg[(4 * h + j) * kSY + r];
+#pragma unroll
+          for (int jt = 0; jt < kNT; ++jt) bv3[j][jt] = H2img[(4 * h + j) * kSI + jt * kTW + (jt == kNT - 1 ? n3 : n)];
+        }
       }
       PDS_FPRIO_MFMA();
       // ---- dZ2^T = (W3^T dY^T) * act'(H2^T): the k-slot (step jj, lane group h) carries output 4 jj + h, so one
@@ -1099,11 +1137,20 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
 #pragma unroll
         for (int it = 0; it < kNT; ++it) cc[it] = PDS_MFMA_F(W3s[(4 + h) * kS + it * kTW + r], dyb2, cc[it]);
       }
-      // ---- dW3 += dY^T H2 (its 16 MFMAs cover the result latency of dZ2) ----
+      // ---- dW3 += dY^T H2 (its MFMAs cover the result latency of dZ2): a 4-row strip, one rank-1 update per sample ----
+      if constexpr (STRIP) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+        for (int sm = 0; sm < kTS; ++sm) gW3s = PDS_MFMA44(sa3[sm], sb3[sm], gW3s);
+        if (m.d_out > 4) {
 #pragma unroll
-        for (int jt = 0; jt < kNT; ++jt) gW3[jt] = PDS_MFMA_F(av3[j], bv3[j][jt], gW3[jt]);
+          for (int sm = 0; sm < kTS; ++sm) gW3s2 = PDS_MFMA44(dYimg[sm * kSY + 4 + (lane & 3)], sb3[sm], gW3s2);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int jt = 0; jt < kNT; ++jt) gW3[jt] = PDS_MFMA_F(av3[j], bv3[j][jt], gW3[jt]);
+      }
       PDS_FPRIO_VALU();
       PDS_SSTAMP(0, 8);
 #pragma unroll
@@ -1122,7 +1169,7 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
   // ---- block sums: the 4 waves of each role add up what that role accumulates (F: dW3, statistics; G / G1: dW1 (+ dW2);
   // G2: dW2); rounds 2,3 -> 0,1 and 1 -> 0 through LDS (the images are free now) -------------------------------------
   {
-    constexpr int kRegs1 = 4 * (kNT * NIN + (NG == 1 ? kNT * kNT : 0)), kRegs2 = 4 * kNT * kNT, kRegsF = 4 * kNT + kStats;
+    constexpr int kRegs1 = 4 * (kNT * NIN + (NG == 1 ? kNT * kNT : 0)), kRegs2 = 4 * kNT * kNT, kRegsF = 4 * kNT + kStats;  // (upper bounds with STRIP)
     static_assert(2 * (kRegs1 + (NG == 2 ? kRegs2 : 0)) * 64 <= kPairs * 2 * kSetFloats, "the register images of the weight-gradient roles must fit in the tile sets");
     static_assert(2 * kRegsF * 64 <= kPairs * kPrivFloats, "two F register images must fit in the private images");
     auto xfer = [&](float *slot, bool add) {
@@ -1134,22 +1181,27 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
       };
       if (role == 1) {
 #pragma unroll
-        for (int i = 0; i < kNT; ++i) {
+        for (int i = 0; i < NTF; ++i) {
 #pragma unroll
           for (int j = 0; j < NIN; ++j) four(gW1[i][j]);
           if (NG == 1) {
 #pragma unroll
-            for (int j = 0; j < kNT; ++j) four(gW2[i][j]);
+            for (int j = 0; j < NTF; ++j) four(gW2[i][j]);
           }
         }
+        if (STRIP) { four(gW2r); four(gW2c); four(gW1r); }
       } else if (role == 2) {
 #pragma unroll
         for (int i = 0; i < kNT; ++i)
 #pragma unroll
           for (int j = 0; j < kNT; ++j) four(gW2[i][j]);
       } else {
+        if (STRIP) {
+          four(gW3s); four(gW3s2);
+        } else {
 #pragma unroll
-        for (int i = 0; i < kNT; ++i) four(gW3[i]);
+          for (int i = 0; i < kNT; ++i) four(gW3[i]);
+        }
         f32x4 st = {st_loss, st_ratio, st_kl, st_cnt};
         four(st);
         st_loss = st[0]; st_ratio = st[1]; st_kl = st[2]; st_cnt = st[3];
@@ -1172,7 +1224,7 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
   const Offsets o = offsets(m);
   if (role != 0) {
 #pragma unroll
-    for (int it = 0; it < kNT; ++it) {
+    for (int it = 0; it < NTF; ++it) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int i = it * kTW + 4 * g + q;
@@ -1183,12 +1235,42 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
             if (jt < NIN && i < m.h1 && j < m.d_in) out[o.w1 + i * m.d_in + j] = gW1[it][jt < NIN ? jt : 0][q];
             if (jt < NIN && i < m.h1 && j == m.d_in) out[o.b1 + i] = gW1[it][jt < NIN ? jt : 0][q];
           }
-          if (role == (NG == 1 ? 1 : 2)) {
+          if (role == (NG == 1 ? 1 : 2) && jt < NTF) {
             if (i < m.h2 && j < m.h1) out[o.w2 + i * m.h1 + j] = gW2[it][jt][q];
             if (i < m.h2 && j == m.h1) out[o.b2 + i] = gW2[it][jt][q];
           }
         }
       }
+    }
+    if (STRIP && role == 1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        // row strips: lane l holds rows 48 + q at column l
+        const int i = 48 + q;
+        if (i < m.h2 && lane < m.h1) out[o.w2 + i * m.h1 + lane] = gW2r[q];
+        if (i < m.h2 && lane == m.h1) out[o.b2 + i] = gW2r[q];
+        if (i < m.h1 && lane < m.d_in) out[o.w1 + i * m.d_in + lane] = gW1r[q];
+        if (i < m.h1 && lane == m.d_in) out[o.b1 + i] = gW1r[q];
+        // column strip: lane l holds rows 4 (l / 4) + q at column 48 + l % 4 (rows 48.. belong to the row strip)
+        const int ic = 4 * (lane >> 2) + q, jc = 48 + (lane & 3);
+        if (ic < 48 && jc < m.h1) out[o.w2 + ic * m.h1 + jc] = gW2c[q];
+        if (ic < 48 && jc == m.h1) out[o.b2 + ic] = gW2c[q];
+      }
+    }
+  } else if (STRIP) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {  // lane l holds outputs q (gW3s) and 4 + q (gW3s2) at column l
+      if (q < m.d_out && lane < m.h2) out[o.w3 + q * m.h2 + lane] = gW3s[q];
+      if (q < m.d_out && lane == m.h2) out[o.b3 + q] = gW3s[q];
+      if (4 + q < m.d_out && lane < m.h2) out[o.w3 + (4 + q) * m.h2 + lane] = gW3s2[q];
+      if (4 + q < m.d_out && lane == m.h2) out[o.b3 + 4 + q] = gW3s2[q];
+    }
+    float s4[kStats] = {st_loss, st_ratio, st_kl, st_cnt};
+#pragma unroll
+    for (int q = 0; q < kStats; ++q) {
+      float v = s4[q];
+      for (int d = 8; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+      if (lane == 0) out[o.total + q] = v;
     }
   } else {
 #pragma unroll
