@@ -54,6 +54,23 @@ def main():
     for name in tn.NOISE_SCENARIOS:
         tn.test_noisy_single_step_vs_reference(name)
         tn.test_noisy_reset_vs_reference(name)
+    single = dict(REC)
+    REC.clear()
+    # closed loop (tests/test_gpu_parity.py::test_closed_loop_short_horizon): error growth per step, as a multiple of
+    # the single-step unit 1e-6 |want| + 1e-6
+    CL = collections.defaultdict(float)
+
+    def record_cl(a, b, rtol, atol, what=""):
+        a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+        scen, tt, field = what.split(" ")
+        CL[(field, int(tt[1:]))] = max(CL[(field, int(tt[1:]))], float((np.abs(a - b) / (1e-6 * np.abs(b) + 1e-6)).max()))
+    gu.assert_close = record_cl
+    for scen in ["hover_det", "circle_det", "takeoff_det"] + tp.LAT_DET:
+        tp.test_closed_loop_short_horizon(scen)
+    print("closed loop: max |err| / (1e-6 |want| + 1e-6) by step")
+    for field in ("obs", "reward"):
+        print(f"  {field:7s}", " ".join(f"t{t}:{CL[(field, t)]:.1f}" for t in sorted(t for f, t in CL if f == field)))
+    REC.update(single)
     print(f"{'field':28s} {'max |err|':>12s} {'max slack over 1e-6 rel':>26s}  worst scenario")
     for k in sorted(REC):
         e, s, sc = REC[k]

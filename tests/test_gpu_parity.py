@@ -203,8 +203,10 @@ LAT_DET = [n for n in DET_SCENARIOS if "lat" in n]
 
 @pytest.mark.parametrize("scen", ["hover_det", "circle_det", "takeoff_det"] + LAT_DET)
 def test_closed_loop_short_horizon(scen):
-    """G3: 8-12-step closed-loop rollouts from the reference's reset draws stay within 1e-4 (the latency
-    scenarios exercise the delayed-action ring and the aliased history entries over whole episodes)."""
+    """G3: 8-12-step closed-loop rollouts from the reference's reset draws stay within 2e-5 relative + 2e-5 absolute
+    (round 4; 1e-4 before): the measured error growth over the 12 steps peaks at 9.3 x the single-step unit
+    1e-6 |want| + 1e-6 (profiles/r04_parity_margins.txt).  The latency scenarios exercise the delayed-action ring and
+    the aliased history entries over whole episodes."""
     g = gu.Golden(scen)
     task = scen
     env = _make(g, g.E, auto_reset=False)
@@ -215,8 +217,8 @@ def test_closed_loop_short_horizon(scen):
         alive &= g["valid"][:, t].astype(bool)
         if not alive.any():
             break
-        gu.assert_close(o.cpu().numpy()[alive], g["obs"][alive, t], 1e-4, 1e-4, f"{task} t{t} obs")
-        gu.assert_close(r.cpu().numpy()[alive], g["reward"][alive, t], 1e-4, 1e-4, f"{task} t{t} reward")
+        gu.assert_close(o.cpu().numpy()[alive], g["obs"][alive, t], 2e-5, 2e-5, f"{task} t{t} obs")
+        gu.assert_close(r.cpu().numpy()[alive], g["reward"][alive, t], 2e-5, 2e-5, f"{task} t{t} reward")
     env.close()
 
 
