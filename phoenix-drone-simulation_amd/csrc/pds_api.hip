@@ -462,12 +462,8 @@ extern "C" int pds_create(const pds_config *cfg, pds_handle **out) {
     const int obs_rate = sim_freq / cfg->observation_frequency;
     if (obs_rate < 1) PDS_CREATE_FAIL(PDS_EINVAL, "observation_frequency %d above sim_freq %d: obs_rate 0 (the reference divides by it)", cfg->observation_frequency, sim_freq);
   }
-  if (cfg->observation_noise > 0) {
-    const int obs_rate = (int)llround(1.0 / cfg->time_step) / cfg->observation_frequency;
-    if (obs_rate != 1 && (cfg->control_mode != PDS_CTRL_PWM || cfg->use_latency))
-      PDS_CREATE_FAIL(PDS_EUNSUPPORTED, "observation noise with obs_rate %d > 1 (Kalman-hold branch) is built for control_mode PWM "
-                      "without latency", obs_rate);
-  }
+  // (observation noise with obs_rate > 1 -- the Kalman-hold branch -- together with a PID control mode or the latency
+  //  ring: built since round 4)
   const int lat_steps = cfg->use_latency ? latency_steps_ctor(cfg->latency, cfg->time_step) : 0;
   if (lat_steps > kMaxLatSteps) PDS_CREATE_FAIL(PDS_EUNSUPPORTED, "latency %g s = %d steps (limit %d)", cfg->latency, lat_steps, kMaxLatSteps);
   // (use_latency + the ground-effect extension: built for control_mode PWM since round 3; the PID modes have no
@@ -624,7 +620,6 @@ extern "C" int pds_set_latency(pds_handle *h, double latency) {
     if (steps > kMaxLatSteps) return fail(h, PDS_EUNSUPPORTED, "latency %g s = %d steps (limit %d)", latency, steps, kMaxLatSteps);
   }
   // every check and the allocation come BEFORE the handle is touched: a refused call leaves it as it was
-  if (steps > 0 && h->flags.hold) return fail(h, PDS_EUNSUPPORTED, "latency with obs_rate > 1 is not built");
   DeviceGuard guard(h->cfg.device);
   PDS_HIP(h, guard.err);
   PDS_HIP(h, hipDeviceSynchronize());

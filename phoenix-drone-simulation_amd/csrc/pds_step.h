@@ -1264,18 +1264,36 @@ inline void launch_lat(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s,
   }
 }
 
-// hold: observation noise with obs_rate > 1 (control_mode PWM, no latency): motor x DR x GE x TN
-template <int TASK>
-inline void launch_hold(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a) {
-  // ON = true, HOLD = true, control_mode PWM, no latency: MOTOR x DR x GE x TN
-#define PDS_HOLD(M, R, G, T) launch_variant<Variant<TASK, M, R, G, T, true, 0, false, true>>(kind, false, grid, s, a)
+// hold: observation noise with obs_rate > 1 (the Kalman-hold branch): motor x DR x GE x TN for control_mode PWM with and
+// without the latency ring; round 4: also the PID control modes (no ground effect there), with and without latency
+template <int TASK, int CTRL, bool LAT>
+inline void launch_hold_family(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a) {
+  // ON = true, HOLD = true
+#define PDS_HOLD(M, R, G, T) launch_variant<Variant<TASK, M, R, G, T, true, CTRL, LAT, true>>(kind, false, grid, s, a)
 #define PDS_HOLD_T(M, R, G) do { if (f.tn) PDS_HOLD(M, R, G, true); else PDS_HOLD(M, R, G, false); } while (0)
-#define PDS_HOLD_G(M, R) do { if (f.ge) PDS_HOLD_T(M, R, true); else PDS_HOLD_T(M, R, false); } while (0)
+#define PDS_HOLD_G(M, R) do { if (CTRL == 0 && f.ge) { if constexpr (CTRL == 0) PDS_HOLD_T(M, R, true); } else PDS_HOLD_T(M, R, false); } while (0)
   if (f.motor) { if (f.dr) PDS_HOLD_G(true, true); else PDS_HOLD_G(true, false); }
   else { if (f.dr) PDS_HOLD_G(false, true); else PDS_HOLD_G(false, false); }
 #undef PDS_HOLD_G
 #undef PDS_HOLD_T
 #undef PDS_HOLD
+}
+template <int TASK>
+inline void launch_hold(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a) {
+  if constexpr (TASK == PDS_TASK_TAKEOFF) {  // TakeOff fixes control_mode = 'PWM' (envs/takeoff.py:225)
+    if (f.lat) launch_hold_family<TASK, 0, true>(kind, f, grid, s, a);
+    else launch_hold_family<TASK, 0, false>(kind, f, grid, s, a);
+  } else {
+    if (f.lat) {
+      if (f.ctrl == 0) launch_hold_family<TASK, 0, true>(kind, f, grid, s, a);
+      else if (f.ctrl == 1) launch_hold_family<TASK, 1, true>(kind, f, grid, s, a);
+      else launch_hold_family<TASK, 2, true>(kind, f, grid, s, a);
+    } else {
+      if (f.ctrl == 0) launch_hold_family<TASK, 0, false>(kind, f, grid, s, a);
+      else if (f.ctrl == 1) launch_hold_family<TASK, 1, false>(kind, f, grid, s, a);
+      else launch_hold_family<TASK, 2, false>(kind, f, grid, s, a);
+    }
+  }
 }
 
 }  // namespace pds

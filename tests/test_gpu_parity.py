@@ -417,6 +417,16 @@ def _variant_grid(task):
         yield motor, dr, tn, on, 1, "PWM", 1, dict(use_latency=True, latency=0.025)
     for motor, dr, tn in itertools.product((0, 1), (0, 1), (0, 1)):
         yield motor, dr, tn, 1, 1, "PWM", 1, dict(observation_frequency=50)
+    # round 4: the Kalman-hold branch together with the PID control modes and / or the latency ring
+    if task != "takeoff":
+        for motor, dr, ctrl in itertools.product((0, 1), (0, 1), ("AttitudeRate", "Attitude")):
+            yield motor, dr, 1, 1, 0, ctrl, 1, dict(observation_frequency=50)
+        for motor, ctrl in itertools.product((0, 1), ("AttitudeRate", "Attitude")):
+            yield motor, 1, 0, 1, 0, ctrl, 2, dict(observation_frequency=33, use_latency=True, latency=0.025)
+    for motor, dr, tn in itertools.product((0, 1), (0, 1), (0, 1)):
+        if task == "takeoff" and motor:
+            continue
+        yield motor, dr, tn, 1, 0, "PWM", 1, dict(observation_frequency=50, use_latency=True, latency=0.025)
 
 
 @pytest.mark.parametrize("task", ["hover", "circle", "takeoff"])
