@@ -669,7 +669,8 @@ extern "C" int pds_bytes_per_env_step_k(const pds_handle *h, int k_steps) {
   const int full = pds_bytes_per_env_step(h);
   const int stream = 16 + 4 * h->obs_dim + 10 + (f.lat ? 32 * h->cfg.aggregate_phy_steps : 0);
   // once per launch: the state read + written, both ring slots and the randomised parameters written back
-  const int state = full - stream + 16 + (f.dr ? 24 : 0) + (f.dr && f.motor ? 32 : 0);
+  // (+ the kept noisy observation, which the K-step kernel reads from and leaves in oh0-2: materialize_oh_kernel)
+  const int state = full - stream + 16 + (f.dr ? 24 : 0) + (f.dr && f.motor ? 32 : 0) + ((PDS_REGEN_OBS && f.on && !f.hold) ? 80 : 0);
   return stream + (state + k_steps - 1) / k_steps;
 }
 
@@ -778,6 +779,31 @@ extern "C" int pds_step(pds_handle *h, const float *d_actions, float *d_obs, flo
                                 d_final_obs, stream);
 }
 
+// In front of the K-step kernel of an observation-noise variant (regen_obs_variant): the kept noisy observation of every env
+// that does not have it in oh0-2 (i.e. every env after a pds_step, none after a pds_step_k) is regenerated there and flagged
+// in the counter word -- what the single-step kernels do in their prologue (init_kept_obs), as a pass of its own so that the
+// K-step kernel's loop is not compiled around it (csrc/pds_step.h, step_k_kernel).  Same function, same inputs, same bits.
+// 4 B per env when every env is flagged, 52 + 44 B otherwise.
+namespace pds {
+__global__ __launch_bounds__(kBlock) void materialize_oh_kernel(DevState st, Consts k, long long n, unsigned long long env_id_base,
+                                                                uint32_t seed_lo, uint32_t seed_hi) {
+  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t c = st.ctr[i];
+  if (ctr_oh(c) != 0u) return;
+  const WaveClock ck = st.clk[i / kWave];
+  const RngKey now{seed_lo, seed_hi, ck.x, ck.y};
+  const float4 q0 = st.s0[i], q1 = st.s1[i], q2 = st.s2[i];
+  const EnvRegs e{q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+  NoisyObs o;
+  regen_kept_obs(k, (uint32_t)(env_id_base + (unsigned long long)i), now, ctr_step(c) == 0u, e, o);
+  st.oh0[i] = make_float4(o.x, o.y, o.z, o.qx);
+  st.oh1[i] = make_float4(o.qy, o.qz, o.qw, o.vx);
+  st.oh2[i] = make_float2(o.vy, o.vz);
+  st.ctr[i] = c | kCtrOhBit;
+}
+}  // namespace pds
+
 extern "C" int pds_step_k(pds_handle *h, int k_steps, const float *d_actions, float *d_obs, float *d_reward,
                           uint8_t *d_terminated, uint8_t *d_truncated, float *d_cost, float *d_final_obs, void *stream) {
   if (!h) return PDS_EINVAL;
@@ -806,6 +832,9 @@ extern "C" int pds_step_k(pds_handle *h, int k_steps, const float *d_actions, fl
   const dim3 grid((unsigned)((a.n + kBlock - 1) / kBlock));
   LaunchFlags lf = h->flags;
   lf.half_tile = false;
+  if (PDS_REGEN_OBS && lf.on && !lf.hold)
+    hipLaunchKernelGGL(pds::materialize_oh_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, h->st, h->k, a.n, a.env_id_base,
+                       a.seed_lo, a.seed_hi);
   launch_family(h, kLaunchStepK, lf, grid, (hipStream_t)stream, a);
   PDS_HIP(h, hipGetLastError());
   h->tick += (uint64_t)k_steps;

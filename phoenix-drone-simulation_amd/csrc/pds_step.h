@@ -15,6 +15,7 @@
 // envs/agents.py:259-298, envs/control.py:94-100, envs/base.py:303-319,433-475, envs/hover.py,
 // envs/circle.py, envs/takeoff.py, envs/sensors.py:75-134, envs/utils.py:59-108.
 #pragma once
+#include <type_traits>
 #include "pds_reset.h"
 
 namespace pds {
@@ -69,7 +70,10 @@ using Idx = EnvIdxT<saddr_variant<V>()>;
 // Observation-noise variants without the Kalman hold do not keep the noisy o(k) in memory: it is regenerated
 // (regen_kept_obs, csrc/pds_reset.h) unless the env's counter word says it was stored (kCtrOhBit; PDS_REGEN_OBS in pds_types.h).
 template <class V>
-constexpr bool regen_obs_variant() { return PDS_REGEN_OBS && V::ON && !V::HOLD; }
+constexpr bool regen_obs_variant() { return PDS_REGEN_OBS && V::ON && !V::HOLD && !V::OH_STORED; }
+// ... and a kernel that leaves every env's kept observation in oh0-2 says so in the counter word (StoredOh)
+template <class V>
+constexpr bool flags_oh_variant() { return PDS_REGEN_OBS && V::ON && !V::HOLD && V::OH_STORED; }
 
 // Wave-cooperative copy of this wave's [rows, D] LDS tile to global memory (contiguous region).
 template <int D, int TR, bool SADDR>
@@ -255,7 +259,7 @@ PDS_DEV void store_state(const StepArgs &a, const Idx<V> i_, int new_parity, con
   st_store4(at(a.st.s1, i), make_float4(e.vy, e.vz, e.roll, e.pitch));
   st_store4(at(a.st.s2, i), make_float4(e.yaw, e.wx, e.wy, e.wz));
   st_store4(at(a.st.hist[new_parity], i), S.h1);
-  *at(a.st.ctr, i) = S.ctr;
+  *at(a.st.ctr, i) = flags_oh_variant<V>() ? (S.ctr | kCtrOhBit) : S.ctr;
   if (V::MOTOR) *at(a.st.mx, i) = make_float4(S.xm[0], S.xm[1], S.xm[2], S.xm[3]);
   if (V::TN) *at(a.st.ou, i) = make_float4(S.ns.ou[0], S.ns.ou[1], S.ns.ou[2], S.ns.ou[3]);
   if (V::CTRL >= 1) {
@@ -1137,28 +1141,34 @@ __global__ __launch_bounds__(kBlock, (PDS_MIN_WAVES) * (256 / kBlock)) void step
 // K env.step()s per launch for open-loop action sequences (pds_step_k): the env state stays in
 // registers, per step only the action (16 B) comes in and the observation row, reward, cost and flags
 // go out -- 4 D + 26 B per env-step instead of 4 D + 178 B, and one launch instead of K.
-// K-step kernel: the state of the env stays in registers across the loop, so the noise variants need more than the
-// 168 VGPRs of 3 blocks per CU (27-74 spilled registers inside the loop); at 2 blocks per CU they spill nothing.
-// Same box, 2^20 envs, K = 8, us per env-step, 3 vs 2: Hover noise + DR 86.1 vs 80.1, + PT1 102.2 vs 83.9, latency
-// ring 116.7 vs 88.7, Circle default 85.3 vs 77.1; TakeOff (hardly any resets) 49.2 vs 53.2 and the noise-free
-// variants 47.4 vs 46.5 / 49.0 vs 49.5 keep 3 (profiles/r02_variant_timings_stepk_minwaves.txt).
+// K-step kernel: the state of the env stays in registers across the loop.  Rounds 2-3: the noise variants needed more than
+// the 168 VGPRs of 3 blocks per CU (27-74 spilled registers inside the loop at that cap) and were built for 2
+// (profiles/r02_variant_timings_stepk_minwaves.txt).  Round 4: with the kept observation read from memory (StoredOh, below)
+// they need 144-186, and at the 168 cap 45 of the 288 kernels spill 1-15 registers: 3 blocks per CU for all of them.  Same
+// box, 2^20 envs, K = 8, us per env-step, cap 168 vs 256: Hover latency ring + noise 69.0 vs 83.6, Kalman hold 74.2 vs 86.9, Circle
+// PT1 + noise 61.5 vs 70.7, Circle latency 77.9 vs 81.6, everything else equal (profiles/r04_ab_stepk_regen.txt).
 #ifndef PDS_STEPK_OPAQUE_KEY
 #define PDS_STEPK_OPAQUE_KEY 1  // A/B: 0 = round-3 form (key schedule hoisted out of the K loop and spilled)
 #endif
-#ifndef PDS_STEPK_MIN_WAVES
-#define PDS_STEPK_MIN_WAVES ((V::ON && V::TASK != PDS_TASK_TAKEOFF) ? 2 : 3)
+#ifndef PDS_STEPK_MIN_WAVES_OF
+#define PDS_STEPK_MIN_WAVES_OF(V) 3
 #endif
-template <class V>
-__global__ __launch_bounds__(kBlock, (PDS_STEPK_MIN_WAVES) * (256 / kBlock)) void step_k_kernel(const StepArgs a) {
+template <class V_>
+__global__ __launch_bounds__(kBlock, (PDS_STEPK_MIN_WAVES_OF(V_)) * (256 / kBlock)) void step_k_kernel(const StepArgs a) {
+  // (round 4) the kept noisy observation comes out of oh0-2 and goes back there: regenerating it in the prologue (the
+  // single-step kernels' way) took the register allocation of the whole loop from 152 to 200 VGPRs, i.e. from three blocks
+  // per CU to two -- Hover noise + DR, K = 8: 79.1 vs 64.7 us per env-step, 2 sub-steps 114.3 vs 95.9
+  // (profiles/r04_ab_stepk_regen.txt).  pds_step_k launches materialize_oh_kernel in front of this kernel.
+  using W = std::conditional_t<regen_obs_variant<V_>(), StoredOh<V_>, V_>;
   constexpr int TR = kWave;
-  constexpr int RM = merged_reset_variant<V>() ? RM_MERGED : RM_INLINE;
+  constexpr int RM = merged_reset_variant<W>() ? RM_MERGED : RM_INLINE;
 #ifdef PDS_STAMPS
   unsigned long long stamp_[kStampSlots];
 #endif
   prefetch_kernargs();
-  PDS_WAVE_SETUP(V, TR, RM)
+  PDS_WAVE_SETUP(W, TR, RM)
   Loaded cur;
-  load_env<V>(a, ix, t, cur);
+  load_env<W>(a, ix, t, cur);
   RngKey rk{a.seed_lo, a.seed_hi, 0u, 0u};
   int parity;
   rk.tick_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.clk.x);
@@ -1166,15 +1176,15 @@ __global__ __launch_bounds__(kBlock, (PDS_STEPK_MIN_WAVES) * (256 / kBlock)) voi
   parity = __builtin_amdgcn_readfirstlane((int)cur.clk.z) & 1;
   const RngKey rk0 = rk;
   EnvState S;
-  unpack_state<V>(a.k, cur, parity, S);
-  init_kept_obs<V>(a, rk, ix, S);
+  unpack_state<W>(a.k, cur, parity, S);
+  init_kept_obs<W>(a, rk, ix, S);
   const int K = a.k_steps;
   float4 act = cur.act;  // actions[0]
   int qcount = 0;
   for (int s = 0; s < K; ++s) {
     // a fresh view of the kernel arguments per iteration: what the loop body needs is re-read (scalar-cache
     // hits) instead of being hoisted out of the loop into SGPRs that do not exist (41-79 spills in round 2)
-    const StepArgs &al = reload_args<106, PDS_STEPK_OPAQUE_KEY || heavy_variant<V>()>(a, s);
+    const StepArgs &al = reload_args<106, PDS_STEPK_OPAQUE_KEY || heavy_variant<W>()>(a, s);
     // ... and the Philox key: the 2 x 10 round keys (seed + r x Weyl constant) are loop-invariant, so the compiler forms
     // them in the loop header and -- with the 102 SGPRs taken -- spills them to VGPR lanes there and reads them back in
     // every round of every Philox call of every iteration (2-45 spilled SGPRs per step_k kernel in round 3).  An opaque
@@ -1187,14 +1197,14 @@ __global__ __launch_bounds__(kBlock, (PDS_STEPK_MIN_WAVES) * (256 / kBlock)) voi
     if (PDS_STEPK_OPAQUE_KEY) asm volatile("" : "+v"(lane_s));
     float4 act_next = act;
     if (s + 1 < K) act_next = nt_load4(at(al.actions + (long long)(s + 1) * al.n, ix));  // in flight during step s
-    step_once<V, TR, RM, false>(al, (long long)s * al.n, rks, parity, ref_lds, tile, park, queue, scratch, lane_s, wave_base, ix, active, act, S, qcount, nullptr, nullptr PDS_STAMP_ARG);
+    step_once<W, TR, RM, false>(al, (long long)s * al.n, rks, parity, ref_lds, tile, park, queue, scratch, lane_s, wave_base, ix, active, act, S, qcount, nullptr, nullptr PDS_STAMP_ARG);
     act = act_next;
     parity ^= 1;
     rk.tick_lo += 1u;
     if (rk.tick_lo == 0u) rk.tick_hi += 1u;
   }
-  const StepArgs &az = reload_args<107, heavy_variant<V>()>(a);
-  if (active) store_state<V>(az, ix, parity, S, true);
+  const StepArgs &az = reload_args<107, heavy_variant<W>()>(a);
+  if (active) store_state<W>(az, ix, parity, S, true);
   advance_clock(az.st.clk, t, rk0, parity, (uint32_t)K, lane);
 }
 

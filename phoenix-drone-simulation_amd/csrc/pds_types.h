@@ -254,6 +254,15 @@ struct Variant {
   static constexpr int O = ON_ ? (TASK_ == PDS_TASK_HOVER ? 13 : (TASK_ == PDS_TASK_CIRCLE ? 16 : 20))
                                : (TASK_ == PDS_TASK_HOVER ? 17 : (TASK_ == PDS_TASK_CIRCLE ? 16 : 20));
   static constexpr int D = 2 * (O + 4);
+  static constexpr bool OH_STORED = false;  // see StoredOh
+};
+
+// The same variant for a kernel that finds the kept noisy observation of EVERY env in oh0-2 (flagged kCtrOhBit by
+// materialize_oh_kernel, csrc/pds_api.hip) and leaves it there: the K-step kernel, which reads and writes the state once per
+// K steps -- regenerating in its prologue cost it 40-50 VGPRs over the whole loop (csrc/pds_step.h, step_k_kernel).
+template <class V>
+struct StoredOh : V {
+  static constexpr bool OH_STORED = true;
 };
 
 struct EnvRegs {
