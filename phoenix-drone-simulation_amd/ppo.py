@@ -18,6 +18,7 @@ PyTorch is used for what it is good at here: the two tiny MLPs and Adam.
 """
 import ctypes as C
 import math
+
 import time
 
 import torch
@@ -216,8 +217,10 @@ class PPOTrainer:
                  train_v_iterations=5, num_mini_batches=16, target_kl=0.01, use_kl_early_stopping=False,
                  use_linear_lr_decay=True, use_exploration_noise_anneal=True, use_reward_scaling=True,
                  use_standardized_obs=True, use_max_grad_norm=False, max_grad_norm=0.5, ac_kwargs=None,
-                 seed=0, fused=None, graph_rollout=None, fused_rollout=None, reset_each_rollout=False):
+                 seed=0, fused=None, graph_rollout=None, fused_rollout=None, reset_each_rollout=False,
+                 overlap_value_update=True):
         self.env, self.T, self.N = env, int(rollout_len), env.num_envs
+        self.overlap_value_update, self._side_stream = bool(overlap_value_update), None
         self.epochs, self.gamma, self.lam, self.clip_ratio = epochs, gamma, lam, clip_ratio
         self.entropy_coef = entropy_coef if use_entropy else 0.0
         self.train_pi_iterations, self.train_v_iterations = train_pi_iterations, train_v_iterations
@@ -477,17 +480,35 @@ class PPOTrainer:
         obs, target_v = data["obs"].contiguous(), data["target_v"].contiguous()
         with torch.no_grad():
             loss_v_before = ((self.fm_v.forward(obs).view(-1) - target_v) ** 2).mean()
-        for _ in range(self.train_v_iterations):
-            # one elementwise launch (pds_permutation) where torch.randperm sorts (~160 us at 2^19 samples, 5 x per epoch)
-            self._perm_calls += 1
-            perm = random_permutation(B, self._sample_seed ^ 0x5045524D, self._perm_calls, obs.device)
-            for s in range(0, mbs * self.num_mini_batches, mbs):
-                if world == 1:  # the Adam step rides on the gradient's partial-sum kernel (same bits, one launch less)
-                    self.fm_v.value_grad(obs, target_v, index=perm[s:s + mbs], adam_lr=self.vf_opt.param_groups[0]["lr"])
-                    continue
-                self.fm_v.value_grad(obs, target_v, index=perm[s:s + mbs])
-                average(self.fm_v)
-                self.fm_v.adam_step(self.vf_opt.param_groups[0]["lr"])
+
+        def value_update():
+            for _ in range(self.train_v_iterations):
+                # one elementwise launch (pds_permutation) where torch.randperm sorts (~160 us at 2^19 samples, 5 x per epoch)
+                self._perm_calls += 1
+                perm = random_permutation(B, self._sample_seed ^ 0x5045524D, self._perm_calls, obs.device)
+                for s in range(0, mbs * self.num_mini_batches, mbs):
+                    if world == 1:  # the Adam step rides on the gradient's partial-sum kernel (same bits, one launch less)
+                        self.fm_v.value_grad(obs, target_v, index=perm[s:s + mbs], adam_lr=self.vf_opt.param_groups[0]["lr"])
+                        continue
+                    self.fm_v.value_grad(obs, target_v, index=perm[s:s + mbs])
+                    average(self.fm_v)
+                    self.fm_v.adam_step(self.vf_opt.param_groups[0]["lr"])
+
+        # The two updates share no state (two networks, two optimisers, read-only batch): single process, the value net's 80
+        # mini-batch steps -- each 10 us of work behind ~27 us of fixed latency -- run on a second stream next to the policy
+        # net's 80 full-batch steps instead of in front of them.  Same launches, same bits.  (Several ranks: the two nets'
+        # all-reduces would have to be issued in one order on every rank: kept sequential.)
+        side = None
+        if world == 1 and self.overlap_value_update and obs.is_cuda:
+            main = torch.cuda.current_stream(obs.device)
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=obs.device)  # (a high-priority stream: no gain, profiles/r04_ppo_overlap.txt)
+            side = self._side_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                value_update()
+        else:
+            value_update()
         act, adv, logp_old = data["act"].contiguous(), data["adv"].contiguous(), data["log_p"].contiguous()
         log_std = ac.pi.log_std
         # entropy of Normal(., sigma): sum(0.5 + 0.5 log 2 pi + log sigma), independent of the network
@@ -516,6 +537,8 @@ class PPOTrainer:
                 if kl.item() > self.target_kl:
                     stop_iter = i + 1
                     break
+        if side is not None:
+            torch.cuda.current_stream(obs.device).wait_stream(side)
         if self.use_standardized_obs:
             ac.obs_oms.update(raw_obs)
         if self.use_reward_scaling:

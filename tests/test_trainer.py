@@ -303,6 +303,30 @@ def test_graph_captured_rollout_equals_eager_rollout_bitwise():
 
 
 @pytest.mark.gpu
+def test_value_update_on_a_second_stream_equals_the_sequential_update_bitwise():
+    """PPOTrainer(overlap_value_update=True) runs the value net's mini-batch steps on a second HIP stream next to the
+    policy net's full-batch steps: same launches on disjoint state, so every parameter and both optimiser states come
+    out bit for bit as from the sequential order, epoch after epoch."""
+    import phoenix_drone_simulation_amd as pds
+    from phoenix_drone_simulation_amd.ppo import PPOTrainer
+    mk = lambda o: PPOTrainer(pds.make("DroneHoverSimpleEnv-v0", num_envs=2048, seed=5), rollout_len=16, epochs=5,
+                              train_pi_iterations=12, train_v_iterations=3, seed=5, fused=True, overlap_value_update=o)
+    a, b = mk(True), mk(False)
+    for ep in range(3):
+        ia, ib = a.learn_one_epoch(), b.learn_one_epoch()
+        torch.cuda.synchronize()
+        assert a._side_stream is not None and b._side_stream is None
+        for (ka, pa), (kb, pb) in zip(a.ac.state_dict().items(), b.ac.state_dict().items()):
+            assert ka == kb and torch.equal(pa, pb), (ep, ka)
+        for oa, ob in ((a.pi_opt, b.pi_opt), (a.vf_opt, b.vf_opt)):
+            for sa, sb in zip(oa.state.values(), ob.state.values()):
+                for k in sa:
+                    assert torch.equal(torch.as_tensor(sa[k]), torch.as_tensor(sb[k])), (ep, k)
+        assert ia["loss_pi"] == ib["loss_pi"] and ia["loss_v"] == ib["loss_v"], (ep, ia, ib)
+    a.env.close(); b.env.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("task,kw,n", [
     ("DroneHoverSimpleEnv-v0", dict(observation_noise=-1, domain_randomization=-1, motor_thrust_noise=0), 512),
     ("DroneHoverSimpleEnv-v0", dict(), 1000),                                   # reference defaults, ragged last tile
