@@ -73,6 +73,39 @@ def test_step_k_equals_k_single_steps_bitwise(task, kw, N):
     e1.close(); ek.close()
 
 
+@pytest.mark.parametrize("task,kw", [VARIANTS[3], VARIANTS[4], VARIANTS[10], ("hover", dict(aggregate_phy_steps=2, use_motor_dynamics=True))])
+def test_step_k_between_single_steps_bitwise(task, kw):
+    """pds_step and pds_step_k interleaved.  The single-step kernels of the observation-noise variants do not keep the noisy
+    o(k) in memory (it is regenerated), the K-step kernel reads it from oh0-2: pds_step_k materialises it first
+    (materialize_oh_kernel) for the envs a pds_step has left unflagged, and a pds_step after a pds_step_k finds every env
+    flagged.  Either way the trajectory is the one of single steps, bit for bit."""
+    import phoenix_drone_simulation_amd as pds
+    N = 1500
+    mk = lambda: pds.make(ENV_ID[task], num_envs=N, seed=21, max_episode_steps=7, **kw)
+    e1, em = mk(), mk()
+    e1.reset(); em.reset()
+    plan = [1, 1, 5, 1, 4, 3, 1, 1, 6]  # 1 = pds_step, K > 1 = pds_step_k
+    for r, K in enumerate(plan):
+        acts = _actions(K, N, e1.device, seed=50 + r)
+        if K == 1:
+            o, rw, te, tr, info = em.step(acts[0])
+            got = (o[None], rw[None], te[None], tr[None], info["cost"][None], info["final_obs"][None])
+        else:
+            o, rw, te, tr, info = em.step_k(acts)
+            got = (o, rw, te, tr, info["cost"], info["final_obs"])
+        for s in range(K):
+            o1, rw1, te1, tr1, info1 = e1.step(acts[s])
+            w = f"{task} call {r} step {s}"
+            fin = te1 | tr1
+            assert torch.equal(o1, got[0][s]) and torch.equal(rw1, got[1][s]), w
+            assert torch.equal(te1, got[2][s]) and torch.equal(tr1, got[3][s]) and torch.equal(info1["cost"], got[4][s]), w
+            assert torch.equal(info1["final_obs"][fin], got[5][s][fin]), w
+        for name in ("pos", "rpy", "omega", "gyro_bias", "gyro_lpf", "noisy_obs", "step_count"):
+            assert torch.equal(e1.get_state(name), em.get_state(name)), (r, name)
+    assert e1.tick == em.tick
+    e1.close(); em.close()
+
+
 def test_step_k_ragged_and_no_autoreset():
     import phoenix_drone_simulation_amd as pds
     for N in (1, 63, 321):
