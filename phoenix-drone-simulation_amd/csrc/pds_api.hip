@@ -898,7 +898,11 @@ extern "C" int pds_rollout(pds_handle *h, int T, const pds_mlp *pi, const pds_ml
   ra.act_buf = d_act_buf; ra.logp_buf = d_logp_buf; ra.val_buf = d_val_buf; ra.fval_buf = d_fval_buf; ra.last_val = d_last_val;
   ra.ep_ret = d_ep_ret; ra.ep_len = d_ep_len; ra.stats = d_stats;
   const long long tiles = (n + kWave - 1) / kWave;
-  const dim3 grid((unsigned)((tiles + kRolloutTiles - 1) / kRolloutTiles));  // one block per kRolloutTiles tiles
+  const dim3 grid((unsigned)tiles);  // (the number of tiles: the launchers pick one or two tiles per block, csrc/pds_rollout.h)
+  // the env waves read the kept noisy observation from oh0-2 (StoredOh, like the K-step kernel)
+  if (PDS_REGEN_OBS && h->flags.on && !h->flags.hold)
+    hipLaunchKernelGGL(pds::materialize_oh_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+                       h->st, h->k, n, ra.s.env_id_base, ra.s.seed_lo, ra.s.seed_hi);
   bool ok;
   if (h->cfg.task == PDS_TASK_HOVER) ok = launch_rollout_hover(h->flags, grid, (hipStream_t)stream, ra);
   else if (h->cfg.task == PDS_TASK_CIRCLE) ok = launch_rollout_circle(h->flags, grid, (hipStream_t)stream, ra);

@@ -40,12 +40,22 @@
 
 namespace pds {
 
+#ifndef PDS_ROLLOUT_TWO_TEAMS_ABOVE
+#define PDS_ROLLOUT_TWO_TEAMS_ABOVE 256  // tiles (one per CU)
+#endif
+constexpr int kRolloutTwoTeamsAbove = PDS_ROLLOUT_TWO_TEAMS_ABOVE;
+#ifndef PDS_ROLLOUT_ENV_PRIO
+#define PDS_ROLLOUT_ENV_PRIO 3
+#endif
+#ifndef PDS_ROLLOUT_ACTOR_PRIO
+#define PDS_ROLLOUT_ACTOR_PRIO 0
+#endif
 #ifndef PDS_ROLLOUT_SKIP
 #define PDS_ROLLOUT_SKIP 0  // profiling builds only: 1 = no actor / critic passes, 2 = no env step, 4 = no V(final_obs)
 #endif
 constexpr int kRolloutMlpWaves = 4;               // network waves per block (16 rows of the tile each)
-constexpr int kRolloutThreads = kWave * (kRolloutMlpWaves + 1);  // + the env wave
-static_assert(kRolloutTiles == 1, "one tile per block (pds_api.hip sizes the grid with kRolloutTiles)");
+constexpr int kRolloutTeamWaves = kRolloutMlpWaves + 1;    // + the env wave: one TEAM per 64-env tile
+constexpr int kRolloutThreads = kWave * kRolloutTeamWaves;  // threads per team
 
 // network input of this lane: features 16 kt + 4 g + q of row `r` of an LDS image with row stride `stride`
 template <int NIN>
@@ -74,9 +84,15 @@ PDS_DEV void rollout_post(int *flag, int lane) {  // +1, after every lane's LDS 
   if (lane == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <class V>
-__global__ __launch_bounds__(kRolloutThreads, 1) void rollout_kernel(const RolloutArgs ra) {
+// TEAMS: tiles (= teams of 4 network waves + 1 env wave) per block.  One team per block is the latency form (8 192 envs:
+// 128 blocks on 256 CUs); with more tiles than CUs the network waves' idle time -- they work 5-9 of a step's 14 us -- is
+// what a second team on the same CU fills: the two teams share nothing but the weight images (84 of the block's 124 KB
+// of LDS) and the CU.  (Ten waves per CU = three per SIMD on two SIMDs: the 168-register cap, which the env wave only
+// meets because it reads the kept noisy observation from memory, StoredOh, like the K-step kernel.)
+template <class V_, int TEAMS>
+__global__ __launch_bounds__(kRolloutThreads * TEAMS, 1) void rollout_kernel(const RolloutArgs ra) {
   using namespace pds_mlpf;
+  using V = std::conditional_t<regen_obs_variant<V_>(), StoredOh<V_>, V_>;
   constexpr int D = V::D;
   constexpr int TS = tile_stride<D>();
   constexpr int NIN = (D + 15) / 16;
@@ -86,13 +102,13 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void rollout_kernel(const Rollo
   __shared__ __attribute__((aligned(16))) float net_pi[kNetFloats];
   __shared__ __attribute__((aligned(16))) float net_vf[kNetFloats];
   __shared__ __attribute__((aligned(16))) float mus[64], iss[64];
-  __shared__ __attribute__((aligned(16))) float tile_all[kRolloutTiles][kWave * TS];
-  __shared__ __attribute__((aligned(16))) float fin_all[kRolloutTiles][kWave * D];
-  __shared__ __attribute__((aligned(16))) float4 act_all[kRolloutTiles][kWave];
-  __shared__ uint32_t done_all[kRolloutTiles][kWave];
-  __shared__ uint32_t queue_all[kRolloutTiles][kQueueCap];
-  __shared__ U4 scratch_all[kRolloutTiles][kScratchU4_ > 0 ? kScratchU4_ : 1];
-  __shared__ int obs_ready[kRolloutTiles], act_ready[kRolloutTiles];
+  __shared__ __attribute__((aligned(16))) float tile_all[TEAMS][kWave * TS];
+  __shared__ __attribute__((aligned(16))) float fin_all[TEAMS][kWave * D];
+  __shared__ __attribute__((aligned(16))) float4 act_all[TEAMS][kWave];
+  __shared__ uint32_t done_all[TEAMS][kWave];
+  __shared__ uint32_t queue_all[TEAMS][kQueueCap];
+  __shared__ U4 scratch_all[TEAMS][kScratchU4_ > 0 ? kScratchU4_ : 1];
+  __shared__ int obs_ready[TEAMS], act_ready[TEAMS];
 #ifdef PDS_STAMPS
   unsigned long long stamp_[kStampSlots];
 #endif
@@ -100,12 +116,14 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void rollout_kernel(const Rollo
   const StepArgs &a = ra.s;
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int team = __builtin_amdgcn_readfirstlane(tid / kRolloutThreads);                   // wave-uniform
+  const int wave = __builtin_amdgcn_readfirstlane((tid - team * kRolloutThreads) >> 6);     // wave within its team
   const bool is_env = wave >= kRolloutMlpWaves;
+  constexpr int kThreads = kRolloutThreads * TEAMS;
   const int n16 = lane & 15, g = lane >> 4;
   const NetLds wpi = net_lds(net_pi), wvf = net_lds(net_vf);
   const long long ntiles = (a.n + kWave - 1) / kWave;
-  const long long tile0 = (long long)blockIdx.x * kRolloutTiles;  // first 64-env tile of this block
+  const long long tile0 = (long long)blockIdx.x * TEAMS;  // first 64-env tile of this block
   const int T = ra.T;
   const int d_out = ra.pi.d_out;
   auto tile_rows = [&](int j) -> int {  // envs of tile j of this block (0: the last block of an odd tile count)
@@ -116,18 +134,18 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void rollout_kernel(const Rollo
   };
 
   // ---- prologue: networks, statistics and o(0) into LDS; env state into the env waves' registers --------------
-  stage_net(ra.pi, wpi, tid, kRolloutThreads);
-  stage_net(ra.vf, wvf, tid, kRolloutThreads);
+  stage_net(ra.pi, wpi, tid, kThreads);
+  stage_net(ra.vf, wvf, tid, kThreads);
   if (tid < 64) {
     const bool on = ra.mean != nullptr && tid < D;
     mus[tid] = on ? ra.mean[tid] : 0.f;
     iss[tid] = on ? 1.0f / (ra.stdv[tid] + ra.eps) : 1.f;
   }
-  if (tid < kRolloutTiles) { obs_ready[tid] = 0; act_ready[tid] = 0; }
+  if (tid < TEAMS) { obs_ready[tid] = 0; act_ready[tid] = 0; }
 #pragma unroll
-  for (int j = 0; j < kRolloutTiles; ++j) {
+  for (int j = 0; j < TEAMS; ++j) {
     const int rows = tile_rows(j);
-    for (int idx = tid; idx < kWave * D; idx += kRolloutThreads) {
+    for (int idx = tid; idx < kWave * D; idx += kThreads) {
       const int r = idx / D, c = idx - r * D;
       tile_all[j][r * TS + c] = (r < rows) ? ra.obs0[((tile0 + j) * kWave + r) * D + c] : 0.f;
     }
@@ -139,7 +157,10 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void rollout_kernel(const Rollo
 
   if (is_env) {
     // ================================ env wave: one tile's 64 envs in registers =================================
-    const int grp = wave - kRolloutMlpWaves;
+    const int grp = team;
+#if PDS_ROLLOUT_ENV_PRIO
+    __builtin_amdgcn_s_setprio(PDS_ROLLOUT_ENV_PRIO);  // the env wave's instructions before its SIMD-mates' (network waves)
+#endif
     const long long t = tile0 + grp;
     if (t >= ntiles) return;
     const long long wave_base = t * kWave;
@@ -205,11 +226,12 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void rollout_kernel(const Rollo
   // ================================ network waves: 16 rows of the tile each ====================================
   // rows 16 w .. 16 w + 15 are wave w's; the critic of wave 0's rows runs on wave 1 and their V(final_obs) on wave 2
   // (wave 0 shares its SIMD with the env wave: it only works while that one waits).
-  constexpr int j = 0;
+  const int j = team;
   const int rows = tile_rows(j);
+  if (rows == 0) return;  // (the last block of an odd tile count: this team has no env wave to wait for)
   const int own = wave * 16 + n16;  // this lane's sample row
   const bool own_ok = own < rows, r0_ok = n16 < rows;
-  const long long env_own = tile0 * kWave + own, env_r0 = tile0 * kWave + n16;
+  const long long env_own = (tile0 + j) * kWave + own, env_r0 = (tile0 + j) * kWave + n16;
   for (int s = 0; s <= T; ++s) {  // s == T: only V(o(T)) and the last step's V(final_obs)
     const RolloutArgs &rl = *reinterpret_cast<const RolloutArgs *>(&reload_args<203, true>(ra.s, s));
     const long long o1 = (long long)s * rl.s.n;
@@ -233,6 +255,9 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void rollout_kernel(const Rollo
       }
     }
     rollout_wait_ge(&obs_ready[j], s);  // o(s) and the outcome of step s - 1 are in LDS
+#if PDS_ROLLOUT_ACTOR_PRIO
+    __builtin_amdgcn_s_setprio(PDS_ROLLOUT_ACTOR_PRIO);  // the actor pass is on the step's critical path, the critic passes are not
+#endif
     gather_input<NIN>(tile_all[j], TS, own, D, mus, iss, g, x_own);
     if (wave == 1) gather_input<NIN>(tile_all[j], TS, n16, D, mus, iss, g, x_r0);
     const bool skip_fin = (PDS_ROLLOUT_SKIP & 4) != 0;
@@ -261,6 +286,9 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void rollout_kernel(const Rollo
       }
       rollout_post(&act_ready[j], lane);  // this wave is done with the tile, `fin` and the flags of step s - 1
     }
+#if PDS_ROLLOUT_ACTOR_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     // ---- off the critical path: the env wave is stepping (wave 0, its SIMD-mate, stays quiet) ------------------
     auto critic = [&](const f32x4 (&x)[NIN]) -> float {
       const f32x4 v = (rl.vf.activation == 0) ? forward16_shape<0, NIN>(wvf, rl.vf, x, n16, g) : forward16_shape<1, NIN>(wvf, rl.vf, x, n16, g);
@@ -301,7 +329,15 @@ inline bool launch_rollout_family(const LaunchFlags &f, dim3 grid, hipStream_t s
   const bool lean = !f.dr && !f.tn && !f.on, full = f.dr && f.tn && f.on;
   if (!lean && !full) return false;
   if (TASK == PDS_TASK_TAKEOFF && f.motor && !LAT) return false;
-#define PDS_ROLLOUT_LAUNCH(M, X) hipLaunchKernelGGL((rollout_kernel<Variant<TASK, M, X, false, X, X, CTRL, LAT, false>>), grid, dim3(kRolloutThreads), 0, s, ra)
+  // `grid.x` = number of 64-env tiles; more tiles than CUs: two teams per block
+#define PDS_ROLLOUT_LAUNCH(M, X)                                                                                           \
+  do {                                                                                                                     \
+    using RV_ = Variant<TASK, M, X, false, X, X, CTRL, LAT, false>;                                                         \
+    if (grid.x > (unsigned)kRolloutTwoTeamsAbove)                                                                            \
+      hipLaunchKernelGGL((rollout_kernel<RV_, 2>), dim3((grid.x + 1) / 2), dim3(2 * kRolloutThreads), 0, s, ra);          \
+    else                                                                                                                   \
+      hipLaunchKernelGGL((rollout_kernel<RV_, 1>), grid, dim3(kRolloutThreads), 0, s, ra);                                 \
+  } while (0)
   if constexpr (TASK == PDS_TASK_TAKEOFF && !LAT) {
     if (full) PDS_ROLLOUT_LAUNCH(false, true); else PDS_ROLLOUT_LAUNCH(false, false);
   } else {

@@ -351,7 +351,6 @@ struct LaunchFlags {
 enum LaunchKind { kLaunchStep = 0, kLaunchStepK = 1, kLaunchReset = 2 };
 // one translation unit per (task, family) keeps the build parallel: pds_task_*.hip
 // Arguments of the fused rollout (csrc/pds_rollout.h).
-constexpr int kRolloutTiles = 1;  // 64-env tiles per block of the fused rollout
 struct RolloutArgs {
   StepArgs s;  // FIRST member (reload_args reads the kernarg segment as a StepArgs); reward / term / trunc / cost point
                // at the [T, N] rollout buffers, obs at obs_buf + N D (step t writes o(t + 1) into row t + 1)

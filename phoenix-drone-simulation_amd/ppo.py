@@ -256,10 +256,8 @@ class PPOTrainer:
         # ONE launch per rollout (csrc/pds_rollout.h: networks + sampling + env step + bookkeeping for all T steps,
         # the env state in registers, the observation tile in LDS); None = use it when the env configuration has an
         # instantiation (found out at the first rollout), False = the per-step kernels (same bits)
-        if fused_rollout is None and env.num_envs > 262144:
-            # one 64-env tile per 256-thread block, one block per CU: from ~2^19 envs the per-step kernels (all CUs
-            # streaming, 3-4 blocks per CU) win -- 2^20 x 8: 9.1 vs 6.3 ms; 65 536 x 32: 2.2 vs 3.0; 8 192 x 64: 1.1 vs 4.1
-            fused_rollout = False
+        # (round 3 fell back to the per-step kernels above 262 144 envs, where one tile per block lost -- 2^20 x 8: 9.1 vs 6.3 ms;
+        #  with two tiles per block where there are more tiles than CUs the one-launch form wins at every size: 5.6 vs 6.1 ms)
         self.fused_rollout = fused_rollout
         if self.fused:
             from .fused import FusedMLP

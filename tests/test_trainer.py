@@ -338,6 +338,10 @@ def test_value_update_on_a_second_stream_equals_the_sequential_update_bitwise():
     ("DroneHoverSimpleEnv-v0", dict(use_latency=True, latency=0.02), 256),
     ("DroneHoverSimpleEnv-v0", dict(observation_noise=-1, domain_randomization=-1, motor_thrust_noise=0, use_latency=True,
                                     latency=0.035, control_mode="PWM"), 130),
+    # more tiles than CUs: two tiles (teams) per block; an odd tile count leaves the last block with one
+    ("DroneHoverSimpleEnv-v0", dict(), 64 * 313 - 7),
+    ("DroneCircleSimpleEnv-v0", dict(control_mode="AttitudeRate", aggregate_phy_steps=2, use_motor_dynamics=True), 64 * 258),
+    ("DroneTakeOffSimpleEnv-v0", dict(observation_noise=-1, domain_randomization=-1, motor_thrust_noise=0), 64 * 300),
 ])
 def test_fused_rollout_equals_per_step_rollout_bitwise(task, kw, n):
     """pds_rollout (ONE launch for the T closed-loop steps: both networks on the matrix cores, Gaussian sampling, env
