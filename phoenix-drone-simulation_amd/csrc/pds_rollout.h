@@ -44,6 +44,14 @@ namespace pds {
 #define PDS_ROLLOUT_TWO_TEAMS_ABOVE 256  // tiles (one per CU)
 #endif
 constexpr int kRolloutTwoTeamsAbove = PDS_ROLLOUT_TWO_TEAMS_ABOVE;
+// Network wave 0 shares its SIMD with the env wave.  Where the env wave's step is long (observation noise: 20 k cycles per step,
+// 14 k of them the in-place reset of the finished envs) wave 0 stays quiet while it runs and waves 1 / 2 take its critic
+// passes; where it is short (lean variants: 8 k cycles) the network waves' shadow work is what bounds the step, and wave 0
+// does its own share (same box, 8 192 x 64 lean: 0.91 -> 0.76 ms; default config 0.96 -> 1.05 the other way;
+// profiles/r04_rollout_timing.txt).
+#ifndef PDS_ROLLOUT_M0_QUIET
+#define PDS_ROLLOUT_M0_QUIET (V::ON)
+#endif
 #ifndef PDS_ROLLOUT_ENV_PRIO
 #define PDS_ROLLOUT_ENV_PRIO 3
 #endif
@@ -180,10 +188,19 @@ __global__ __launch_bounds__(kRolloutThreads * TEAMS, 1) void rollout_kernel(con
     init_kept_obs<V>(a, rk, ix, S);
     float ep_ret = *at(ra.ep_ret, ix), ep_len = *at(ra.ep_len, ix), st0 = 0.f, st1 = 0.f, st2 = 0.f;
     int qcount = 0;
+#ifdef PDS_ROLLOUT_TIMING
+    unsigned long long tw = 0, ts = 0, tp = 0, tph = 0, tout = 0, trst = 0;
+#endif
     for (int s = 0; s < T; ++s) {
       const RolloutArgs &rl = *reinterpret_cast<const RolloutArgs *>(&reload_args<201, true>(ra.s, s));
       const long long o1 = (long long)s * rl.s.n;
+#ifdef PDS_ROLLOUT_TIMING
+      const unsigned long long q0 = __builtin_amdgcn_s_memtime();
+#endif
       rollout_wait_ge(&act_ready[grp], kRolloutMlpWaves * (s + 1));  // the network waves have read o(s) and written a(s)
+#ifdef PDS_ROLLOUT_TIMING
+      const unsigned long long q1 = __builtin_amdgcn_s_memtime();
+#endif
       if (!(PDS_ROLLOUT_SKIP & 2)) {
         // (opaque per-iteration copies of the seed and the lane index: see step_k_kernel -- their loop-invariant
         //  derivatives would otherwise be formed in the loop header and spilled)
@@ -205,8 +222,23 @@ __global__ __launch_bounds__(kRolloutThreads * TEAMS, 1) void rollout_kernel(con
         ep_len = dn ? 0.f : el;
         done_all[grp][lane] = dn ? 1u : 0u;
       }
+#ifdef PDS_ROLLOUT_TIMING
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const unsigned long long q2 = __builtin_amdgcn_s_memtime();
+#endif
       rollout_post(&obs_ready[grp], lane);  // o(s + 1) in the tile, the finished envs' last rows in `fin`, flags
+#ifdef PDS_ROLLOUT_TIMING
+      const unsigned long long q3 = __builtin_amdgcn_s_memtime();
+      tw += q1 - q0; ts += q2 - q1; tp += q3 - q2;
+#ifdef PDS_STAMPS
+      if (!(PDS_ROLLOUT_SKIP & 2)) { tph += stamp_[3] - q1; tout += stamp_[4] - stamp_[3]; trst += stamp_[5] - stamp_[4]; }
+#endif
+#endif
     }
+#ifdef PDS_ROLLOUT_TIMING
+    if (blockIdx.x == 0 && team == 0 && lane == 0) { ra.stats[8] = (float)tw / T; ra.stats[9] = (float)ts / T; ra.stats[10] = (float)tp / T;
+      ra.stats[11] = (float)tph / T; ra.stats[12] = (float)tout / T; ra.stats[13] = (float)trst / T; }
+#endif
     const RolloutArgs &rl = *reinterpret_cast<const RolloutArgs *>(&reload_args<202, true>(ra.s, T));
     if (active) {
       store_state<V>(rl.s, ix, parity, S, true);
@@ -232,7 +264,13 @@ __global__ __launch_bounds__(kRolloutThreads * TEAMS, 1) void rollout_kernel(con
   const int own = wave * 16 + n16;  // this lane's sample row
   const bool own_ok = own < rows, r0_ok = n16 < rows;
   const long long env_own = (tile0 + j) * kWave + own, env_r0 = (tile0 + j) * kWave + n16;
+#ifdef PDS_ROLLOUT_TIMING
+  unsigned long long mw = 0, mg = 0, ma = 0, mp = 0, mc = 0, mpre = 0;
+#endif
   for (int s = 0; s <= T; ++s) {  // s == T: only V(o(T)) and the last step's V(final_obs)
+#ifdef PDS_ROLLOUT_TIMING
+    const unsigned long long r00 = __builtin_amdgcn_s_memtime();
+#endif
     const RolloutArgs &rl = *reinterpret_cast<const RolloutArgs *>(&reload_args<203, true>(ra.s, s));
     const long long o1 = (long long)s * rl.s.n;
     f32x4 x_own[NIN], x_r0[NIN], f_own[NIN], f_r0[NIN];
@@ -254,19 +292,31 @@ __global__ __launch_bounds__(kRolloutThreads * TEAMS, 1) void rollout_kernel(con
         sig[q] = expf(lsd[q]);
       }
     }
+#ifdef PDS_ROLLOUT_TIMING
+    const unsigned long long r0 = __builtin_amdgcn_s_memtime();
+#endif
     rollout_wait_ge(&obs_ready[j], s);  // o(s) and the outcome of step s - 1 are in LDS
+#ifdef PDS_ROLLOUT_TIMING
+    const unsigned long long r1 = __builtin_amdgcn_s_memtime();
+#endif
 #if PDS_ROLLOUT_ACTOR_PRIO
     __builtin_amdgcn_s_setprio(PDS_ROLLOUT_ACTOR_PRIO);  // the actor pass is on the step's critical path, the critic passes are not
 #endif
     gather_input<NIN>(tile_all[j], TS, own, D, mus, iss, g, x_own);
-    if (wave == 1) gather_input<NIN>(tile_all[j], TS, n16, D, mus, iss, g, x_r0);
+    constexpr bool kQuiet = PDS_ROLLOUT_M0_QUIET;
+    if (kQuiet && wave == 1) gather_input<NIN>(tile_all[j], TS, n16, D, mus, iss, g, x_r0);
     const bool skip_fin = (PDS_ROLLOUT_SKIP & 4) != 0;
     const bool dn_own = done_all[j][own] != 0u;                                   // (step s - 1; zeros before the first step)
-    const bool any_own = wave != 0 && __ballot(dn_own) != 0ull && !skip_fin;      // wave-uniform: one of these 16 envs finished
+    const bool any_own = (wave != 0 || !kQuiet) && __ballot(dn_own) != 0ull && !skip_fin;      // wave-uniform: one of these 16 envs finished
     const bool dn_r0 = done_all[j][n16] != 0u;
-    const bool any_r0 = wave == 2 && __ballot(dn_r0) != 0ull && !skip_fin;
+    const bool any_r0 = kQuiet && wave == 2 && __ballot(dn_r0) != 0ull && !skip_fin;
     if (any_own) gather_input<NIN>(fin_all[j], D, own, D, mus, iss, g, f_own);
     if (any_r0) gather_input<NIN>(fin_all[j], D, n16, D, mus, iss, g, f_r0);
+#ifdef PDS_ROLLOUT_TIMING
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned long long r2 = __builtin_amdgcn_s_memtime();
+    unsigned long long r3 = r2, r4 = r2;
+#endif
     if (s < T) {
       if (!(PDS_ROLLOUT_SKIP & 1)) {
         const f32x4 mu = (rl.pi.activation == 0) ? forward16_shape<0, NIN>(wpi, rl.pi, x_own, n16, g) : forward16_shape<1, NIN>(wpi, rl.pi, x_own, n16, g);
@@ -284,7 +334,13 @@ __global__ __launch_bounds__(kRolloutThreads * TEAMS, 1) void rollout_kernel(con
           }
         }
       }
+#ifdef PDS_ROLLOUT_TIMING
+      r3 = __builtin_amdgcn_s_memtime();
+#endif
       rollout_post(&act_ready[j], lane);  // this wave is done with the tile, `fin` and the flags of step s - 1
+#ifdef PDS_ROLLOUT_TIMING
+      r4 = __builtin_amdgcn_s_memtime();
+#endif
     }
 #if PDS_ROLLOUT_ACTOR_PRIO
     __builtin_amdgcn_s_setprio(0);
@@ -294,14 +350,14 @@ __global__ __launch_bounds__(kRolloutThreads * TEAMS, 1) void rollout_kernel(con
       const f32x4 v = (rl.vf.activation == 0) ? forward16_shape<0, NIN>(wvf, rl.vf, x, n16, g) : forward16_shape<1, NIN>(wvf, rl.vf, x, n16, g);
       return v[0];
     };
-    if (wave != 0 && !(PDS_ROLLOUT_SKIP & 1)) {
+    if ((wave != 0 || !kQuiet) && !(PDS_ROLLOUT_SKIP & 1)) {
       const float v = critic(x_own);
       if (g == 0 && own_ok) {
         if (s < T) rl.val_buf[o1 + env_own] = v;
         else rl.last_val[env_own] = v;
       }
     }
-    if (wave == 1 && !(PDS_ROLLOUT_SKIP & 1)) {
+    if (kQuiet && wave == 1 && !(PDS_ROLLOUT_SKIP & 1)) {
       const float v = critic(x_r0);
       if (g == 0 && r0_ok) {
         if (s < T) rl.val_buf[o1 + env_r0] = v;
@@ -317,7 +373,18 @@ __global__ __launch_bounds__(kRolloutThreads * TEAMS, 1) void rollout_kernel(con
       const float v = critic(f_r0);
       if (g == 0 && dn_r0 && r0_ok) rl.fval_buf[o1 - rl.s.n + env_r0] = v;
     }
+#ifdef PDS_ROLLOUT_TIMING
+    const unsigned long long r5 = __builtin_amdgcn_s_memtime();
+    if (s > 0 && s < T) { mpre += r0 - r00; mw += r1 - r0; mg += r2 - r1; ma += r3 - r2; mp += r4 - r3; mc += r5 - r4; }
+#endif
   }
+#ifdef PDS_ROLLOUT_TIMING
+  // (diagnostic builds: the caller's `stats` must have room for 64 floats -- profiles/tools/rollout_timing.py)
+  if (blockIdx.x == 0 && team == 0 && lane == 0) {
+    float *o = ra.stats + 16 + 8 * wave;
+    o[0] = (float)mpre / (T - 1); o[1] = (float)mw / (T - 1); o[2] = (float)mg / (T - 1); o[3] = (float)ma / (T - 1); o[4] = (float)mp / (T - 1); o[5] = (float)mc / (T - 1);
+  }
+#endif
 }
 
 // The variants the fused rollout is built for: {lean, reference default (DR + thrust noise + observation noise)} x
