@@ -304,7 +304,8 @@ typedef struct pds_mlp {
  *   V(o) -> d_val_buf[t];  a = mu(o) + exp(log_std) z, log p -> d_act_buf[t], d_logp_buf[t] (the draws of
  *   pds_gaussian_sample with call = *d_call_base + call_offset + t + 1);  env.step(a) (bitwise pds_step) ->
  *   d_rew_buf[t], d_term_buf[t], d_trunc_buf[t], d_cost_buf[t], next observation -> d_obs_buf[t + 1];
- *   V(final observation) of the envs that finished -> d_fval_buf[t] (other entries are left alone: pds_gae never
+ *   V(final observation) of the envs whose episode the TimeLimit cut at step t (truncated and not terminated: the
+ *   bootstrap value of algs/iwpg/iwpg.py:375-385) -> d_fval_buf[t] (other entries are left alone: pds_gae never
  *   reads them);  episode return / length bookkeeping of pds_rollout_record -> d_ep_ret, d_ep_len, d_stats[3]
  * -- and V(o(T)) -> d_last_val.  d_obs_buf is [T + 1, N, D]: row 0 holds o(0) on entry, rows 1..T are written.
  * Networks: actor d_in = D, d_out = 4; critic d_in = D, d_out = 1; hidden <= 64; inputs standardised with

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(kRolloutThreads * TEAMS, 1) void rollout_kernel(con
   constexpr int TS = tile_stride<D>();
   constexpr int NIN = (D + 15) / 16;
   constexpr int RM = merged_reset_variant<V>() ? RM_MERGED : RM_INLINE;
-  constexpr int kScratchU4_ = (RM == RM_MERGED) ? kMergedScratchU4 : (inline_coop_variant<V>() ? inline_envs_per_pass<V>() * scratch_stride<V>() : 0);
+  constexpr int kScratchU4_ = (RM == RM_MERGED) ? kMergedScratchU4 : (inline_coop_variant<V>() ? inline_envs<V, false>() * scratch_stride<V>() : 0);
   static_assert(D <= 64, "network input <= 64 features");
   __shared__ __attribute__((aligned(16))) float net_pi[kNetFloats];
   __shared__ __attribute__((aligned(16))) float net_vf[kNetFloats];
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(kRolloutThreads * TEAMS, 1) void rollout_kernel(con
     float ep_ret = *at(ra.ep_ret, ix), ep_len = *at(ra.ep_len, ix), st0 = 0.f, st1 = 0.f, st2 = 0.f;
     int qcount = 0;
 #ifdef PDS_ROLLOUT_TIMING
-    unsigned long long tw = 0, ts = 0, tp = 0, tph = 0, tout = 0, trst = 0;
+    unsigned long long tw = 0, ts = 0, tp = 0, tph = 0, tout = 0, trst = 0, tfin = 0, tev = 0;
 #endif
     for (int s = 0; s < T; ++s) {
       const RolloutArgs &rl = *reinterpret_cast<const RolloutArgs *>(&reload_args<201, true>(ra.s, s));
@@ -220,7 +220,10 @@ __global__ __launch_bounds__(kRolloutThreads * TEAMS, 1) void rollout_kernel(con
         if (dn) { st0 += er; st1 += el; st2 += 1.f; }
         ep_ret = dn ? 0.f : er;
         ep_len = dn ? 0.f : el;
-        done_all[grp][lane] = dn ? 1u : 0u;
+        // V(final_obs) is the bootstrap of an episode the TimeLimit cut (algs/iwpg/iwpg.py:375-385); one that terminated
+        // bootstraps with 0 and pds_gae never reads its fval entry: only the truncated envs ask the network waves for a pass
+        // (a young policy ends ~5 % of its episodes per step, nearly all of them by termination)
+        done_all[grp][lane] = (so.trunc && !so.done && active) ? 1u : 0u;
       }
 #ifdef PDS_ROLLOUT_TIMING
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -231,13 +234,13 @@ __global__ __launch_bounds__(kRolloutThreads * TEAMS, 1) void rollout_kernel(con
       const unsigned long long q3 = __builtin_amdgcn_s_memtime();
       tw += q1 - q0; ts += q2 - q1; tp += q3 - q2;
 #ifdef PDS_STAMPS
-      if (!(PDS_ROLLOUT_SKIP & 2)) { tph += stamp_[3] - q1; tout += stamp_[4] - stamp_[3]; trst += stamp_[5] - stamp_[4]; }
+      if (!(PDS_ROLLOUT_SKIP & 2)) { tph += stamp_[3] - q1; tout += stamp_[4] - stamp_[3]; trst += stamp_[5] - stamp_[4]; tfin += stamp_[6] - stamp_[4]; tev += stamp_[7] - stamp_[6]; }
 #endif
 #endif
     }
 #ifdef PDS_ROLLOUT_TIMING
     if (blockIdx.x == 0 && team == 0 && lane == 0) { ra.stats[8] = (float)tw / T; ra.stats[9] = (float)ts / T; ra.stats[10] = (float)tp / T;
-      ra.stats[11] = (float)tph / T; ra.stats[12] = (float)tout / T; ra.stats[13] = (float)trst / T; }
+      ra.stats[11] = (float)tph / T; ra.stats[12] = (float)tout / T; ra.stats[13] = (float)trst / T; ra.stats[14] = (float)tfin / T; ra.stats[15] = (float)tev / T; }
 #endif
     const RolloutArgs &rl = *reinterpret_cast<const RolloutArgs *>(&reload_args<202, true>(ra.s, T));
     if (active) {

@@ -485,6 +485,15 @@ constexpr int inline_envs_per_pass() {
   // CONVERTED variates (336 B per env): 3 envs per pass -- 4 x (8704 + 3 x 336 + 256) = 39 872 B per block
   return (V::ON && !V::LAT && V::TASK == PDS_TASK_HOVER) ? 3 : kResetsPerPass / 2;
 }
+// ... in the single-step kernel.  The K-step and rollout kernels (STORE == false) have the LDS for 8: a training rollout under a
+// young policy finishes ~5 % of its envs per step, 3.2 per tile, and every pass beyond the first repeats the whole evaluation.
+#ifndef PDS_INLINE_ENVS_KSTEP
+#define PDS_INLINE_ENVS_KSTEP 8
+#endif
+template <class V, bool STORE>
+constexpr int inline_envs() {  // (Circle's 46 KB of observation tiles per block leave no room for more at three blocks per CU)
+  return (STORE || V::TASK != PDS_TASK_HOVER) ? inline_envs_per_pass<V>() : PDS_INLINE_ENVS_KSTEP;
+}
 // U4 slots per env of the in-register resets' scratch (LdsVariates layout: floats, see fill_reset_variates)
 template <class V>
 constexpr int scratch_stride() { return (variates_floats<V>() + 3) / 4; }
@@ -853,6 +862,7 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
         if (fin_lds != nullptr) fin_lds[src_lane * D + lane] = v;
       }
     }
+    if constexpr (!STORE) { PDS_STAMP(6); }  // (K-step / rollout kernels: the single-step kernel uses slot 6 itself)
     if (RM != RM_DEFERRED && reset_mask != 0ull) {  // wave-uniform: the reset envs' rows become [o0, u0, o0', u0]
       if constexpr (RM == RM_INLINE) {
         // TakeOff ends episodes by truncation only, i.e. all 64 envs of a wave at once every 500 steps: there every
@@ -925,7 +935,7 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
           __builtin_amdgcn_wave_barrier();  // every final_obs row has left the tile
           if (need_reset) evaluate(DirectWords(env_id, rk));
         } else {
-          constexpr int IE = inline_envs_per_pass<V>();
+          constexpr int IE = inline_envs<V, STORE>();
           const int count = __popcll(reset_mask);
           const int pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(reset_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)reset_mask, 0u));
           if (need_reset) queue[pos] = (uint32_t)lane;
@@ -957,6 +967,7 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    if constexpr (!STORE) { PDS_STAMP(7); }
     const long long left = rem - pass * TR;
     if (left > 0)
       flush_tile<D, TR, saddr_variant<V>()>(tile, a.obs + (o1 + wave_base + pass * TR) * D, left >= TR ? TR : (int)left, lane);
@@ -1049,13 +1060,13 @@ PDS_DEV void prefetch_kernargs() {
 #ifndef PDS_XCD_REMAP
 #define PDS_XCD_REMAP 1
 #endif
-#define PDS_WAVE_LDS(V, TR, RM)                                                                        \
+#define PDS_WAVE_LDS(V, TR, RM, ST)                                                                      \
   __shared__ __attribute__((aligned(16))) float tile_all[(kBlock / kWave) * TR * tile_stride<V::D>()]; \
   constexpr int kParkFloats_ = (TR == kWave || !park_variant<V>()) ? 0 : (kWave - TR) * park_stride<V::O + 4>(); \
   __shared__ __attribute__((aligned(16))) float park_all[kParkFloats_ > 0 ? (kBlock / kWave) * kParkFloats_ : 4]; \
   const float2 *ref_lds = nullptr; /* (the Circle table of rounds 1-2: the reference point is evaluated now) */ \
   __shared__ uint32_t queue_all[(kBlock / kWave) * kQueueCap];                                        \
-  constexpr int kScratchU4_ = (RM == RM_MERGED) ? kMergedScratchU4 : ((RM == RM_INLINE && inline_coop_variant<V>()) ? inline_envs_per_pass<V>() * scratch_stride<V>() : 0); \
+  constexpr int kScratchU4_ = (RM == RM_MERGED) ? kMergedScratchU4 : ((RM == RM_INLINE && inline_coop_variant<V>()) ? inline_envs<V, ST>() * scratch_stride<V>() : 0); \
   __shared__ U4 scratch_all[kScratchU4_ > 0 ? (kBlock / kWave) * kScratchU4_ : 1];                     \
   const int tid = threadIdx.x;                                                                         \
   const int lane = tid & (kWave - 1);                                                                  \
@@ -1065,8 +1076,8 @@ PDS_DEV void prefetch_kernargs() {
   float *tile = tile_all + wave * (TR * tile_stride<V::D>());                                          \
   float *park = park_all + wave * kParkFloats_;
 
-#define PDS_WAVE_SETUP(V, TR, RM)                                                                      \
-  PDS_WAVE_LDS(V, TR, RM)                                                                              \
+#define PDS_WAVE_SETUP(V, TR, RM, ST)                                                                    \
+  PDS_WAVE_LDS(V, TR, RM, ST)                                                                            \
   const long long ntiles = (a.n + kWave - 1) / kWave;                                                  \
   long long blk_ = blockIdx.x;                                                                         \
   if (PDS_XCD_REMAP) { /* blocks b, b + 8, ... (one XCD) take consecutive tiles */                     \
@@ -1111,7 +1122,7 @@ __global__ __launch_bounds__(kBlock, (PDS_MIN_WAVES) * (256 / kBlock)) void step
   PDS_STAMP_DECL
   prefetch_kernargs();
   constexpr int RM = merged_reset_variant<V, TR>() ? RM_MERGED : (inline_reset_single_step<V, TR>() ? RM_INLINE : RM_DEFERRED);
-  PDS_WAVE_SETUP(V, TR, RM)
+  PDS_WAVE_SETUP(V, TR, RM, true)
   // The loads are issued before anything else so that the scalar preamble of the kernel
   // (kernel-argument loads, uniform constants) overlaps with their latency.
   Loaded cur;
@@ -1166,7 +1177,7 @@ __global__ __launch_bounds__(kBlock, (PDS_STEPK_MIN_WAVES_OF(V_)) * (256 / kBloc
   unsigned long long stamp_[kStampSlots];
 #endif
   prefetch_kernargs();
-  PDS_WAVE_SETUP(W, TR, RM)
+  PDS_WAVE_SETUP(W, TR, RM, false)
   Loaded cur;
   load_env<W>(a, ix, t, cur);
   RngKey rk{a.seed_lo, a.seed_hi, 0u, 0u};

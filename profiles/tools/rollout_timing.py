@@ -24,7 +24,7 @@ for kw in (dict(), dict(observation_noise=-1, domain_randomization=-1, motor_thr
         torch.cuda.synchronize(); t0 = time.time(); st = tr.roll_out(); torch.cuda.synchronize(); dt = time.time() - t0
     raw = keep[-1].cpu().tolist()
     print(kw, "rollout %.3f ms" % (dt * 1e3))
-    print(" E wave cycles per step: wait action %.0f  step %.0f  post %.0f | step = row half 1 + physics %.0f, reward + row half 2 + stores %.0f, final_obs + reset + flush %.0f" % tuple(raw[8:14]))
+    print(" E wave cycles per step: wait action %.0f  step %.0f  post %.0f | step = row half 1 + physics %.0f, reward + row half 2 + stores %.0f, final_obs + reset + flush %.0f (final_obs copies %.0f, reset %.0f)" % tuple(raw[8:16]))
     for w in range(4):
         o = raw[16 + 8 * w: 16 + 8 * w + 6]
         print(" M%d cycles per step: pre (noise draw) %.0f  wait obs %.0f  gather %.0f  actor+sample %.0f  post %.0f  critic etc %.0f" % (w, *o))

@@ -366,7 +366,10 @@ def test_fused_rollout_equals_per_step_rollout_bitwise(task, kw, n):
         assert torch.equal(a.obs, b.obs)
         done = (a.term_buf | a.trunc_buf).bool()
         assert int(done.sum()) >= n  # max_episode_steps = 9 < T
-        assert torch.equal(a.fval_buf[done], b.fval_buf[done])
+        # V(final_obs) where pds_gae reads it: episodes the TimeLimit cut (a terminated one bootstraps with 0, and the
+        # one-launch rollout does not evaluate its row)
+        cut = a.trunc_buf.bool() & ~a.term_buf.bool()
+        assert int(cut.sum()) > 0 and torch.equal(a.fval_buf[cut], b.fval_buf[cut])
         torch.testing.assert_close(sa, sb, rtol=1e-5, atol=1e-3)  # (sums over all envs: atomics, order differs)
         for f in ("pos", "vel", "rpy", "omega", "last_action", "step_count"):
             assert torch.equal(a.env.get_state(f), b.env.get_state(f)), f
