@@ -189,7 +189,7 @@ __global__ __launch_bounds__(kRolloutThreads * TEAMS, 1) void rollout_kernel(con
     float ep_ret = *at(ra.ep_ret, ix), ep_len = *at(ra.ep_len, ix), st0 = 0.f, st1 = 0.f, st2 = 0.f;
     int qcount = 0;
 #ifdef PDS_ROLLOUT_TIMING
-    unsigned long long tw = 0, ts = 0, tp = 0, tph = 0, tout = 0, trst = 0, tfin = 0, tev = 0;
+    unsigned long long tw = 0, ts = 0, tp = 0, tph = 0, tout = 0, trst = 0, tfin = 0, tev = 0, tfill = 0, teval = 0;
 #endif
     for (int s = 0; s < T; ++s) {
       const RolloutArgs &rl = *reinterpret_cast<const RolloutArgs *>(&reload_args<201, true>(ra.s, s));
@@ -209,6 +209,9 @@ __global__ __launch_bounds__(kRolloutThreads * TEAMS, 1) void rollout_kernel(con
         if (PDS_STEPK_OPAQUE_KEY) asm volatile("" : "+s"(rks.seed_lo), "+s"(rks.seed_hi), "+v"(lane_s));
         const float4 act = act_all[grp][lane_s];
         StepOut so;
+#ifdef PDS_STAMPS_RESET
+        stamp_[8] = 0; stamp_[9] = 0;
+#endif
         step_once<V, kWave, RM, false>(rl.s, o1, rks, parity, nullptr, tile, nullptr, queue_all[grp], scratch_all[grp], lane_s,
                                        wave_base, ix, active, act, S, qcount, fin, &so PDS_STAMP_ARG);
         parity ^= 1;
@@ -235,12 +238,15 @@ __global__ __launch_bounds__(kRolloutThreads * TEAMS, 1) void rollout_kernel(con
       tw += q1 - q0; ts += q2 - q1; tp += q3 - q2;
 #ifdef PDS_STAMPS
       if (!(PDS_ROLLOUT_SKIP & 2)) { tph += stamp_[3] - q1; tout += stamp_[4] - stamp_[3]; trst += stamp_[5] - stamp_[4]; tfin += stamp_[6] - stamp_[4]; tev += stamp_[7] - stamp_[6]; }
+#ifdef PDS_STAMPS_RESET
+      tfill += stamp_[8]; teval += stamp_[9];
+#endif
 #endif
 #endif
     }
 #ifdef PDS_ROLLOUT_TIMING
     if (blockIdx.x == 0 && team == 0 && lane == 0) { ra.stats[8] = (float)tw / T; ra.stats[9] = (float)ts / T; ra.stats[10] = (float)tp / T;
-      ra.stats[11] = (float)tph / T; ra.stats[12] = (float)tout / T; ra.stats[13] = (float)trst / T; ra.stats[14] = (float)tfin / T; ra.stats[15] = (float)tev / T; }
+      ra.stats[11] = (float)tph / T; ra.stats[12] = (float)tout / T; ra.stats[13] = (float)trst / T; ra.stats[14] = (float)tfin / T; ra.stats[15] = (float)tev / T; ra.stats[48] = (float)tfill / T; ra.stats[49] = (float)teval / T; }
 #endif
     const RolloutArgs &rl = *reinterpret_cast<const RolloutArgs *>(&reload_args<202, true>(ra.s, T));
     if (active) {

@@ -944,14 +944,26 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
           for (int base = 0; base < count; base += IE) {
             const int cnt = min(IE, count - base);  // wave-uniform
+#ifdef PDS_STAMPS_RESET
+            const unsigned long long z0 = __builtin_amdgcn_s_memtime();
+#endif
             fill_reset_variates<V>(a, rk, queue + base, cnt, lane, wave_base, reinterpret_cast<float *>(scratch));
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef PDS_STAMPS_RESET
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long z1 = __builtin_amdgcn_s_memtime();
+#endif
             if (need_reset && pos >= base && pos < base + cnt)
               evaluate(LdsVariates{reinterpret_cast<const float *>(scratch) + (pos - base) * variates_floats<V>()});
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();  // the scratch is refilled by the next pass
+#ifdef PDS_STAMPS_RESET
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long z2 = __builtin_amdgcn_s_memtime();
+            stamp_[8] += z1 - z0; stamp_[9] += z2 - z1;
+#endif
           }
         }
       } else {

@@ -25,6 +25,7 @@ for kw in (dict(), dict(observation_noise=-1, domain_randomization=-1, motor_thr
     raw = keep[-1].cpu().tolist()
     print(kw, "rollout %.3f ms" % (dt * 1e3))
     print(" E wave cycles per step: wait action %.0f  step %.0f  post %.0f | step = row half 1 + physics %.0f, reward + row half 2 + stores %.0f, final_obs + reset + flush %.0f (final_obs copies %.0f, reset %.0f)" % tuple(raw[8:16]))
+    if raw[48] or raw[49]: print("   reset = cooperative Philox + conversion %.0f, evaluation + rows %.0f (-DPDS_STAMPS_RESET)" % (raw[48], raw[49]))
     for w in range(4):
         o = raw[16 + 8 * w: 16 + 8 * w + 6]
         print(" M%d cycles per step: pre (noise draw) %.0f  wait obs %.0f  gather %.0f  actor+sample %.0f  post %.0f  critic etc %.0f" % (w, *o))
