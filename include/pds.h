@@ -221,7 +221,8 @@ int pds_step_with_variates(pds_handle *h, const float *d_actions, const float *d
 /* K lockstep env.step()s in ONE launch for open-loop action sequences (the replay of recorded actions
  * in simopt, simopt/pybullet.py:127-183: `for i in range(T-1): sim_env.step(acs[i])`): the env state
  * stays in registers between the K steps, only actions (in) and observations / rewards / flags (out)
- * stream through HBM.  Bitwise identical to K pds_step calls.
+ * stream through HBM.  Bitwise identical to K pds_step calls.  (Two launches on `stream` for the observation-noise
+ * configurations: the kept noisy observation, which pds_step regenerates instead of storing, is materialised first.)
  *   d_actions [K,N,4]   d_obs [K,N,D]   d_reward, d_cost [K,N]   d_terminated, d_truncated [K,N] u8
  *   d_final_obs [K,N,D] or NULL */
 int pds_step_k(pds_handle *h, int k_steps, const float *d_actions, float *d_obs, float *d_reward,
