@@ -128,77 +128,6 @@ __device__ __forceinline__ f32x4 forward16(const NetLds &w, const f32x4 (&xin)[N
   return c + b;
 }
 
-// The same pass with the network's A operands (4 consecutive floats of a weight row per (output tile, k-tile): the
-// ds_read_b128 of gemm_wt) held in REGISTERS: a wave that evaluates the same network step after step (the actor of the
-// fused rollout, on the critical path of every step) reads them from LDS once -- the GEMMs become pure MFMA chains
-// instead of read -> wait -> 2 MFMAs.  (NIN + 4) x 4 + 4 f32x4 = 128-144 registers.  Same operation order, same bits.
-template <int NIN>
-struct NetRegs {
-  f32x4 w1[kNT][NIN], w2[kNT][kNT], w3[kNT];  // (the biases stay in LDS: 36 more registers spill the rollout's network waves)
-};
-template <int NIN>
-__device__ __forceinline__ void load_net_regs(const NetLds &w, int n, int g, NetRegs<NIN> &r) {
-#pragma unroll
-  for (int it = 0; it < kNT; ++it) {
-#pragma unroll
-    for (int kt = 0; kt < NIN; ++kt) r.w1[it][kt] = lds4(w.W1 + (it * kTW + n) * kS + 4 * g + kt * kTW);
-#pragma unroll
-    for (int kt = 0; kt < kNT; ++kt) r.w2[it][kt] = lds4(w.W2 + (it * kTW + n) * kS + 4 * g + kt * kTW);
-    r.w3[it] = lds4(w.W3 + n * kS + 4 * g + it * kTW);
-  }
-}
-template <int ACT, int NIN, int KJI, int KJH>
-__device__ __forceinline__ f32x4 forward16_regs(const NetRegs<NIN> &r, const NetLds &w, const f32x4 (&xin)[NIN], int n, int g) {
-  f32x4 h1r[kNT], h2r[kNT], cc[kNT];
-#pragma unroll
-  for (int it = 0; it < kNT; it += 2) {  // (gemm_wt2: two accumulation chains alternate)
-    f32x4 c0 = (f32x4)(0.f), c1 = (f32x4)(0.f);
-#pragma unroll
-    for (int kt = 0; kt < NIN; ++kt)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (kt < NIN - 1 || j < KJI) {
-          c0 = PDS_MLPF_MFMA(r.w1[it][kt][j], xin[kt][j], c0);
-          c1 = PDS_MLPF_MFMA(r.w1[it + 1][kt][j], xin[kt][j], c1);
-        }
-    cc[it] = c0; cc[it + 1] = c1;
-  }
-#pragma unroll
-  for (int it = 0; it < kNT; ++it) {
-    const f32x4 b = lds4(w.b1 + it * kTW + 4 * g);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) h1r[it][q] = act_fn<ACT>(cc[it][q] + b[q]);
-  }
-#pragma unroll
-  for (int it = 0; it < kNT; it += 2) {
-    f32x4 c0 = (f32x4)(0.f), c1 = (f32x4)(0.f);
-#pragma unroll
-    for (int kt = 0; kt < kNT; ++kt)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (kt < kNT - 1 || j < KJH) {
-          c0 = PDS_MLPF_MFMA(r.w2[it][kt][j], h1r[kt][j], c0);
-          c1 = PDS_MLPF_MFMA(r.w2[it + 1][kt][j], h1r[kt][j], c1);
-        }
-    cc[it] = c0; cc[it + 1] = c1;
-  }
-#pragma unroll
-  for (int it = 0; it < kNT; ++it) {
-    const f32x4 b = lds4(w.b2 + it * kTW + 4 * g);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) h2r[it][q] = act_fn<ACT>(cc[it][q] + b[q]);
-  }
-  f32x4 c = (f32x4)(0.f);
-#pragma unroll
-  for (int kt = 0; kt < kNT; ++kt)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (kt < kNT - 1 || j < KJH) c = PDS_MLPF_MFMA(r.w3[kt][j], h2r[kt][j], c);
-  return c + lds4(w.b3 + 4 * g);
-}
-template <int ACT, int NIN>
-__device__ __forceinline__ f32x4 forward16_regs_shape(const NetRegs<NIN> &r, const NetLds &w, const pds_mlp &m, const f32x4 (&xin)[NIN], int n, int g);
-
 // run-time shape -> the instantiation with the fewest k-steps (data steps of the last k-tile of a dimension `dim`
 // that spans `tiles` 16-wide tiles; 4 when the tile is full or the dimension ends in an earlier tile)
 __device__ __forceinline__ int last_tile_steps(int dim, int tiles) {
@@ -211,14 +140,6 @@ __device__ __forceinline__ f32x4 forward16_shape(const NetLds &w, const pds_mlp 
   const bool kh2 = m.h1 == m.h2 && last_tile_steps(m.h1, kNT) == 2;
   if (kh2) return ki2 ? forward16<ACT, NIN, 2, 2>(w, xin, n, g) : forward16<ACT, NIN, 4, 2>(w, xin, n, g);
   return ki2 ? forward16<ACT, NIN, 2, 4>(w, xin, n, g) : forward16<ACT, NIN, 4, 4>(w, xin, n, g);
-}
-
-template <int ACT, int NIN>
-__device__ __forceinline__ f32x4 forward16_regs_shape(const NetRegs<NIN> &r, const NetLds &w, const pds_mlp &m, const f32x4 (&xin)[NIN], int n, int g) {
-  const bool ki2 = last_tile_steps(m.d_in, NIN) == 2;
-  const bool kh2 = m.h1 == m.h2 && last_tile_steps(m.h1, kNT) == 2;
-  if (kh2) return ki2 ? forward16_regs<ACT, NIN, 2, 2>(r, w, xin, n, g) : forward16_regs<ACT, NIN, 4, 2>(r, w, xin, n, g);
-  return ki2 ? forward16_regs<ACT, NIN, 2, 4>(r, w, xin, n, g) : forward16_regs<ACT, NIN, 4, 4>(r, w, xin, n, g);
 }
 
 }  // namespace pds_mlpf

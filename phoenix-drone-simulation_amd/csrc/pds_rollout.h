@@ -22,7 +22,7 @@
 // bootstrap V(final_obs) (algs/iwpg/iwpg.py:375-385), the action-noise draws of the NEXT step and all buffer writes of
 // the network waves run while the env wave steps.  Measured and kept out: the critic as one pds_mlp_forward over
 // obs_buf after the kernel (0.97 vs 0.91 ms at 8 192 x 64), the actor's weight operands resident in registers
-// (forward16_regs of csrc/pds_mlp_fwd.h: no change, 14.0 us per step either way -- the pass is a dependent chain of
+// (a forward16 that keeps its 29 b128 weight operands in 116 registers: no change, 14.0 us per step either way -- the pass is a dependent chain of
 // 110 MFMAs + epilogues, not LDS-bound).
 // Waves w and w + 4 of a block share a SIMD (profiles/r03_mlp_microbench.txt), and a wave that
 // streams MFMAs halves the vector-ALU rate of its SIMD-mate (a first version with two tiles per block, every env wave
