@@ -370,6 +370,11 @@ def test_fused_rollout_equals_per_step_rollout_bitwise(task, kw, n):
         # one-launch rollout does not evaluate its row)
         cut = a.trunc_buf.bool() & ~a.term_buf.bool()
         assert int(cut.sum()) > 0 and torch.equal(a.fval_buf[cut], b.fval_buf[cut])
+        # ... so what the update sees is the same, bit for bit: advantages, value targets, discounted returns
+        from phoenix_drone_simulation_amd.ppo import gae
+        ga, gb = (gae(t_.rew_buf, t_.val_buf, t_.term_buf, t_.trunc_buf, t_.fval_buf, t_.last_val, 0.99, 0.95, 0.37, 10.0) for t_ in tr)
+        for x, y in zip(ga, gb):
+            assert torch.equal(x, y)
         torch.testing.assert_close(sa, sb, rtol=1e-5, atol=1e-3)  # (sums over all envs: atomics, order differs)
         for f in ("pos", "vel", "rpy", "omega", "last_action", "step_count"):
             assert torch.equal(a.env.get_state(f), b.env.get_state(f)), f
