@@ -494,6 +494,12 @@ def main():
     scen.append(("circle_noise_agg2", "circle", dict(aggregate_phy_steps=2, domain_randomization=-1), 6, 10, act_random(0.2), 326, False, None, False))
     scen.append(("circle_defaults_agg3", "circle", dict(aggregate_phy_steps=3), 6, 8, act_random(0.2), 327, False, None, False))
 
+    # round 4: the Kalman-hold branch together with a PID control mode / the latency ring (refused until then)
+    scen.append(("hover_obsf50_rate", "hover", dict(observation_frequency=50, domain_randomization=-1, control_mode="AttitudeRate"), 8, 10, pid_act, 328, False, None, False))
+    scen.append(("circle_obsf50_att_agg2", "circle", dict(observation_frequency=50, control_mode="Attitude", aggregate_phy_steps=2), 6, 8, pid_act, 329, False, None, False))
+    lat_scen("hover_obsf50_lat2", "hover", dict(observation_frequency=50, latency=0.025, domain_randomization=-1), 8, 8, act_random(0.2), 330)
+    lat_scen("hover_obsf50_rate_lat2_defaults", "hover", dict(observation_frequency=50, latency=0.02, control_mode="AttitudeRate"), 6, 8, pid_act, 331)
+
     only = set(args.only.split(",")) if args.only else None
     index = {}
     if only is not None and os.path.exists(os.path.join(args.out, "INDEX.json")):
