@@ -479,7 +479,8 @@ class PPOTrainer:
         with torch.no_grad():
             loss_v_before = ((self.fm_v.forward(obs).view(-1) - target_v) ** 2).mean()
 
-        def value_update():
+        def value_steps():
+            """one mini-batch step of the value net per next()"""
             for _ in range(self.train_v_iterations):
                 # one elementwise launch (pds_permutation) where torch.randperm sorts (~160 us at 2^19 samples, 5 x per epoch)
                 self._perm_calls += 1
@@ -487,26 +488,37 @@ class PPOTrainer:
                 for s in range(0, mbs * self.num_mini_batches, mbs):
                     if world == 1:  # the Adam step rides on the gradient's partial-sum kernel (same bits, one launch less)
                         self.fm_v.value_grad(obs, target_v, index=perm[s:s + mbs], adam_lr=self.vf_opt.param_groups[0]["lr"])
-                        continue
-                    self.fm_v.value_grad(obs, target_v, index=perm[s:s + mbs])
-                    average(self.fm_v)
-                    self.fm_v.adam_step(self.vf_opt.param_groups[0]["lr"])
+                    else:
+                        self.fm_v.value_grad(obs, target_v, index=perm[s:s + mbs])
+                        average(self.fm_v)
+                        self.fm_v.adam_step(self.vf_opt.param_groups[0]["lr"])
+                    yield
 
         # The two updates share no state (two networks, two optimisers, read-only batch): single process, the value net's 80
         # mini-batch steps -- each 10 us of work behind ~27 us of fixed latency -- run on a second stream next to the policy
-        # net's 80 full-batch steps instead of in front of them.  Same launches, same bits.  (Several ranks: the two nets'
-        # all-reduces would have to be issued in one order on every rank: kept sequential.)
+        # net's 80 full-batch steps instead of in front of them, and the host feeds the two streams ALTERNATELY (one value
+        # step per policy step: enqueueing the whole value path first keeps the policy stream empty for its 2.4 ms of host
+        # time).  Same launches, same bits.  (Several ranks: the two nets' all-reduces would have to be issued in one order
+        # on every rank: kept sequential.)
         side = None
+        vgen = value_steps()
         if world == 1 and self.overlap_value_update and obs.is_cuda:
             main = torch.cuda.current_stream(obs.device)
             if self._side_stream is None:
                 self._side_stream = torch.cuda.Stream(device=obs.device)  # (a high-priority stream: no gain, profiles/r04_ppo_overlap.txt)
             side = self._side_stream
             side.wait_stream(main)
-            with torch.cuda.stream(side):
-                value_update()
         else:
-            value_update()
+            for _ in vgen:
+                pass
+
+        def feed_value_stream(steps):
+            if side is None:
+                return
+            with torch.cuda.stream(side):
+                for _ in range(steps):
+                    if next(vgen, StopIteration) is StopIteration:
+                        break
         act, adv, logp_old = data["act"].contiguous(), data["adv"].contiguous(), data["log_p"].contiguous()
         log_std = ac.pi.log_std
         # entropy of Normal(., sigma): sum(0.5 + 0.5 log 2 pi + log sigma), independent of the network
@@ -516,7 +528,10 @@ class PPOTrainer:
                 mu_old = self.fm_pi.forward(obs)
         first = None
         stop_iter = self.train_pi_iterations
+        v_total = self.train_v_iterations * self.num_mini_batches
         for i in range(self.train_pi_iterations):
+            # the value steps due by now: spread evenly over the policy iterations
+            feed_value_stream((i + 1) * v_total // self.train_pi_iterations - i * v_total // self.train_pi_iterations)
             ride = world == 1 and not self.use_max_grad_norm  # Adam inside the gradient call (same bits)
             stats = self.fm_pi.ppo_grad(obs, act, adv, logp_old, log_std, self.clip_ratio,
                                         adam_lr=self.pi_opt.param_groups[0]["lr"] if ride else None)
@@ -536,6 +551,7 @@ class PPOTrainer:
                     stop_iter = i + 1
                     break
         if side is not None:
+            feed_value_stream(v_total)  # (whatever an early stop of the policy loop has left)
             torch.cuda.current_stream(obs.device).wait_stream(side)
         if self.use_standardized_obs:
             ac.obs_oms.update(raw_obs)
