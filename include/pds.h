@@ -270,6 +270,12 @@ const char *pds_last_error(const pds_handle *h);
  * against the Random123 known-answer vectors.  Runs on the current device. */
 int pds_philox4x32(const uint32_t *d_ctr, const uint32_t *d_key, int rounds, int64_t n, uint32_t *d_out, void *stream);
 
+/* The standard normals of the per-step noise, exposed for verification: d_out[i][0..7] = the four
+ * one-word Box-Muller pairs of Philox4x32-7(counter (env_id_base + i, tick lo, tick hi, block), key = seed) for i < n --
+ * the device functions the step kernels draw the OU / gyro / sensor normals with (envs/sensors.py:75-134, envs/base.py:457-468).
+ * tests/ hold 2^26 of them against N(0, 1): Kolmogorov-Smirnov distance, moments, tail mass.  Runs on the current device. */
+int pds_noise_normals(uint64_t seed, uint64_t tick, uint32_t block, uint64_t env_id_base, int64_t n, float *d_out, void *stream);
+
 /* observation_history_size = H other than 2 (envs/base.py:44, 303-319, 417-431): advances the [N, H, half]
  * history of every env by the step's new row `d_obs2` [N, 2 * half] (the pds_step output) in one launch.
  * Running envs: hist' = [hist[1:], newest half].  Finished envs (auto_reset != 0): their final history

@@ -15,7 +15,13 @@ The linear schedules (exploration-noise anneal core.py:268-276, LambdaLR iwpg.py
 Stand-ins (absent modules, as for the other generators): pybullet / pybullet_data / pybullet_utils (pure
 math + a dict of base poses, see gen_golden.py), gymnasium, mpi4py (one rank), torch.utils.tensorboard.
 
-usage: gen_golden_learning.py [--seeds 5] [--epochs 30] [--workers 5] [--out tests/golden/learning_curve.json]
+The file is a STATISTICAL SAMPLE of the reference trainer's seed distribution, not a known answer: a re-run of
+the same seed reproduces epoch 1 exactly and differs from the first update on (torch's CPU reductions are not
+run-to-run deterministic here; the trajectories then diverge chaotically while keeping their shape).  It feeds
+two-sample tests only.  `--first-seed K --merge` appends seeds K.. to an existing file.
+
+usage: gen_golden_learning.py [--seeds 5] [--first-seed 0] [--merge] [--epochs 30] [--workers 5]
+                              [--out tests/golden/learning_curve.json]
 """
 import argparse
 import csv
@@ -67,21 +73,34 @@ def run_seed(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=5)
+    ap.add_argument("--first-seed", type=int, default=0)
+    ap.add_argument("--merge", action="store_true", help="append to the seeds already in --out")
     ap.add_argument("--epochs", type=int, default=30)
     ap.add_argument("--steps-per-epoch", type=int, default=32 * 1000)
     ap.add_argument("--workers", type=int, default=5)
     ap.add_argument("--env", default=ENV_ID)
     ap.add_argument("--out", default=os.path.join(HERE, "..", "..", "tests", "golden", "learning_curve.json"))
     a = ap.parse_args()
-    jobs = [(s, a.epochs, a.steps_per_epoch, a.env) for s in range(a.seeds)]
+    jobs = [(s, a.epochs, a.steps_per_epoch, a.env) for s in range(a.first_seed, a.first_seed + a.seeds)]
     with mp.get_context("spawn").Pool(min(a.workers, len(jobs))) as pool:
         res = pool.map(run_seed, jobs)
+    old = None
+    if a.merge and os.path.exists(a.out):
+        with open(a.out) as f:
+            old = json.load(f)
+        assert old["epochs"] == a.epochs and old["steps_per_epoch"] == a.steps_per_epoch and old["env_id"] == a.env
     out = dict(
-        what="per-epoch log of the reference's ProximalPolicyOptimizationAlgorithm.learn() on its own env, one entry per seed",
+        what="per-epoch log of the reference's ProximalPolicyOptimizationAlgorithm.learn() on its own env, one entry per "
+             "seed.  STATISTICAL SAMPLE, NOT BIT-REPRODUCIBLE: re-running a seed reproduces epoch 1 and diverges from the "
+             "first update on (same distribution, different trajectory); use it for two-sample tests only",
         generator="oracle/refgen/gen_golden_learning.py", env_id=a.env, epochs=a.epochs, steps_per_epoch=a.steps_per_epoch,
         obs_dim=res[0]["obs_dim"], hyper=res[0]["hyper"], columns=COLUMNS,
         seeds=[r["seed"] for r in res], wall_s=[round(r["wall_s"], 1) for r in res],
         curves={str(r["seed"]): {c: [row.get(c) for row in r["rows"]] for c in COLUMNS} for r in res})
+    if old is not None:
+        out["seeds"] = old["seeds"] + out["seeds"]
+        out["wall_s"] = old["wall_s"] + out["wall_s"]
+        out["curves"] = {**old["curves"], **out["curves"]}
     with open(a.out, "w") as f:
         json.dump(out, f, indent=0, sort_keys=True)
     print("wrote", a.out, os.path.getsize(a.out) // 1024, "kB")

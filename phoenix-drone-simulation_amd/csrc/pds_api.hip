@@ -207,6 +207,30 @@ __global__ __launch_bounds__(256) void latency_clear_kernel(DevState st, long lo
   st.ctr[i] = ctr_pack(ctr_step(c), ctr_sign(c), ctr_off(c), 0u) | (c & kCtrOhBit);
 }
 
+// In front of the K-step kernel of an observation-noise variant (regen_obs_variant): the kept noisy observation of every env
+// that does not have it in oh0-2 (i.e. every env after a pds_step, none after a pds_step_k) is regenerated there and flagged
+// in the counter word -- what the single-step kernels do in their prologue (init_kept_obs), as a pass of its own so that the
+// K-step kernel's loop is not compiled around it (csrc/pds_step.h, step_k_kernel).  Same function, same inputs, same bits.
+// 4 B per env when every env is flagged, 52 + 44 B otherwise.
+__global__ __launch_bounds__(kBlock) void materialize_oh_kernel(DevState st, Consts k, long long n, unsigned long long env_id_base,
+                                                                uint32_t seed_lo, uint32_t seed_hi) {
+  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t c = st.ctr[i];
+  if (ctr_oh(c) != 0u) return;
+  const WaveClock ck = st.clk[i / kWave];
+  const RngKey now{seed_lo, seed_hi, ck.x, ck.y};
+  const float4 q0 = st.s0[i], q1 = st.s1[i], q2 = st.s2[i];
+  const EnvRegs e{q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+  NoisyObs o;
+  regen_kept_obs(k, (uint32_t)(env_id_base + (unsigned long long)i), now, ctr_step(c) == 0u, e, o);
+  st.oh0[i] = make_float4(o.x, o.y, o.z, o.qx);
+  st.oh1[i] = make_float4(o.qy, o.qz, o.qw, o.vx);
+  st.oh2[i] = make_float2(o.vy, o.vz);
+  st.ctr[i] = c | kCtrOhBit;
+}
+
+
 }  // namespace pds
 
 // =================================================================================================
@@ -266,6 +290,20 @@ static thread_local char g_create_err[512] = "";
     hipError_t e_ = (call);                                                                     \
     if (e_ != hipSuccess) return fail(h, PDS_EHIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
   } while (0)
+
+// The kept noisy observation of every env into oh0-2 (flagged in the counter word) where the variant regenerates it from the
+// previous tick's Philox blocks and the env's state: in front of everything that moves a tile's clock, an env's state or its step
+// counter WITHOUT stepping the env -- a masked reset (the reset kernel advances the clock of every tile, also for the envs outside
+// the mask), pds_set_tick, the pds_set_state edits -- and in front of the K-step / rollout kernels, which read it from memory.
+// The history half of the next observation is then the observation that was returned, as in the reference (envs/base.py:303-319).
+static int materialize_kept_obs(pds_handle *h, hipStream_t s) {
+  if (!(PDS_REGEN_OBS && h->flags.on && !h->flags.hold)) return PDS_OK;
+  const long long n = h->cfg.num_envs;
+  hipLaunchKernelGGL(pds::materialize_oh_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, h->st, h->k, n,
+                     (unsigned long long)h->cfg.env_id_base, (uint32_t)h->cfg.seed, (uint32_t)(h->cfg.seed >> 32));
+  PDS_HIP(h, hipGetLastError());
+  return PDS_OK;
+}
 
 extern "C" int pds_version(void) { return PDS_VERSION; }
 
@@ -600,6 +638,7 @@ extern "C" int pds_set_tick(pds_handle *h, uint64_t tick) {
   DeviceGuard guard(h->cfg.device);
   PDS_HIP(h, guard.err);
   PDS_HIP(h, hipDeviceSynchronize());  // no stream argument: order behind everything in flight
+  if (const int rc = materialize_kept_obs(h, 0)) return rc;  // (regenerated from the OLD tick's blocks)
   const long long ntiles = (h->cfg.num_envs + kWave - 1) / kWave;
   hipLaunchKernelGGL(clock_fill_kernel, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, 0, h->st.clk, ntiles,
                      (unsigned long long)tick, 1);
@@ -714,6 +753,8 @@ static int do_reset(pds_handle *h, const uint8_t *d_mask, const float *d_samples
   base_args(h, a);
   a.mask = d_mask; a.samples = d_samples; a.obs = d_obs;
   const dim3 grid((unsigned)((a.n + kBlock - 1) / kBlock));
+  if (d_mask != nullptr)  // (the envs outside the mask keep their episode: see materialize_kept_obs)
+    if (const int rc = materialize_kept_obs(h, (hipStream_t)stream)) return rc;
   launch_family(h, kLaunchReset, h->flags, grid, (hipStream_t)stream, a);
   PDS_HIP(h, hipGetLastError());
   h->tick += 1;
@@ -779,31 +820,6 @@ extern "C" int pds_step(pds_handle *h, const float *d_actions, float *d_obs, flo
                                 d_final_obs, stream);
 }
 
-// In front of the K-step kernel of an observation-noise variant (regen_obs_variant): the kept noisy observation of every env
-// that does not have it in oh0-2 (i.e. every env after a pds_step, none after a pds_step_k) is regenerated there and flagged
-// in the counter word -- what the single-step kernels do in their prologue (init_kept_obs), as a pass of its own so that the
-// K-step kernel's loop is not compiled around it (csrc/pds_step.h, step_k_kernel).  Same function, same inputs, same bits.
-// 4 B per env when every env is flagged, 52 + 44 B otherwise.
-namespace pds {
-__global__ __launch_bounds__(kBlock) void materialize_oh_kernel(DevState st, Consts k, long long n, unsigned long long env_id_base,
-                                                                uint32_t seed_lo, uint32_t seed_hi) {
-  const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t c = st.ctr[i];
-  if (ctr_oh(c) != 0u) return;
-  const WaveClock ck = st.clk[i / kWave];
-  const RngKey now{seed_lo, seed_hi, ck.x, ck.y};
-  const float4 q0 = st.s0[i], q1 = st.s1[i], q2 = st.s2[i];
-  const EnvRegs e{q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
-  NoisyObs o;
-  regen_kept_obs(k, (uint32_t)(env_id_base + (unsigned long long)i), now, ctr_step(c) == 0u, e, o);
-  st.oh0[i] = make_float4(o.x, o.y, o.z, o.qx);
-  st.oh1[i] = make_float4(o.qy, o.qz, o.qw, o.vx);
-  st.oh2[i] = make_float2(o.vy, o.vz);
-  st.ctr[i] = c | kCtrOhBit;
-}
-}  // namespace pds
-
 extern "C" int pds_step_k(pds_handle *h, int k_steps, const float *d_actions, float *d_obs, float *d_reward,
                           uint8_t *d_terminated, uint8_t *d_truncated, float *d_cost, float *d_final_obs, void *stream) {
   if (!h) return PDS_EINVAL;
@@ -832,9 +848,7 @@ extern "C" int pds_step_k(pds_handle *h, int k_steps, const float *d_actions, fl
   const dim3 grid((unsigned)((a.n + kBlock - 1) / kBlock));
   LaunchFlags lf = h->flags;
   lf.half_tile = false;
-  if (PDS_REGEN_OBS && lf.on && !lf.hold)
-    hipLaunchKernelGGL(pds::materialize_oh_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, h->st, h->k, a.n, a.env_id_base,
-                       a.seed_lo, a.seed_hi);
+  if (const int rc = materialize_kept_obs(h, (hipStream_t)stream)) return rc;  // (the K-step kernel reads oh0-2: StoredOh)
   launch_family(h, kLaunchStepK, lf, grid, (hipStream_t)stream, a);
   PDS_HIP(h, hipGetLastError());
   h->tick += (uint64_t)k_steps;
@@ -899,16 +913,17 @@ extern "C" int pds_rollout(pds_handle *h, int T, const pds_mlp *pi, const pds_ml
   ra.ep_ret = d_ep_ret; ra.ep_len = d_ep_len; ra.stats = d_stats;
   const long long tiles = (n + kWave - 1) / kWave;
   const dim3 grid((unsigned)tiles);  // (the number of tiles: the launchers pick one or two tiles per block, csrc/pds_rollout.h)
+  // support is decided BEFORE the handle is touched (a refused call leaves it as it was)
+  if (!rollout_supported(h->cfg.task, h->flags))
+    return fail(h, PDS_EUNSUPPORTED, "pds_rollout: no kernel for this env configuration (ground effect; TakeOff with motor dynamics "
+                                     "and no latency ring)");
   // the env waves read the kept noisy observation from oh0-2 (StoredOh, like the K-step kernel)
-  if (PDS_REGEN_OBS && h->flags.on && !h->flags.hold)
-    hipLaunchKernelGGL(pds::materialize_oh_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
-                       h->st, h->k, n, ra.s.env_id_base, ra.s.seed_lo, ra.s.seed_hi);
+  if (const int rc = materialize_kept_obs(h, (hipStream_t)stream)) return rc;
   bool ok;
   if (h->cfg.task == PDS_TASK_HOVER) ok = launch_rollout_hover(h->flags, grid, (hipStream_t)stream, ra);
   else if (h->cfg.task == PDS_TASK_CIRCLE) ok = launch_rollout_circle(h->flags, grid, (hipStream_t)stream, ra);
   else ok = launch_rollout_takeoff(h->flags, grid, (hipStream_t)stream, ra);
-  if (!ok) return fail(h, PDS_EUNSUPPORTED, "pds_rollout: built without Kalman hold / ground effect, latency with control_mode PWM only, "
-                                            "with {no, all of} domain randomisation + thrust noise + observation noise");
+  if (!ok) return fail(h, PDS_EHIP, "pds_rollout: rollout_supported() and the launchers disagree");
   PDS_HIP(h, hipGetLastError());
   h->tick += (uint64_t)T;
   return PDS_OK;
@@ -937,6 +952,10 @@ static int do_field(pds_handle *h, int field, void *d_ptr, int set, void *stream
   a.st = h->st; a.k = h->k; a.user = d_ptr; a.n = h->cfg.num_envs; a.field = field; a.task = h->cfg.task; a.set = set;
   a.has_motor = h->flags.motor; a.has_dr = h->flags.dr; a.has_tn = h->flags.tn; a.has_on = h->flags.on; a.ctrl = h->flags.ctrl;
   a.regen_obs = PDS_REGEN_OBS && h->flags.on && !h->flags.hold;
+  // an edit of the state / step counter does not change what the env has OBSERVED: the kept observation is regenerated from the
+  // unedited state first and stays in oh0-2 (the reference's history keeps the row that was returned, envs/base.py:303-319)
+  if (set && field != PDS_F_NOISY_OBS)
+    if (const int rc = materialize_kept_obs(h, (hipStream_t)stream)) return rc;
   a.env_id_base = (unsigned long long)h->cfg.env_id_base;
   a.seed_lo = (uint32_t)h->cfg.seed; a.seed_hi = (uint32_t)(h->cfg.seed >> 32);
   const dim3 grid((unsigned)((a.n + kBlock - 1) / kBlock));
@@ -971,6 +990,31 @@ __global__ __launch_bounds__(256) void philox_kernel(const uint32_t *ctr, const 
   if (i >= n) return;
   const U4 r = philox4x32<ROUNDS>(ctr[4 * i], ctr[4 * i + 1], ctr[4 * i + 2], ctr[4 * i + 3], key[2 * i], key[2 * i + 1]);
   out[4 * i] = r.x; out[4 * i + 1] = r.y; out[4 * i + 2] = r.z; out[4 * i + 3] = r.w;
+}
+
+__global__ __launch_bounds__(256) void noise_normals_kernel(uint32_t seed_lo, uint32_t seed_hi, uint32_t tick_lo, uint32_t tick_hi,
+                                                            uint32_t block, unsigned long long id_base, long long n, float *out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const U4 r = philox4x32_7((uint32_t)(id_base + (unsigned long long)i), tick_lo, tick_hi, block, seed_lo, seed_hi);
+  float z[8];
+  box_muller_word(r.x, z[0], z[1]);
+  box_muller_word(r.y, z[2], z[3]);
+  box_muller_word(r.z, z[4], z[5]);
+  box_muller_word(r.w, z[6], z[7]);
+  float4 *o = reinterpret_cast<float4 *>(out + 8 * i);
+  o[0] = make_float4(z[0], z[1], z[2], z[3]);
+  o[1] = make_float4(z[4], z[5], z[6], z[7]);
+}
+
+extern "C" int pds_noise_normals(uint64_t seed, uint64_t tick, uint32_t block, uint64_t env_id_base, int64_t n, float *d_out,
+                                 void *stream) {
+  if (!d_out || n < 0 || (((uintptr_t)d_out) & 15u)) return PDS_EINVAL;
+  if (n == 0) return PDS_OK;
+  hipLaunchKernelGGL(noise_normals_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (uint32_t)seed,
+                     (uint32_t)(seed >> 32), (uint32_t)tick, (uint32_t)(tick >> 32), block, (unsigned long long)env_id_base,
+                     (long long)n, d_out);
+  return hipGetLastError() == hipSuccess ? PDS_OK : PDS_EHIP;
 }
 
 extern "C" int pds_philox4x32(const uint32_t *d_ctr, const uint32_t *d_key, int rounds, int64_t n, uint32_t *d_out, void *stream) {

@@ -396,41 +396,82 @@ __global__ __launch_bounds__(kRolloutThreads * TEAMS, 1) void rollout_kernel(con
 #endif
 }
 
-// The variants the fused rollout is built for: {lean, reference default (DR + thrust noise + observation noise)} x
-// {with, without motor dynamics} for control_mode PWM, for the PID control modes (what the reference's exp-07 trains:
-// experiments/07_control_structure_hypothesis/run_control_structures.py:53-61, envs/control.py:120-287) and for the
-// latency ring with control_mode PWM (envs/agents.py:267-276); no Kalman hold, no ground effect.
+// The variants the fused rollout is built for (rollout_supported in csrc/pds_types.h states the same rule for the host):
+//   control_mode PWM, no latency ring, no Kalman hold: every combination of domain randomisation / thrust noise /
+//     observation noise (the reference's ctor arguments are independent: envs/base.py:26-48) x {with, without motor dynamics};
+//   the PID control modes (what the reference's exp-07 trains: experiments/07_control_structure_hypothesis/
+//     run_control_structures.py:53-61, envs/control.py:120-287) and the latency ring (envs/agents.py:267-276), also together:
+//     {lean, reference default (DR + thrust noise + observation noise)} x {with, without motor dynamics};
+//   the Kalman hold (observation_frequency < sim_freq, envs/hover.py:134-156) with control_mode PWM: observation noise with
+//     {none, both} of DR + thrust noise x {with, without motor dynamics};
+//   never the ground effect.
+// `grid.x` = number of 64-env tiles; more tiles than CUs: two teams per block.
+template <class RV_>
+inline void launch_rollout_variant(dim3 grid, hipStream_t s, const RolloutArgs &ra) {
+  if (grid.x > (unsigned)kRolloutTwoTeamsAbove)
+    hipLaunchKernelGGL((rollout_kernel<RV_, 2>), dim3((grid.x + 1) / 2), dim3(2 * kRolloutThreads), 0, s, ra);
+  else
+    hipLaunchKernelGGL((rollout_kernel<RV_, 1>), grid, dim3(kRolloutThreads), 0, s, ra);
+}
+// motor dynamics x {lean, full}
 template <int TASK, int CTRL, bool LAT>
-inline bool launch_rollout_family(const LaunchFlags &f, dim3 grid, hipStream_t s, const RolloutArgs &ra) {
+inline bool launch_rollout_lean_or_full(const LaunchFlags &f, dim3 grid, hipStream_t s, const RolloutArgs &ra) {
   const bool lean = !f.dr && !f.tn && !f.on, full = f.dr && f.tn && f.on;
   if (!lean && !full) return false;
-  if (TASK == PDS_TASK_TAKEOFF && f.motor && !LAT) return false;
-  // `grid.x` = number of 64-env tiles; more tiles than CUs: two teams per block
-#define PDS_ROLLOUT_LAUNCH(M, X)                                                                                           \
-  do {                                                                                                                     \
-    using RV_ = Variant<TASK, M, X, false, X, X, CTRL, LAT, false>;                                                         \
-    if (grid.x > (unsigned)kRolloutTwoTeamsAbove)                                                                            \
-      hipLaunchKernelGGL((rollout_kernel<RV_, 2>), dim3((grid.x + 1) / 2), dim3(2 * kRolloutThreads), 0, s, ra);          \
-    else                                                                                                                   \
-      hipLaunchKernelGGL((rollout_kernel<RV_, 1>), grid, dim3(kRolloutThreads), 0, s, ra);                                 \
-  } while (0)
-  if constexpr (TASK == PDS_TASK_TAKEOFF && !LAT) {
-    if (full) PDS_ROLLOUT_LAUNCH(false, true); else PDS_ROLLOUT_LAUNCH(false, false);
+  if (f.motor) {
+    if (full) launch_rollout_variant<Variant<TASK, true, true, false, true, true, CTRL, LAT, false>>(grid, s, ra);
+    else launch_rollout_variant<Variant<TASK, true, false, false, false, false, CTRL, LAT, false>>(grid, s, ra);
   } else {
-    if (f.motor) { if (full) PDS_ROLLOUT_LAUNCH(true, true); else PDS_ROLLOUT_LAUNCH(true, false); }
-    else { if (full) PDS_ROLLOUT_LAUNCH(false, true); else PDS_ROLLOUT_LAUNCH(false, false); }
+    if (full) launch_rollout_variant<Variant<TASK, false, true, false, true, true, CTRL, LAT, false>>(grid, s, ra);
+    else launch_rollout_variant<Variant<TASK, false, false, false, false, false, CTRL, LAT, false>>(grid, s, ra);
   }
-#undef PDS_ROLLOUT_LAUNCH
+  return true;
+}
+// control_mode PWM without latency / hold: all eight noise settings
+template <int TASK, bool MOTOR>
+inline void launch_rollout_pwm(const LaunchFlags &f, dim3 grid, hipStream_t s, const RolloutArgs &ra) {
+#define PDS_ROLLOUT_CASE(DR, TN, ON) \
+  if (f.dr == DR && f.tn == TN && f.on == ON) return launch_rollout_variant<Variant<TASK, MOTOR, DR, false, TN, ON, 0, false, false>>(grid, s, ra)
+  PDS_ROLLOUT_CASE(false, false, false); PDS_ROLLOUT_CASE(true, true, true);
+  PDS_ROLLOUT_CASE(true, false, false); PDS_ROLLOUT_CASE(false, true, false); PDS_ROLLOUT_CASE(false, false, true);
+  PDS_ROLLOUT_CASE(true, true, false); PDS_ROLLOUT_CASE(true, false, true); PDS_ROLLOUT_CASE(false, true, true);
+#undef PDS_ROLLOUT_CASE
+}
+template <int TASK, bool MOTOR>
+inline bool launch_rollout_hold(const LaunchFlags &f, dim3 grid, hipStream_t s, const RolloutArgs &ra) {
+  if (!f.on || f.dr != f.tn) return false;
+  if (f.dr) launch_rollout_variant<Variant<TASK, MOTOR, true, false, true, true, 0, false, true>>(grid, s, ra);
+  else launch_rollout_variant<Variant<TASK, MOTOR, false, false, false, true, 0, false, true>>(grid, s, ra);
+  return true;
+}
+// The families are instantiated in translation units of their own (csrc/pds_rollout_<task>[_pwm|_lat].hip: the build compiles
+// them in parallel); launch_rollout_task is the dispatcher in csrc/pds_rollout_<task>.hip.
+template <int TASK>
+inline bool launch_rollout_pwm_family(const LaunchFlags &f, dim3 grid, hipStream_t s, const RolloutArgs &ra) {
+  constexpr bool kMotor = TASK != PDS_TASK_TAKEOFF;  // (TakeOff + motor dynamics: only with the latency ring)
+  if constexpr (kMotor) { if (f.motor) { launch_rollout_pwm<TASK, true>(f, grid, s, ra); return true; } }
+  launch_rollout_pwm<TASK, false>(f, grid, s, ra);
   return true;
 }
 template <int TASK>
-inline bool launch_rollout_task(const LaunchFlags &f, dim3 grid, hipStream_t s, const RolloutArgs &ra) {
-  if (f.hold || f.ge) return false;
-  if (f.lat) return f.ctrl == 0 ? launch_rollout_family<TASK, 0, true>(f, grid, s, ra) : false;
-  if (f.ctrl == 0) return launch_rollout_family<TASK, 0, false>(f, grid, s, ra);
+inline bool launch_rollout_lat_family(const LaunchFlags &f, dim3 grid, hipStream_t s, const RolloutArgs &ra) {
+  if (f.ctrl == 0) return launch_rollout_lean_or_full<TASK, 0, true>(f, grid, s, ra);
   if constexpr (TASK != PDS_TASK_TAKEOFF) {  // TakeOff fixes control_mode = 'PWM' (envs/takeoff.py:225)
-    if (f.ctrl == 1) return launch_rollout_family<TASK, 1, false>(f, grid, s, ra);
-    return launch_rollout_family<TASK, 2, false>(f, grid, s, ra);
+    if (f.ctrl == 1) return launch_rollout_lean_or_full<TASK, 1, true>(f, grid, s, ra);
+    return launch_rollout_lean_or_full<TASK, 2, true>(f, grid, s, ra);
+  }
+  return false;
+}
+template <int TASK>
+inline bool launch_rollout_pid_hold_family(const LaunchFlags &f, dim3 grid, hipStream_t s, const RolloutArgs &ra) {
+  constexpr bool kMotor = TASK != PDS_TASK_TAKEOFF;
+  if (f.hold) {
+    if constexpr (kMotor) { if (f.motor) return launch_rollout_hold<TASK, true>(f, grid, s, ra); }
+    return launch_rollout_hold<TASK, false>(f, grid, s, ra);
+  }
+  if constexpr (TASK != PDS_TASK_TAKEOFF) {
+    if (f.ctrl == 1) return launch_rollout_lean_or_full<TASK, 1, false>(f, grid, s, ra);
+    if (f.ctrl == 2) return launch_rollout_lean_or_full<TASK, 2, false>(f, grid, s, ra);
   }
   return false;
 }

@@ -1,7 +1,13 @@
-// pds_rollout_hover.hip -- instantiates the fused rollout kernel of pds_rollout.h for one task
-// ({lean, reference default} x {with, without motor dynamics}; control_mode PWM, no latency / hold / ground effect).
+// pds_rollout_hover.hip -- the fused rollout (pds_rollout.h) for one task: dispatcher + the PID control modes and the
+// Kalman hold; control_mode PWM with every noise setting: pds_rollout_hover_pwm.hip, the latency ring: pds_rollout_hover_lat.hip.
 #include "pds_rollout.h"
 
 namespace pds {
-bool launch_rollout_hover(const LaunchFlags &f, dim3 grid, hipStream_t s, const RolloutArgs &ra) { return launch_rollout_task<PDS_TASK_HOVER>(f, grid, s, ra); }
+bool launch_rollout_hover(const LaunchFlags &f, dim3 grid, hipStream_t s, const RolloutArgs &ra) {
+  if (!rollout_supported(PDS_TASK_HOVER, f)) return false;
+  if (f.hold) return launch_rollout_pid_hold_family<PDS_TASK_HOVER>(f, grid, s, ra);
+  if (f.lat) return launch_rollout_hover_lat(f, grid, s, ra);
+  if (f.ctrl == 0) return launch_rollout_hover_pwm(f, grid, s, ra);
+  return launch_rollout_pid_hold_family<PDS_TASK_HOVER>(f, grid, s, ra);
+}
 }  // namespace pds

@@ -369,9 +369,24 @@ struct RolloutArgs {
 
 static_assert(offsetof(RolloutArgs, s) == 0, "reload_args() reads the head of the kernarg segment as a StepArgs");
 
+// The env configurations the fused rollout has a kernel for (csrc/pds_rollout.h launch_rollout_task / _family decide by the same
+// rule; pds_rollout asks BEFORE it touches the handle).
+inline bool rollout_supported(int task, const LaunchFlags &f) {
+  if (f.ge) return false;
+  const bool lean = !f.dr && !f.tn && !f.on, full = f.dr && f.tn && f.on;
+  if (f.hold) return f.on && f.dr == f.tn && f.ctrl == 0 && !f.lat && !(task == PDS_TASK_TAKEOFF && f.motor);
+  if (f.lat) return (lean || full) && (f.ctrl == 0 || task != PDS_TASK_TAKEOFF);
+  if (f.ctrl != 0) return (lean || full) && task != PDS_TASK_TAKEOFF;
+  return !(task == PDS_TASK_TAKEOFF && f.motor);  // control_mode PWM: every noise setting
+}
 bool launch_rollout_hover(const LaunchFlags &f, dim3 grid, hipStream_t s, const RolloutArgs &ra);
 bool launch_rollout_circle(const LaunchFlags &f, dim3 grid, hipStream_t s, const RolloutArgs &ra);
 bool launch_rollout_takeoff(const LaunchFlags &f, dim3 grid, hipStream_t s, const RolloutArgs &ra);
+// (their families, one translation unit each: control_mode PWM with every noise setting / the latency ring / PID modes + Kalman hold)
+bool launch_rollout_hover_pwm(const LaunchFlags &f, dim3 grid, hipStream_t s, const RolloutArgs &ra);
+bool launch_rollout_hover_lat(const LaunchFlags &f, dim3 grid, hipStream_t s, const RolloutArgs &ra);
+bool launch_rollout_circle_pwm(const LaunchFlags &f, dim3 grid, hipStream_t s, const RolloutArgs &ra);
+bool launch_rollout_circle_lat(const LaunchFlags &f, dim3 grid, hipStream_t s, const RolloutArgs &ra);
 void launch_hover(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
 void launch_circle(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
 void launch_takeoff(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);

@@ -34,7 +34,7 @@ EXPORTS = ["pds_version", "pds_default_config", "pds_create", "pds_destroy", "pd
            "pds_field_width",
            "pds_get_state", "pds_set_state", "pds_tick", "pds_set_tick", "pds_sync_tick", "pds_count_nonfinite",
            "pds_bytes_per_env_step", "pds_bytes_per_env_step_k", "pds_last_error", "pds_step_k", "pds_set_latency",
-           "pds_latency_steps", "pds_philox4x32", "pds_gae", "pds_history_advance",
+           "pds_latency_steps", "pds_philox4x32", "pds_noise_normals", "pds_gae", "pds_history_advance",
            "pds_mlp_param_count", "pds_mlp_workspace_floats", "pds_mlp_forward", "pds_ppo_policy_grad",
            "pds_value_grad", "pds_ppo_policy_grad_step", "pds_value_grad_step", "pds_gaussian_sample", "pds_gaussian_sample_dev", "pds_counter_add", "pds_permutation", "pds_rollout_record",
            "pds_adam_step", "pds_rollout"]
@@ -115,6 +115,7 @@ def load():
     lib.pds_latency_steps.argtypes = [vp]
     lib.pds_bytes_per_env_step_k.argtypes = [vp, i32]
     lib.pds_philox4x32.argtypes = [vp, vp, i32, i64, vp, vp]
+    lib.pds_noise_normals.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, i64, vp, vp]
     lib.pds_count_nonfinite.argtypes = [vp, C.POINTER(C.c_int64), vp]
     lib.pds_bytes_per_env_step.argtypes = [vp]
     lib.pds_last_error.argtypes = [vp]

@@ -239,3 +239,54 @@ def test_constructor_draw_of_the_gyro_bias():
     quiet = pds.make("DroneHoverSimpleEnv-v0", num_envs=16, seed=5, observation_noise=-1)
     assert float(quiet.get_state("gyro_bias").abs().max()) == 0.0
     quiet.close()
+
+
+def test_step_noise_normals_against_the_normal_distribution():
+    """The per-step noise draws TWO normals from ONE 32-bit Philox word (20-bit radius, 12-bit angle: pds_device.h
+    box_muller_word) where the reference calls numpy's normal() (envs/sensors.py:75-134).  2^26 of them through the
+    device function itself (pds_noise_normals) against N(0, 1): Kolmogorov-Smirnov distance, the first four moments,
+    the tail mass beyond 3 / 4 / 5 sigma and the cut-off (|z| <= sqrt(2 ln 2^20) = 5.26: 1.4e-7 of mass missing),
+    the cos / sin partners of a word uncorrelated, and neighbouring envs / ticks / blocks uncorrelated."""
+    import ctypes as C
+    from phoenix_drone_simulation_amd import native
+    lib = native.load()
+    dev = torch.device("cuda", 0)
+    n = 1 << 23  # envs x 8 normals = 2^26
+    z = torch.empty(n, 8, device=dev)
+    rc = lib.pds_noise_normals(12345, 77, 64, 0, n, C.c_void_p(z.data_ptr()), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    flat = z.reshape(-1).double()
+    m = flat.numel()
+    assert bool(torch.isfinite(flat).all())
+    mean, var = float(flat.mean()), float(flat.var())
+    skew = float(((flat - mean) ** 3).mean() / var ** 1.5)
+    kurt = float(((flat - mean) ** 4).mean() / var ** 2)
+    se = 1.0 / np.sqrt(m)
+    assert abs(mean) < 5 * se and abs(var - 1) < 5 * np.sqrt(2) * se, (mean, var)
+    assert abs(skew) < 5 * np.sqrt(6) * se and abs(kurt - 3) < 5 * np.sqrt(24) * se, (skew, kurt)
+    # Kolmogorov-Smirnov: sup |F_n - Phi|; the 0.1 % critical value is 1.95 / sqrt(m)
+    s, _ = torch.sort(flat)
+    cdf = torch.special.ndtr(s)
+    i = torch.arange(1, m + 1, device=dev, dtype=torch.float64)
+    d = float(torch.maximum((i / m - cdf).abs().max(), (cdf - (i - 1) / m).abs().max()))
+    assert d < 1.95 * se, (d, 1.95 * se)
+    # tails: counts beyond t sigma are Poisson-like around m * 2 (1 - Phi(t))
+    from math import erfc, sqrt
+    a = flat.abs()
+    for t in (3.0, 4.0, 5.0):
+        want = m * erfc(t / sqrt(2.0))
+        got = int((a > t).sum())
+        assert abs(got - want) < 5 * sqrt(want) + 1, (t, got, want)
+    assert float(a.max()) <= np.sqrt(2 * np.log(2.0 ** 20)) + 1e-5 and float(a.max()) > 5.0
+    # the two normals of a word, and the words of a block, are uncorrelated (also in their squares)
+    zz = z.double()
+    for (p, q) in ((0, 1), (2, 3), (0, 2), (1, 6)):
+        assert abs(float((zz[:, p] * zz[:, q]).mean())) < 5 / np.sqrt(n)
+        assert abs(float(((zz[:, p] ** 2 - 1) * (zz[:, q] ** 2 - 1)).mean())) < 5 * 2 / np.sqrt(n)
+    # neighbouring envs, the next tick, the next block
+    z2 = torch.empty(n, 8, device=dev)
+    for args in ((12345, 78, 64, 0), (12345, 77, 65, 0), (12346, 77, 64, 0)):
+        assert lib.pds_noise_normals(*args, n, C.c_void_p(z2.data_ptr()), None) == 0
+        assert abs(float((z * z2).double().mean())) < 5 / np.sqrt(m)
+    assert abs(float((z[:-1] * z[1:]).double().mean())) < 5 / np.sqrt(m)

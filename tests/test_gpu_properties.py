@@ -178,6 +178,39 @@ def test_masked_reset_only_touches_selected_envs():
     env.close()
 
 
+@pytest.mark.parametrize("edit", ["masked_reset", "set_tick", "set_step_count", "set_pos"])
+def test_kept_noisy_observation_survives_calls_that_do_not_step_the_env(edit):
+    """Reference-default (noisy) Hover: the history half of the next row is the observation that was RETURNED by the previous
+    step (envs/base.py:303-319).  The single-step kernels regenerate it from the previous tick's Philox blocks and the env's
+    state, so every call that moves a tile's clock, the step counter or the state without stepping the env -- a masked
+    pds_reset (its kernel advances the clock of every tile), pds_set_tick, pds_set_state -- has to put it into memory first
+    (pds_api.hip materialize_kept_obs; ADVICE round 4, high + medium)."""
+    import phoenix_drone_simulation_amd as pds
+    n = 1000
+    env = pds.make(ENV_ID["hover"], num_envs=n, seed=4, auto_reset=False)
+    assert env.obs_dim == 34
+    env.reset()
+    for k in range(3):
+        prev, *_ = env.step(_actions(n, env.device, k))
+    prev = prev.clone()
+    keep = torch.ones(n, dtype=torch.bool, device=env.device)
+    if edit == "masked_reset":
+        mask = (torch.arange(n, device=env.device) % 3 == 0)
+        env.reset(mask=mask)
+        keep = ~mask
+    elif edit == "set_tick":
+        rc = env.lib.pds_set_tick(env._handle, int(env.tick) + 1000)
+        assert rc == 0
+    elif edit == "set_step_count":
+        env.set_state("step_count", torch.zeros(n, 1, dtype=torch.int32))  # "a reset happened in the previous tick" it did not
+    else:
+        env.set_state("pos", env.get_state("pos") + 0.25)
+    nxt, *_ = env.step(_actions(n, env.device, 9))
+    # o(k): position, quaternion, velocity, filtered gyro, u(k-1) == the second half of the previous row, bit for bit
+    assert torch.equal(nxt[keep, :17], prev[keep, 17:]), float((nxt[keep, :17] - prev[keep, 17:]).abs().max())
+    env.close()
+
+
 @pytest.mark.parametrize("task,kw", [
     ("hover", {}),
     ("hover", dict(control_mode="AttitudeRate", aggregate_phy_steps=2)),

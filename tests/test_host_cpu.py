@@ -220,3 +220,67 @@ def test_all_gather_obs_world2_gloo(total, tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert f"rank {r} ok" in o
+
+
+_WORKER8 = r"""
+import os, sys, time, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+import phoenix_drone_simulation_amd as pds
+from phoenix_drone_simulation_amd.ppo import avg_grads, OnlineMeanStd, ActorCritic
+from phoenix_drone_simulation_amd.sharding import max_over_ranks
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+total, D = {total}, 34
+a, b = pds.shard_range(total, rank, world)
+assert b - a in (total // world, total // world + 1)
+row = lambda lo, hi: torch.arange(lo, hi, dtype=torch.float32)[:, None] * 100 + torch.arange(D, dtype=torch.float32)[None]
+obs, want = row(a, b), row(0, total)
+for _ in range(2):  # (second call: shard sizes from the cache)
+    full = pds.all_gather_obs(obs)
+    assert full.shape == (total, D) and torch.equal(full, want), rank
+gat = pds.P2PObsGather(b - a, D, "cpu", tag="pds_p2p_w8")
+for step in range(5):
+    got = gat.gather(obs + step)
+    if rank in (3, 6):
+        time.sleep(0.02)  # slow consumers
+    assert torch.equal(got, want + step), (rank, step)
+gat.release()
+# gradient average: ONE flattened all-reduce == the reference's per-parameter mpi_avg_grads (utils/mpi_tools.py:30-36)
+torch.manual_seed(0)
+ac = ActorCritic(D, 4)
+for i, p in enumerate(ac.pi.net.parameters()):
+    p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+avg_grads(ac.pi.net)
+for i, p in enumerate(ac.pi.net.parameters()):
+    assert torch.allclose(p.grad, torch.full_like(p, (world + 1) / 2 * (i + 1))), (rank, i)
+# running statistics: 8 equal batches == one update on the concatenated batch (utils/online_mean_std.py:60-95), twice
+torch.manual_seed(1)
+data = [torch.randn(world * 16, D) * 3 + 1, torch.randn(world * 16, D) * 0.5 - 2]
+oms, ref = OnlineMeanStd(shape=(D,)), OnlineMeanStd(shape=(D,))
+for x in data:
+    oms.update(x[rank * 16:(rank + 1) * 16])
+assert max_over_ranks(float(rank), torch.device("cpu")) == float(world - 1)
+dist.barrier()
+dist.destroy_process_group()
+for x in data:
+    ref.update(x)
+assert torch.allclose(oms.mean, ref.mean, atol=1e-5) and torch.allclose(oms.std, ref.std, atol=1e-4), rank
+assert float(oms.count) == 2 * world * 16
+print("rank", rank, "ok")
+"""
+
+
+@pytest.mark.parametrize("total", [8 * 13 + 5, 8 * 16])
+def test_world8_gloo_ragged_and_equal_shards(total, tmp_path):
+    """Everything multi-rank at the node's real world size (8 ranks, one per MI355X): shard_range,
+    all_gather_obs (ragged: pad + strip; equal: all_gather_into_tensor), the peer-to-peer store gather with slow consumers,
+    the flattened gradient average, the all-reduced running statistics, max_over_ranks -- over gloo on CPU tensors."""
+    script = tmp_path / "worker8.py"
+    script.write_text(_WORKER8.format(root=ROOT, total=total))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + total % 97), WORLD_SIZE="8", OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(8)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"rank {r} ok" in o

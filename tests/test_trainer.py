@@ -342,6 +342,22 @@ def test_value_update_on_a_second_stream_equals_the_sequential_update_bitwise():
     ("DroneHoverSimpleEnv-v0", dict(), 64 * 313 - 7),
     ("DroneCircleSimpleEnv-v0", dict(control_mode="AttitudeRate", aggregate_phy_steps=2, use_motor_dynamics=True), 64 * 258),
     ("DroneTakeOffSimpleEnv-v0", dict(observation_noise=-1, domain_randomization=-1, motor_thrust_noise=0), 64 * 300),
+    # round 5: what else the reference trains -- the Kalman hold (observation_frequency < sim_freq, envs/hover.py:134-156),
+    # partial noise settings (the ctor arguments are independent, envs/base.py:26-48), the latency ring with a PID mode
+    ("DroneHoverSimpleEnv-v0", dict(observation_frequency=50), 200),
+    ("DroneCircleSimpleEnv-v0", dict(observation_frequency=50, aggregate_phy_steps=2, use_motor_dynamics=True,
+                                     domain_randomization=-1, motor_thrust_noise=0), 130),
+    ("DroneTakeOffSimpleEnv-v0", dict(observation_frequency=25), 100),
+    ("DroneHoverSimpleEnv-v0", dict(motor_thrust_noise=0), 200),                                   # sensor noise + DR only
+    ("DroneHoverSimpleEnv-v0", dict(observation_noise=-1), 200),                                   # DR + thrust noise only
+    ("DroneCircleSimpleEnv-v0", dict(domain_randomization=-1, use_motor_dynamics=True), 130),      # both noises, no DR
+    ("DroneCircleSimpleEnv-v0", dict(observation_noise=-1, motor_thrust_noise=0), 130),            # DR only
+    ("DroneTakeOffSimpleEnv-v0", dict(domain_randomization=-1, motor_thrust_noise=0), 100),        # sensor noise only
+    ("DroneHoverSimpleEnv-v0", dict(observation_noise=-1, domain_randomization=-1), 64 * 260),     # thrust noise only, two teams
+    ("DroneHoverSimpleEnv-v0", dict(use_latency=True, latency=0.02, control_mode="AttitudeRate", aggregate_phy_steps=2), 200),
+    ("DroneCircleSimpleEnv-v0", dict(use_latency=True, latency=0.03, control_mode="Attitude", aggregate_phy_steps=2,
+                                     use_motor_dynamics=True, observation_noise=-1, domain_randomization=-1,
+                                     motor_thrust_noise=0), 130),
 ])
 def test_fused_rollout_equals_per_step_rollout_bitwise(task, kw, n):
     """pds_rollout (ONE launch for the T closed-loop steps: both networks on the matrix cores, Gaussian sampling, env
@@ -391,15 +407,23 @@ def test_fused_rollout_equals_per_step_rollout_bitwise(task, kw, n):
 
 @pytest.mark.gpu
 def test_fused_rollout_refuses_what_it_is_not_built_for_and_the_trainer_falls_back():
+    """What is left without a rollout kernel: the opt-in ground-effect extension (TakeOff) and `observation_history_size`
+    other than 2 (the trainer does not ask).  A refused call leaves the handle as it was (support is decided first)."""
     import phoenix_drone_simulation_amd as pds
     from phoenix_drone_simulation_amd.ppo import PPOTrainer
-    env = pds.make("DroneHoverSimpleEnv-v0", num_envs=128, seed=3, observation_frequency=50)  # Kalman hold: no rollout kernel
+    env = pds.make("DroneTakeOffSimpleEnv-v0", num_envs=128, seed=3, use_ground_effect=True)
     tr = PPOTrainer(env, rollout_len=4, epochs=2, seed=5, fused=True)
+    before = {f: env.get_state(f).clone() for f in ("pos", "step_count", "noisy_obs")}
+    tick = env.tick
     tr.roll_out()
     assert tr.fused_rollout is False  # PDS_EUNSUPPORTED -> per-step kernels
+    env2 = pds.make("DroneTakeOffSimpleEnv-v0", num_envs=128, seed=3, use_ground_effect=True)
     with pytest.raises(NotImplementedError):
-        PPOTrainer(env, rollout_len=4, epochs=2, seed=5, fused=True, fused_rollout=True).roll_out()
-    env.close()
+        PPOTrainer(env2, rollout_len=4, epochs=2, seed=5, fused=True, fused_rollout=True).roll_out()
+    assert env2.tick == tick and env2.sync_tick() == tick
+    for f, v in before.items():
+        assert torch.equal(env2.get_state(f), v), f
+    env.close(); env2.close()
 
 
 @pytest.mark.gpu
