@@ -236,6 +236,11 @@ int pds_latency_steps(const pds_handle *h); /* current buf_size, 0 when use_late
 
 int pds_field_width(int field);
 int pds_get_state(pds_handle *h, int field, void *d_out, void *stream);
+/* Edits ONE field of every env.  What an env has observed is not edited with it: with observation noise the history half of
+ * the next observation row stays the (noisy) observation the previous step returned -- the kernels regenerate it from the
+ * state and the previous tick's draws, so pds_set_state (like a masked pds_reset and pds_set_tick) first writes it to memory,
+ * one extra launch on `stream`; pds_set_state(PDS_F_NOISY_OBS) replaces it.  Without observation noise o(k) is rebuilt from
+ * the state the step loads, i.e. it follows an edit of PDS_F_POS / PDS_F_RPY / PDS_F_VEL / PDS_F_OMEGA. */
 int pds_set_state(pds_handle *h, int field, const void *d_in, void *stream);
 
 /* Number of reset/step ticks issued so far (the Philox counter word). */

@@ -805,11 +805,12 @@ static void box_muller(uint32_t a, uint32_t b, REAL *z0, REAL *z1) {
   *z1 = r * R_SIN(ang);
 }
 
-/* per-step noise: one word per Box-Muller pair (radius: high 20 bits, angle: low 12 bits), one
+/* per-step noise: one word per Box-Muller pair (radius: high 20 bits, angle: low 12 bits at the MIDPOINTS
+ * (j + 1/2) / 4096 -- an angle grid that contains 0, 1/4, 1/2, 3/4 of a turn puts an atom of mass 1/2048 at z = 0), one
  * 16-bit half word per uniform -- csrc/pds_device.h box_muller_word / u01_lo16 / u01_hi16 */
 static void box_muller_word(uint32_t w, REAL *z0, REAL *z1) {
   REAL u1 = (REAL)((w >> 12) + 1u) * (REAL)(1.0 / 1048576.0);
-  REAL u2 = (REAL)(w & 0xFFFu) * (REAL)(1.0 / 4096.0);
+  REAL u2 = ((REAL)(w & 0xFFFu) + (REAL)0.5) * (REAL)(1.0 / 4096.0);
   REAL r = R_SQRT((REAL)-2 * R_LOG(u1));
   REAL ang = (REAL)(2 * PO_PI) * u2;
   *z0 = r * R_COS(ang);
@@ -908,19 +909,22 @@ static void philox_words(uint64_t seed, uint64_t env_id, uint64_t tick, uint32_t
 }
 
 /* one add_noise call that reaches the observation: 3 blocks -> z[24] (numpy order: pos3 vel3 bias3
- * rw3 to3 theta3 acc6), u[9] (pos3 vel3 theta3) */
+ * rw3 to3 theta3 acc6), u[9] (pos3 vel3 theta3).  Kernel layout (csrc/pds_reset.h words_to_noise8, round 5): words 0..4 ->
+ * normals n[0..9], words 5..7 -> six 16-bit uniforms, words 8..11 -> normals n[10..17]; n = pos3 vel3 theta3 bias3 rw3 to3. */
 static void obs_call_streams(uint64_t seed, uint64_t env_id, uint64_t tick, uint32_t blk0, double *z, double *u) {
   uint32_t w[12];
   philox_words(seed, env_id, tick, blk0, 3, w);
   REAL n[18];
-  for (int p = 0; p < 9; ++p) box_muller_word(w[p], &n[2 * p], &n[2 * p + 1]);
-  /* kernel order: pos_z vel_z bias rw to th_z  == numpy order of the first 18 normals */
-  for (int i = 0; i < 18; ++i) z[i] = (double)n[i];
+  for (int p = 0; p < 5; ++p) box_muller_word(w[p], &n[2 * p], &n[2 * p + 1]);
+  for (int p = 5; p < 9; ++p) box_muller_word(w[p + 3], &n[2 * p], &n[2 * p + 1]);
+  for (int i = 0; i < 6; ++i) z[i] = (double)n[i];           /* pos3 vel3 */
+  for (int i = 0; i < 9; ++i) z[6 + i] = (double)n[9 + i];   /* bias3 rw3 to3 */
+  for (int i = 0; i < 3; ++i) z[15 + i] = (double)n[6 + i];  /* theta3 */
   for (int i = 18; i < 24; ++i) z[i] = 0;
   for (int i = 0; i < 3; ++i) u[3 + i] = 0.5;
-  u[0] = (double)u01_lo16(w[9]);  u[1] = (double)u01_hi16(w[9]);
-  u[2] = (double)u01_lo16(w[10]); u[6] = (double)u01_hi16(w[10]);
-  u[7] = (double)u01_lo16(w[11]); u[8] = (double)u01_hi16(w[11]);
+  u[0] = (double)u01_lo16(w[5]); u[1] = (double)u01_hi16(w[5]);
+  u[2] = (double)u01_lo16(w[6]); u[6] = (double)u01_hi16(w[6]);
+  u[7] = (double)u01_lo16(w[7]); u[8] = (double)u01_hi16(w[7]);
 }
 
 /* streams of one env.step() (aggregate_phy_steps sub-steps): per sub-step OU z4 + discarded call, then

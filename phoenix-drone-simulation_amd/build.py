@@ -4,7 +4,9 @@ The translation units (the host API, one per (task, variant family) -- each inst
 K-step / reset kernel variants -- and the trainer kernels) are compiled in parallel and linked into
 one shared library."""
 import concurrent.futures
+import hashlib
 import os
+import re
 import shutil
 import subprocess
 
@@ -39,32 +41,78 @@ def _stale(target, deps):
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
+_INC = re.compile(r'^\s*#\s*include\s+"([^"]+)"', re.M)
+
+
+def _closure(path, seen=None):
+    """`path` and every file it includes with #include "..." (recursively), in a stable order."""
+    seen = seen if seen is not None else []
+    path = os.path.normpath(path)
+    if path in seen or not os.path.exists(path):
+        return seen
+    seen.append(path)
+    with open(path) as f:
+        text = f.read()
+    for inc in _INC.findall(text):
+        _closure(os.path.join(os.path.dirname(path), inc), seen)
+    return seen
+
+
+def _signature(unit, flags):
+    """sha256 over the flags and the CONTENTS of a translation unit and of the headers it pulls in: an object is rebuilt when
+    what it was compiled from changed, not when a file was touched or a header it never sees was edited."""
+    h = hashlib.sha256(" ".join(flags).encode())
+    for path in _closure(os.path.join(_CSRC, unit)):
+        h.update(path.encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def build_library(force=False, verbose=False, extra_flags=(), out=None):
     """hipcc --offload-arch=gfx950 -c csrc/*.hip (in parallel) -> link libpds_hip.so"""
     out = out or _LIB
-    if not force and not extra_flags and not _stale(out, _DEPS):
-        return out
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not os.path.exists(hipcc):
-        raise RuntimeError("hipcc not found: cannot build libpds_hip.so (there is no CPU fallback)")
     os.makedirs(_OBJ, exist_ok=True)
     tag = "".join(c if c.isalnum() else "_" for c in "".join(extra_flags))
+    flags = _FLAGS + list(extra_flags)
     objs = [os.path.join(_OBJ, os.path.splitext(u)[0] + tag + ".o") for u in _UNITS]
+    sigs = {u: _signature(u, flags) for u in _UNITS}
+
+    def current(unit, obj):
+        sig = obj + ".sig"
+        return os.path.exists(obj) and os.path.exists(sig) and open(sig).read().strip() == sigs[unit]
+
+    # the library carries the signature of everything it was built from (libpds_hip.so.sig travels with it to the GPU box,
+    # the objects under build/ do not): up to date == same sources, whatever the time stamps say
+    link_sig = hashlib.sha256("".join(sigs[u] for u in _UNITS).encode()).hexdigest()
+    lsig = out + ".sig"
+    if not force and os.path.exists(out):
+        if os.path.exists(lsig):
+            if open(lsig).read().strip() == link_sig:
+                return out
+        elif not _stale(out, _DEPS):
+            return out  # (a library without its signature file: trust the time stamps)
+    todo = [(u, o) for u, o in zip(_UNITS, objs) if force or not current(u, o)]
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build libpds_hip.so (there is no CPU fallback)")
 
     def compile_unit(pair):
         unit, obj = pair
-        if not force and not _stale(obj, _DEPS):
-            return
-        cmd = [hipcc] + _FLAGS + list(extra_flags) + ["-c", os.path.join(_CSRC, unit), "-o", obj]
+        cmd = [hipcc] + flags + ["-c", os.path.join(_CSRC, unit), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        with open(obj + ".sig", "w") as f:
+            f.write(sigs[unit])
 
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
-        list(ex.map(compile_unit, zip(_UNITS, objs)))
+        list(ex.map(compile_unit, todo))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out + ".tmp"] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     os.replace(out + ".tmp", out)
+    with open(lsig, "w") as f:
+        f.write(link_sig)
     return out

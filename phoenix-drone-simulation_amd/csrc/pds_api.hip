@@ -238,6 +238,10 @@ __global__ __launch_bounds__(kBlock) void materialize_oh_kernel(DevState st, Con
 // =================================================================================================
 using namespace pds;
 
+#ifndef PDS_STORED_OH_FROM_AGG
+#define PDS_STORED_OH_FROM_AGG 2  // A/B: 0 = every single-step launch regenerates the kept observation (round 4)
+#endif
+
 struct pds_handle {
   pds_config cfg;
   DevState st;
@@ -253,6 +257,8 @@ struct pds_handle {
   int num_cus;    // hipDeviceProp.multiProcessorCount (256 on MI355X): drives the half-tile rule
   uint64_t tick;  // host mirror of the device clock words (pds_sync_tick refreshes it)
   bool was_reset;
+  int stored_from_agg = PDS_STORED_OH_FROM_AGG;  // aggregate_phy_steps from which pds_step keeps the noisy observation in memory
+  bool stored_ready = false;  // kLaunchStepStored handles: the one materialize_oh_kernel pass in front of their first step is done
   char err[512];
 };
 
@@ -525,6 +531,7 @@ extern "C" int pds_create(const pds_config *cfg, pds_handle **out) {
   h->flags.hold = h->k.obs_rate != 1;
   h->flags.half_tile = false;
   if (const char *ft = getenv("PDS_FORCE_TILE")) h->force_tile = (ft[0] == 'h') ? 1 : ((ft[0] == 'f') ? 2 : 0);
+  if (const char *sa = getenv("PDS_STORED_OH_FROM_AGG")) h->stored_from_agg = atoi(sa);  // (A/B runs: 0 = always regenerate)
   const size_t n = (size_t)cfg->num_envs;
   const size_t ntiles = (n + kWave - 1) / kWave;
   const LaunchFlags &f = h->flags;
@@ -682,7 +689,8 @@ extern "C" int pds_set_latency(pds_handle *h, double latency) {
 // read action 16 + dyn state 48 + action history 32 + counter 4; write dyn state 48
 // + newest history slot 16 + counter 4 + reward 4 + cost 4 + terminated 1 + truncated 1; obs 4*D;
 // DR params +24; motor PT1: x R+W 32 (+ A, K 32 when randomised); OU state R+W 32; gyro bias +
-// low-pass R+W 48; kept noisy observation (10 floats) R+W 80 only with the Kalman hold (obs_rate > 1) -- otherwise it is
+// low-pass R+W 48; kept noisy observation (10 floats) R+W 80 with the Kalman hold (obs_rate > 1) and with two or more physics
+// sub-steps per env.step (kLaunchStepStored: the step is bound by the vector ALU there) -- otherwise it is
 // regenerated from the previous tick's Philox blocks, not kept (csrc/pds_reset.h regen_kept_obs; pds_step_with_variates
 // and the first step after an explicit reset still move those 80 B); latency ring: one row R+W per physics
 // sub-step.  (The per-tile clock word adds 0.5 B per env-step and is not counted.)
@@ -694,7 +702,7 @@ extern "C" int pds_bytes_per_env_step(const pds_handle *h) {
   if (f.motor) b += 32;
   if (f.motor && f.dr) b += 32;
   if (f.tn) b += 32;
-  if (f.on) b += 48 + ((f.hold || !PDS_REGEN_OBS) ? 80 : 0);
+  if (f.on) b += 48 + ((f.hold || !PDS_REGEN_OBS || (h->stored_from_agg > 0 && h->cfg.aggregate_phy_steps >= h->stored_from_agg)) ? 80 : 0);
   if (f.ctrl >= 1) b += 48;  // rate-PID integral + last error, R+W
   if (f.ctrl == 2) b += 48;  // attitude-PID integral + last error, R+W
   if (f.lat) b += 32 * h->cfg.aggregate_phy_steps;
@@ -807,7 +815,18 @@ extern "C" int pds_step_with_variates(pds_handle *h, const float *d_actions, con
   lf.half_tile = grid.x > (unsigned)kFullTileBlocksPerCU * cus * (256 / kBlock) && grid.x <= (merged ? 5u : 8u) * cus * (256 / kBlock);
   if (h->force_tile) lf.half_tile = h->force_tile == 1;
   if (lf.on || lf.lat) lf.half_tile = false;  // (no half-tile instantiation)
-  launch_family(h, kLaunchStep, lf, grid, (hipStream_t)stream, a);
+  // observation noise with two or more physics sub-steps: the StoredOh form of the same kernel (kLaunchStepStored); such a
+  // handle never runs the regenerating form, so every env's kept observation is in memory from the first call on
+  int kind = kLaunchStep;
+  if (PDS_REGEN_OBS && h->stored_from_agg > 0 && lf.on && !lf.hold && h->cfg.aggregate_phy_steps >= h->stored_from_agg &&
+      d_variates == nullptr) {
+    kind = kLaunchStepStored;
+    if (!h->stored_ready) {
+      if (const int rc = materialize_kept_obs(h, (hipStream_t)stream)) return rc;
+      h->stored_ready = true;
+    }
+  }
+  launch_family(h, kind, lf, grid, (hipStream_t)stream, a);
   PDS_HIP(h, hipGetLastError());
   h->tick += 1;
   return PDS_OK;

@@ -36,15 +36,17 @@ PDS_DEV void words_to_normals4(const U4 &w, float (&z)[4]) {   // two full-preci
   box_muller(w.x, w.y, z[0], z[1]);
   box_muller(w.z, w.w, z[2], z[3]);
 }
-// block b (0..2) of one add_noise call: words 0..8 of the call -> 18 normals (one Box-Muller pair per word), words
-// 9..11 -> 6 uniforms (16 bits each); f[2 i], f[2 i + 1] = the pair of word i of the block
+// block b (0..2) of one add_noise call (round 5 layout): words 0..4 of the call -> the normals n[0..9] (one Box-Muller pair
+// per word), words 5..7 -> 6 uniforms (16 bits each), words 8..11 -> the normals n[10..17]; f[2 i], f[2 i + 1] = the pair of
+// word i of the block.  What the kept observation is regenerated from -- position, velocity and angle noise: n[0..8] and
+// the uniforms -- sits in blocks 0 and 1, so regen_kept_obs computes two Philox blocks, not three (obs_noise_from_blocks).
 PDS_DEV void words_to_noise8(const U4 &w, int b, float (&f)[8]) {
   const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     float z0, z1;
     box_muller_word(ww[i], z0, z1);
-    const bool uni = b == 2 && i > 0;
+    const bool uni = b == 1 && i > 0;
     f[2 * i] = uni ? u01_lo16(ww[i]) : z0;
     f[2 * i + 1] = uni ? u01_hi16(ww[i]) : z1;
   }
@@ -233,30 +235,38 @@ PDS_DEV void sample_load(const float *row, Sample &s) {
 }
 
 // ---- sensor noise -------------------------------------------------------------------------------
-// 24 standard variates of one add_noise call from three Philox blocks: words 0..8 -> 18 normals
-// (one Box-Muller pair per word), words 9..11 -> 6 uniforms (16 bits each).
-// (f0, f1, f2: the three blocks of the call as words_to_noise8 converts them)
+// 24 standard variates of one add_noise call from three Philox blocks (layout: words_to_noise8): normals n[0..17] =
+// position 3, velocity 3, angle 3, gyro bias walk 3, gyro random walk 3, gyro turn-on 3; uniforms = position 3, angle 3.
+// (f0, f1, f2: the three blocks of the call as words_to_noise8 converts them; NBLK == 2: the gyro normals are not wanted)
+template <int NBLK = kObsCallBlocks>
 PDS_DEV void obs_noise_from_blocks(const float (&f0)[8], const float (&f1)[8], const float (&f2)[8], ObsNoise &n) {
   float z[18];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { z[i] = f0[i]; z[8 + i] = f1[i]; }
-  z[16] = f2[0]; z[17] = f2[1];
+  for (int i = 0; i < 8; ++i) { z[i] = f0[i]; z[10 + i] = NBLK > 2 ? f2[i] : 0.f; }
+  z[8] = f1[0]; z[9] = f1[1];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    n.pos_z[i] = z[i]; n.vel_z[i] = z[3 + i]; n.bias_z[i] = z[6 + i];
-    n.rw_z[i] = z[9 + i]; n.to_z[i] = z[12 + i]; n.th_z[i] = z[15 + i];
+    n.pos_z[i] = z[i]; n.vel_z[i] = z[3 + i]; n.th_z[i] = z[6 + i];
+    n.bias_z[i] = z[9 + i]; n.rw_z[i] = z[12 + i]; n.to_z[i] = z[15 + i];
   }
-  n.pos_u[0] = f2[2]; n.pos_u[1] = f2[3];
-  n.pos_u[2] = f2[4]; n.th_u[0] = f2[5];
-  n.th_u[1] = f2[6]; n.th_u[2] = f2[7];
+  n.pos_u[0] = f1[2]; n.pos_u[1] = f1[3];
+  n.pos_u[2] = f1[4]; n.th_u[0] = f1[5];
+  n.th_u[1] = f1[6]; n.th_u[2] = f1[7];
 }
 
+template <int NBLK = kObsCallBlocks>
 PDS_DEV void obs_noise_philox(uint32_t env_id, const RngKey &a, uint32_t blk0, ObsNoise &n) {
   float f[kObsCallBlocks][8];
 #pragma unroll
-  for (int b = 0; b < kObsCallBlocks; ++b)
-    words_to_noise8(philox4x32_7(env_id, a.tick_lo, a.tick_hi, blk0 + (uint32_t)b, a.seed_lo, a.seed_hi), b, f[b]);
-  obs_noise_from_blocks(f[0], f[1], f[2], n);
+  for (int b = 0; b < kObsCallBlocks; ++b) {
+    if (b < NBLK) {
+      words_to_noise8(philox4x32_7(env_id, a.tick_lo, a.tick_hi, blk0 + (uint32_t)b, a.seed_lo, a.seed_hi), b, f[b]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[b][i] = 0.f;
+    }
+  }
+  obs_noise_from_blocks<NBLK>(f[0], f[1], f[2], n);
 }
 
 template <class SRC>
@@ -323,7 +333,7 @@ PDS_DEV void regen_kept_obs(const Consts &k, uint32_t env_id, const RngKey &now,
   prev.tick_lo = now.tick_lo - 1u;
   if (now.tick_lo == 0u) prev.tick_hi = now.tick_hi - 1u;
   ObsNoise n;
-  obs_noise_philox(env_id, prev, after_reset ? kBlkResetNoise + (uint32_t)kObsCallBlocks : kBlkObsNoise, n);
+  obs_noise_philox<2>(env_id, prev, after_reset ? kBlkResetNoise + (uint32_t)kObsCallBlocks : kBlkObsNoise, n);  // (no gyro normals)
   NoiseState unused;
 #pragma unroll
   for (int j = 0; j < 3; ++j) { unused.bias[j] = 0.f; unused.lpf[j] = 0.f; }

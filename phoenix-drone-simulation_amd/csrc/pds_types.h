@@ -48,9 +48,11 @@ PDS_DEV uint32_t ctr_off(uint32_t c) { return (c >> 17) & 0x1FFu; }
 PDS_DEV uint32_t ctr_lat(uint32_t c) { return (c >> 26) & 0x7u; }
 // bit 29 (observation-noise variants without the Kalman hold): "the kept noisy observation o(k) of this env is in
 // oh0-2".  Clear = it is REGENERATED from the stored true state and the previous tick's Philox blocks (round 4: the
-// Philox-driven step neither reads nor writes oh0-2, -80 B per env-step); set by whatever produced o(k) from draws that
-// Philox cannot replay or on a state that may since have been edited: pds_reset / pds_reset_from_samples,
-// pds_step_with_variates, pds_set_state(NOISY_OBS), the deferred-drain resets.
+// Philox-driven single-step kernel neither reads nor writes oh0-2, -80 B per env-step).  Set by whatever produced o(k) from
+// draws that Philox cannot replay -- pds_reset / pds_reset_from_samples, pds_step_with_variates, pds_set_state(NOISY_OBS), the
+// deferred-drain resets --, by the kernels that keep it in memory (StoredOh: pds_step_k, pds_rollout, pds_step with two or more
+// physics sub-steps) and by materialize_oh_kernel, which csrc/pds_api.hip runs in front of everything that would otherwise
+// invalidate the regeneration's inputs: a masked reset (the clock of every tile advances), pds_set_tick, any pds_set_state.
 #ifndef PDS_REGEN_OBS
 #define PDS_REGEN_OBS 1  // A/B: 0 = the kept observation always lives in oh0-2 (rounds 1-3)
 #endif
@@ -348,7 +350,10 @@ struct LaunchFlags {
   bool hold;
   bool half_tile;  // per launch: use the 32-row observation tile (variants without observation noise)
 };
-enum LaunchKind { kLaunchStep = 0, kLaunchStepK = 1, kLaunchReset = 2 };
+// kLaunchStepStored: the single-step kernel of an observation-noise variant in its StoredOh form (the kept noisy observation read
+// from and written to oh0-2 instead of regenerated): pds_step with aggregate_phy_steps >= 2, where the step is bound by the
+// vector ALU and the regeneration costs more than the 80 B per env-step it saves (csrc/pds_step.h launch_variant).
+enum LaunchKind { kLaunchStep = 0, kLaunchStepK = 1, kLaunchReset = 2, kLaunchStepStored = 3 };
 // one translation unit per (task, family) keeps the build parallel: pds_task_*.hip
 // Arguments of the fused rollout (csrc/pds_rollout.h).
 struct RolloutArgs {

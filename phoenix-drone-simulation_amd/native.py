@@ -115,7 +115,6 @@ def load():
     lib.pds_latency_steps.argtypes = [vp]
     lib.pds_bytes_per_env_step_k.argtypes = [vp, i32]
     lib.pds_philox4x32.argtypes = [vp, vp, i32, i64, vp, vp]
-    lib.pds_noise_normals.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, i64, vp, vp]
     lib.pds_count_nonfinite.argtypes = [vp, C.POINTER(C.c_int64), vp]
     lib.pds_bytes_per_env_step.argtypes = [vp]
     lib.pds_last_error.argtypes = [vp]
@@ -146,6 +145,7 @@ def load():
     later("pds_value_grad_step", [mp, vp, vp, vp, i64, vp, vp, vp, ap, vp])
     later("pds_gaussian_sample_dev", [vp, vp, i64, i32, u64, vp, u64, u64, i32, vp, vp, vp])
     later("pds_counter_add", [vp, u64, vp])
+    later("pds_noise_normals", [u64, u64, C.c_uint32, u64, i64, vp, vp])
     later("pds_permutation", [vp, i64, u64, u64, vp])
     later("pds_rollout", [vp, i32, mp, mp, vp, vp, C.c_float, vp, u64, vp, u64, i32] + [vp] * 14)
     _lib = lib

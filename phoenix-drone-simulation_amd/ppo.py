@@ -529,30 +529,35 @@ class PPOTrainer:
         first = None
         stop_iter = self.train_pi_iterations
         v_total = self.train_v_iterations * self.num_mini_batches
-        for i in range(self.train_pi_iterations):
-            # the value steps due by now: spread evenly over the policy iterations
-            feed_value_stream((i + 1) * v_total // self.train_pi_iterations - i * v_total // self.train_pi_iterations)
-            ride = world == 1 and not self.use_max_grad_norm  # Adam inside the gradient call (same bits)
-            stats = self.fm_pi.ppo_grad(obs, act, adv, logp_old, log_std, self.clip_ratio,
-                                        adam_lr=self.pi_opt.param_groups[0]["lr"] if ride else None)
-            if first is None:
-                first = stats.clone()
-            if not ride:
-                if self.use_max_grad_norm:
-                    torch.nn.utils.clip_grad_norm_(ac.pi.net.parameters(), self.max_grad_norm)
-                average(self.fm_pi)
-                self.fm_pi.adam_step(self.pi_opt.param_groups[0]["lr"])  # lr follows the LambdaLR schedule
-            if self.use_kl_early_stopping:
-                with torch.no_grad():  # KL(N(mu_old, s) || N(mu_new, s)) = sum (mu_old - mu_new)^2 / (2 s^2)
-                    kl = (((mu_old - self.fm_pi.forward(obs)) ** 2) / (2 * torch.exp(2 * log_std))).sum(-1).mean()
-                    if world > 1:
-                        dist.all_reduce(kl); kl /= world
-                if kl.item() > self.target_kl:
-                    stop_iter = i + 1
-                    break
-        if side is not None:
-            feed_value_stream(v_total)  # (whatever an early stop of the policy loop has left)
-            torch.cuda.current_stream(obs.device).wait_stream(side)
+        try:
+            for i in range(self.train_pi_iterations):
+                # the value steps due by now: spread evenly over the policy iterations
+                feed_value_stream((i + 1) * v_total // self.train_pi_iterations - i * v_total // self.train_pi_iterations)
+                ride = world == 1 and not self.use_max_grad_norm  # Adam inside the gradient call (same bits)
+                stats = self.fm_pi.ppo_grad(obs, act, adv, logp_old, log_std, self.clip_ratio,
+                                            adam_lr=self.pi_opt.param_groups[0]["lr"] if ride else None)
+                if first is None:
+                    first = stats.clone()
+                if not ride:
+                    if self.use_max_grad_norm:
+                        torch.nn.utils.clip_grad_norm_(ac.pi.net.parameters(), self.max_grad_norm)
+                    average(self.fm_pi)
+                    self.fm_pi.adam_step(self.pi_opt.param_groups[0]["lr"])  # lr follows the LambdaLR schedule
+                if self.use_kl_early_stopping:
+                    with torch.no_grad():  # KL(N(mu_old, s) || N(mu_new, s)) = sum (mu_old - mu_new)^2 / (2 s^2)
+                        kl = (((mu_old - self.fm_pi.forward(obs)) ** 2) / (2 * torch.exp(2 * log_std))).sum(-1).mean()
+                        if world > 1:
+                            dist.all_reduce(kl); kl /= world
+                    if kl.item() > self.target_kl:
+                        stop_iter = i + 1
+                        break
+        finally:
+            # whatever happens in the policy loop (a non-finite KL, KeyboardInterrupt): the value steps already enqueued on the
+            # side stream read `obs`, `target_v` and the value net's tensors, which were allocated on the main stream -- the
+            # main stream waits for them before anything can be freed or reused (no value step is left half-fed either)
+            if side is not None:
+                feed_value_stream(v_total)  # (whatever an early stop of the policy loop has left)
+                torch.cuda.current_stream(obs.device).wait_stream(side)
         if self.use_standardized_obs:
             ac.obs_oms.update(raw_obs)
         if self.use_reward_scaling:

@@ -27,6 +27,10 @@ VARIANTS = {
     "n2": (2, {}, {}),
     "n32": (32, {}, {}),
     "seqvalue": (8, dict(overlap_value_update=False), {}),
+    # mechanism check: without the sensor noise (no persistent gyro bias shared by all episodes of an env)
+    "n1_quiet": (1, {}, dict(observation_noise=-1)),
+    "n8_quiet": (8, {}, dict(observation_noise=-1)),
+    "n64": (64, {}, {}),
 }
 
 
@@ -49,6 +53,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=12)
     ap.add_argument("--variants", default="base,perstep,torchops,n1,n32")
+    ap.add_argument("--first-seed", type=int, default=100)
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     ref, rret, rlen = reference_curves()
@@ -57,10 +62,12 @@ def main():
     res = {}
     for name in a.variants.split(","):
         n, tkw, ekw = VARIANTS[name]
-        runs = [run(100 + s, E, spe, n, ref["env_id"], tkw, ekw) for s in range(a.seeds)]
+        runs = [run(a.first_seed + s, E, spe, n, ref["env_id"], tkw, ekw) for s in range(a.seeds)]
         res[name] = dict(ret=np.array([r[0] for r in runs]), len=np.array([r[1] for r in runs]),
                          loss_v=np.array([r[2] for r in runs]), secs=float(np.mean([r[3] for r in runs])))
-        print(f"# {name}: {n} envs x {spe // n} steps, {a.seeds} seeds, {res[name]['secs']:.1f} s each", flush=True)
+        lt = res[name]["len"][:, late].mean(axis=1)
+        print(f"# {name}: {n} envs x {spe // n} steps, {a.seeds} seeds from {a.first_seed}, {res[name]['secs']:.1f} s each; late EpLen per seed "
+              f"{np.round(lt, 1).tolist()} -> {lt.mean():.2f} +- {lt.std(ddof=1) / np.sqrt(len(lt)):.2f}", flush=True)
     names = list(res)
     print("epoch | ref EpLen mean (SE) | " + " | ".join(f"{n} EpLen mean (SE)" for n in names))
     se = lambda x: x.std(axis=0, ddof=1) / np.sqrt(x.shape[0])  # noqa: E731

@@ -257,3 +257,41 @@ def obs_atol(g, name, want_obs, rpy_first, rpy_second, noisy_obs=False):
             atol[:, c] = ATOL + 1e-6 * np.abs(want[:, h * half + e_seen[h]])  # |position component| of the same half
             e_seen[h] += 1
     return atol
+
+
+# ---- learning curves: two-sample comparison (tests/test_trainer.py) ----------------------------------------------------------
+LC_PHASES = {"early (epochs 4-8)": slice(3, 8), "first peak (9-16)": slice(8, 16), "dip (17-23)": slice(16, 23),
+             "late (24-40)": slice(23, 40)}
+
+
+def compare_learning_curves(a, b, p_min=0.01):
+    """Two samples of per-epoch curves, `a` [seeds_a, epochs] and `b` [seeds_b, epochs] (EpLen/Mean or EpRet/Mean of independent
+    training runs): are they draws from one distribution of runs?  Returns (list of failures, report dict).
+
+    Epochs WITHIN a run are strongly correlated -- a run's level in epochs 24-40 is a persistent trait of its seed (reference:
+    63 .. 113 steps over 12 seeds, SD 13) -- so the unit of every test is the SEED:
+      * per phase (LC_PHASES): the per-seed mean over the phase's epochs, Welch's t-test between the two samples, p > p_min;
+        this is the test that sees a one-sided offset: a shift of the late level by more than ~2.8 standard errors of the
+        difference fails it;
+      * per epoch: Welch's t-test with a Bonferroni factor of the number of epochs, min over epochs of p x epochs > p_min.
+    A sign test over the epochs (how many of epochs 20-40 have mean(a) above mean(b)) is REPORTED, not asserted: applied to
+    the reference pool split into two halves of 6 seeds it "fails" (more than 14 of 21 on one side) for 770 of the 924
+    splits -- consecutive epochs of a run are one observation, not 21."""
+    import numpy as np
+    from scipy import stats
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    fails, report = [], {}
+    for name, sl in LC_PHASES.items():
+        x, y = a[:, sl].mean(axis=1), b[:, sl].mean(axis=1)
+        t, p = stats.ttest_ind(x, y, equal_var=False)
+        report[name] = dict(mean_a=float(x.mean()), mean_b=float(y.mean()), t=float(t), p=float(p))
+        if not p > p_min:
+            fails.append((name, float(x.mean()), float(y.mean()), float(t), float(p)))
+    t, p = stats.ttest_ind(a, b, axis=0, equal_var=False)
+    e = int(np.argmin(p))
+    report["per epoch"] = dict(worst_epoch=e + 1, t=float(t[e]), p_bonferroni=float(min(1.0, p[e] * a.shape[1])))
+    if not p[e] * a.shape[1] > p_min:
+        fails.append(("epoch %d" % (e + 1), float(a[:, e].mean()), float(b[:, e].mean()), float(t[e]), float(p[e] * a.shape[1])))
+    d = a[:, 19:40].mean(axis=0) - b[:, 19:40].mean(axis=0)
+    report["sign count epochs 20-40 (reported only)"] = (int((d > 0).sum()), int((d < 0).sum()))
+    return fails, report

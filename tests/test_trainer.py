@@ -9,6 +9,7 @@ import pytest
 import torch
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trainer.npz")
+import golden_util as gu  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -426,28 +427,63 @@ def test_fused_rollout_refuses_what_it_is_not_built_for_and_the_trainer_falls_ba
     env.close(); env2.close()
 
 
-@pytest.mark.gpu
-def test_ppo_learning_curve_inside_the_reference_trainers_seed_band():
-    """End-to-end pin of the caller ("Hover return vs epochs"): tests/golden/learning_curve.json
-    holds the per-epoch log of the REFERENCE's own ProximalPolicyOptimizationAlgorithm.learn() (algs/ppo/ppo.py:50-63,
-    algs/iwpg/iwpg.py:259-485, defaults algs/ppo/defaults.py:6-19) on its own DroneHoverSimpleEnv-v0 with the env's
-    default sensor noise / domain randomisation / thrust noise: 6 seeds x 40 epochs x 32 000 steps
-    (oracle/refgen/gen_golden_learning.py, 28 minutes per seed).  PPOTrainer on the HIP envs runs the same
-    configuration -- 32 000 steps per epoch (8 envs x 4 000 steps: episodes follow each other in an env as they do in
-    the reference's single env), 40 epochs (the exploration-noise and learning-rate schedules span exactly them), the
-    same hyper-parameters, env.reset() at the start of every rollout like IWPGAlgorithm.roll_out -- under its own
-    randomness (Philox envs, torch initialisation), 4 seeds, ~2 s each.
-    Band: for every epoch, the mean over the HIP seeds of EpRet/Mean and of EpLen/Mean must lie inside
-    [min over the reference seeds - sigma, max over the reference seeds + sigma], sigma = the reference seeds' standard
-    deviation at that epoch (EpLen: 1.3 - 12 steps, EpRet: 0.4 - 15).  The curve is distinctive: episode length 10 -> 90
-    by epoch 12, back to 68 by epoch 19 while the exploration noise anneals, up to 95 by epoch 40; measured
-    side by side in profiles/r04_learning_curve.txt."""
+def _reference_learning_curves():
     import json
+    ref = json.load(open(os.path.join(os.path.dirname(GOLD), "learning_curve.json")))
+    seeds = [str(s_) for s_ in ref["seeds"]]
+    return ref, {k: np.array([ref["curves"][s_][k] for s_ in seeds]) for k in ("EpRet/Mean", "EpLen/Mean")}
+
+
+def test_learning_curve_fixture_is_a_sample_and_the_comparison_is_calibrated_on_it():
+    """tests/golden/learning_curve.json is a statistical SAMPLE of the reference trainer's run distribution, not a known answer
+    (re-running a seed reproduces epoch 1 and diverges from the first update on): it says so, holds >= 12 seeds, and the
+    two-sample comparison the GPU test applies (golden_util.compare_learning_curves) accepts the reference against itself --
+    its own first half of seeds against the second -- while it rejects a copy shifted by the offset round 4's band could not
+    see (+10 steps of episode length from epoch 24 on)."""
+    ref, cur = _reference_learning_curves()
+    assert "STATISTICAL SAMPLE" in ref["what"] and "NOT BIT-REPRODUCIBLE" in ref["what"]
+    n = len(ref["seeds"])
+    assert n >= 12 and (ref["epochs"], ref["steps_per_epoch"], ref["env_id"]) == (40, 32000, "DroneHoverSimpleEnv-v0")
+    for key, x in cur.items():
+        fails, _ = gu.compare_learning_curves(x[: n // 2], x[n // 2:])
+        assert not fails, (key, fails)
+    # power: what the late-phase test can see is set by the seed-to-seed spread of the late level (SD ~13 steps): the standard
+    # error of the difference of two n-seed means is 13 sqrt(2 / n), and a shift of 3.2 of them is rejected at p = 0.01 -- the
+    # pool against itself + that shift fails, as does a run distribution with the early rise two epochs late
+    x = cur["EpLen/Mean"]
+    lvl = x[:, 23:].mean(axis=1)
+    shift = 3.2 * lvl.std(ddof=1) * np.sqrt(2.0 / n)
+    assert shift < 18.0, shift  # (12 seeds: 17 steps; round 4 saw +8..12 on 6 seeds, i.e. 1.1..1.6 of ITS standard errors)
+    shifted = x.copy(); shifted[:, 23:] += shift
+    fails, rep = gu.compare_learning_curves(x + np.random.default_rng(0).normal(0, 1e-3, x.shape), shifted)
+    assert any(f[0].startswith("late") for f in fails), rep
+    late = np.concatenate([x[:, :1], x[:, :1], x[:, :-2]], axis=1)
+    fails, rep = gu.compare_learning_curves(x, late)
+    assert fails, rep
+
+
+@pytest.mark.gpu
+def test_ppo_learning_curve_matches_the_reference_trainers_run_distribution():
+    """End-to-end pin of the caller ("Hover return vs epochs"): tests/golden/learning_curve.json holds the
+    per-epoch log of the REFERENCE's own ProximalPolicyOptimizationAlgorithm.learn() (algs/ppo/ppo.py:50-63,
+    algs/iwpg/iwpg.py:259-485, defaults algs/ppo/defaults.py:6-19) on its own DroneHoverSimpleEnv-v0 with the env's default
+    sensor noise / domain randomisation / thrust noise: 12 seeds x 40 epochs x 32 000 steps (oracle/refgen/
+    gen_golden_learning.py, 22-28 minutes per seed) -- a SAMPLE of its run distribution.  PPOTrainer on the HIP envs runs the
+    same configuration (32 000 steps per epoch as 8 envs x 4 000 steps, 40 epochs -- the exploration-noise and learning-rate
+    schedules span exactly them --, the same hyper-parameters, env.reset() at the start of every rollout like
+    IWPGAlgorithm.roll_out) under its own randomness, 16 seeds of ~2 s.  The two samples are compared seed-wise
+    (golden_util.compare_learning_curves): Welch's t-test on the per-seed level of four phases of the curve -- the late one is
+    the test that sees the one-sided offset round 4's min/max band hid -- and per epoch with a Bonferroni factor; p > 0.01
+    everywhere, for EpLen and EpRet.  Round 5's bisection (profiles/r05_learning_bisect_*.txt: 24 seeds each of 8 x 4 000,
+    1 x 32 000 -- the reference's layout --, the per-step kernels, the PyTorch-op path) found the round-4 offset to be
+    sampling noise of 6 reference seeds whose late level has a seed-to-seed SD of 13 steps: against 12 reference seeds the
+    late level differs by +0.6 (1 x 32 000) to +1.2 (8 x 4 000) standard errors.
+    The trainer is deterministic for fixed seeds, so this test does not flake: it fails when the code changes the numbers."""
     import phoenix_drone_simulation_amd as pds
     from phoenix_drone_simulation_amd.ppo import PPOTrainer
-    ref = json.load(open(os.path.join(os.path.dirname(GOLD), "learning_curve.json")))
+    ref, rcur = _reference_learning_curves()
     E, spe = ref["epochs"], ref["steps_per_epoch"]
-    assert (E, spe, ref["env_id"]) == (40, 32000, "DroneHoverSimpleEnv-v0") and len(ref["seeds"]) >= 3
+    assert (E, spe, ref["env_id"]) == (40, 32000, "DroneHoverSimpleEnv-v0") and len(ref["seeds"]) >= 12
     hyper = ref["hyper"]  # what the reference ran with == PPOTrainer's defaults
     kw = dict(gamma=hyper["gamma"], lam=hyper["lam"], pi_lr=hyper["pi_lr"], vf_lr=hyper["vf_lr"],
               train_pi_iterations=hyper["train_pi_iterations"], train_v_iterations=hyper["train_v_iterations"],
@@ -457,7 +493,7 @@ def test_ppo_learning_curve_inside_the_reference_trainers_seed_band():
               use_max_grad_norm=hyper["use_max_grad_norm"], use_entropy=hyper["use_entropy"])
     num_envs = 8
     curves = {"EpRet/Mean": [], "EpLen/Mean": []}
-    for seed in (100, 101, 102, 103):
+    for seed in range(100, 116):
         env = pds.make(ref["env_id"], num_envs=num_envs, seed=seed)
         assert env.obs_dim == ref["obs_dim"]
         tr = PPOTrainer(env, rollout_len=spe // num_envs, epochs=E, seed=seed, reset_each_rollout=True, **kw)
@@ -466,12 +502,8 @@ def test_ppo_learning_curve_inside_the_reference_trainers_seed_band():
         curves["EpLen/Mean"].append([r["ep_len"] for r in tr.log])
         env.close()
     for key, mine in curves.items():
-        r = np.array([ref["curves"][str(s)][key] for s in ref["seeds"]])
-        m = np.mean(np.array(mine), axis=0)
-        sigma = r.std(axis=0)
-        lo, hi = r.min(axis=0) - sigma, r.max(axis=0) + sigma
-        bad = np.nonzero((m < lo) | (m > hi))[0]
-        assert bad.size == 0, (key, [(int(e) + 1, float(m[e]), float(lo[e]), float(hi[e])) for e in bad])
-    # ... and it is the reference's curve, not just a wide band: rise, dip while the noise anneals, rise
+        fails, report = gu.compare_learning_curves(np.array(mine), rcur[key])
+        assert not fails, (key, fails, report)
+    # ... and it is the reference's curve: rise, dip while the noise anneals, rise
     ln = np.mean(np.array(curves["EpLen/Mean"]), axis=0)
-    assert ln[:3].mean() < 16 and ln[9:13].mean() > 70 and ln[17:21].mean() < ln[9:13].mean() - 5 and ln[35:].mean() > ln[17:21].mean() + 10
+    assert ln[:3].mean() < 16 and ln[9:13].mean() > 70 and ln[17:21].mean() < ln[9:13].mean() - 4 and ln[35:].mean() > ln[17:21].mean() + 10
