@@ -238,16 +238,12 @@ __global__ __launch_bounds__(kBlock) void materialize_oh_kernel(DevState st, Con
 // =================================================================================================
 using namespace pds;
 
-#ifndef PDS_STORED_OH_FROM_AGG
-#define PDS_STORED_OH_FROM_AGG 2  // A/B: 0 = every single-step launch regenerates the kept observation (round 4)
-#endif
-
 struct pds_handle {
   pds_config cfg;
   DevState st;
   Consts k;
   LaunchFlags flags;
-  int force_tile = 0;  // PDS_FORCE_TILE=half|full (tests / A-B runs): 1 half, 2 full, 0 pick per launch
+  int force_tile;  // PDS_FORCE_TILE=half|full (tests / A-B runs): 1 half, 2 full, 0 pick per launch
   float2 *d_circle_ref;
   void *slab;  // one allocation holds every state array (staggered, see pds_create)
   float4 *lat_buf;  // [PDS_MAX_LATENCY_STEPS][N] delayed-action ring, allocated when latency is first enabled
@@ -257,8 +253,8 @@ struct pds_handle {
   int num_cus;    // hipDeviceProp.multiProcessorCount (256 on MI355X): drives the half-tile rule
   uint64_t tick;  // host mirror of the device clock words (pds_sync_tick refreshes it)
   bool was_reset;
-  int stored_from_agg = PDS_STORED_OH_FROM_AGG;  // aggregate_phy_steps from which pds_step keeps the noisy observation in memory
-  bool stored_ready = false;  // kLaunchStepStored handles: the one materialize_oh_kernel pass in front of their first step is done
+  int stored_from_agg;  // (set in pds_create) aggregate_phy_steps from which pds_step keeps the noisy observation in memory
+  bool stored_ready;  // kLaunchStepStored handles: the one materialize_oh_kernel pass in front of their first step is done
   char err[512];
 };
 
@@ -531,7 +527,9 @@ extern "C" int pds_create(const pds_config *cfg, pds_handle **out) {
   h->flags.hold = h->k.obs_rate != 1;
   h->flags.half_tile = false;
   if (const char *ft = getenv("PDS_FORCE_TILE")) h->force_tile = (ft[0] == 'h') ? 1 : ((ft[0] == 'f') ? 2 : 0);
-  if (const char *sa = getenv("PDS_STORED_OH_FROM_AGG")) h->stored_from_agg = atoi(sa);  // (A/B runs: 0 = always regenerate)
+  h->stored_from_agg = PDS_STORED_OH_FROM_AGG;  // (the memset above wiped the member initialisers)
+  if (PDS_STORED_OH_FROM_AGG > 0)
+    if (const char *sa = getenv("PDS_STORED_OH_FROM_AGG")) h->stored_from_agg = atoi(sa);  // (A/B builds: 0 = always regenerate)
   const size_t n = (size_t)cfg->num_envs;
   const size_t ntiles = (n + kWave - 1) / kWave;
   const LaunchFlags &f = h->flags;
@@ -689,8 +687,7 @@ extern "C" int pds_set_latency(pds_handle *h, double latency) {
 // read action 16 + dyn state 48 + action history 32 + counter 4; write dyn state 48
 // + newest history slot 16 + counter 4 + reward 4 + cost 4 + terminated 1 + truncated 1; obs 4*D;
 // DR params +24; motor PT1: x R+W 32 (+ A, K 32 when randomised); OU state R+W 32; gyro bias +
-// low-pass R+W 48; kept noisy observation (10 floats) R+W 80 with the Kalman hold (obs_rate > 1) and with two or more physics
-// sub-steps per env.step (kLaunchStepStored: the step is bound by the vector ALU there) -- otherwise it is
+// low-pass R+W 48; kept noisy observation (10 floats) R+W 80 only with the Kalman hold (obs_rate > 1) -- otherwise it is
 // regenerated from the previous tick's Philox blocks, not kept (csrc/pds_reset.h regen_kept_obs; pds_step_with_variates
 // and the first step after an explicit reset still move those 80 B); latency ring: one row R+W per physics
 // sub-step.  (The per-tile clock word adds 0.5 B per env-step and is not counted.)

@@ -1243,15 +1243,15 @@ inline void launch_variant(int kind, bool half_tile, dim3 grid, hipStream_t s, c
     // (the PID control modes have no K-step kernel: pds_step_k loops over pds_step for them)
     if constexpr (V::CTRL == 0) hipLaunchKernelGGL((step_k_kernel<V>), grid, dim3(kBlock), 0, s, a);
   } else {
+#if PDS_STORED_OH_FROM_AGG > 0
     if constexpr (regen_obs_variant<V>()) {
-      // stored vs regenerated kept observation is a per-launch choice (same bits either way): regenerate where the step is
-      // memory-bound (one physics sub-step: Hover default 2^20 85.7 -> 79.9 us), keep it in memory where the vector ALU is
-      // the bound (two sub-steps 113.2 vs 116.2 us, four 193.8 vs 200.6: profiles/r04_ab_stepk_regen.txt)
+      // stored vs regenerated kept observation as a per-launch choice (same bits either way): see kLaunchStepStored
       if (kind == kLaunchStepStored) {
         hipLaunchKernelGGL((step_kernel<StoredOh<V>, kWave>), grid, dim3(kBlock), 0, s, a);
         return;
       }
     }
+#endif
     if constexpr (!V::ON && !V::LAT) {
       if (half_tile) {
         hipLaunchKernelGGL((step_kernel<V, kHalfTileRows>), grid, dim3(kBlock), 0, s, a);

@@ -351,8 +351,13 @@ struct LaunchFlags {
   bool half_tile;  // per launch: use the 32-row observation tile (variants without observation noise)
 };
 // kLaunchStepStored: the single-step kernel of an observation-noise variant in its StoredOh form (the kept noisy observation read
-// from and written to oh0-2 instead of regenerated): pds_step with aggregate_phy_steps >= 2, where the step is bound by the
-// vector ALU and the regeneration costs more than the 80 B per env-step it saves (csrc/pds_step.h launch_variant).
+// from and written to oh0-2 instead of regenerated) for pds_step with aggregate_phy_steps >= PDS_STORED_OH_FROM_AGG.  Built and
+// measured in round 5, NOT adopted (the macro is 0: the kernels are not instantiated): the regenerating form is the faster one at
+// every sub-step count -- same box, Hover default 2^20: 2 sub-steps 113.5 vs 120.9 us, 4 sub-steps 197.5 vs 205.4
+// (profiles/r05_ab_stored_vs_regen.txt): it runs four blocks per CU (csrc/pds_step.h four_block_variant), the stored form three.
+#ifndef PDS_STORED_OH_FROM_AGG
+#define PDS_STORED_OH_FROM_AGG 0  // A/B builds: 2 = instantiate the stored single-step kernels and use them from 2 sub-steps on
+#endif
 enum LaunchKind { kLaunchStep = 0, kLaunchStepK = 1, kLaunchReset = 2, kLaunchStepStored = 3 };
 // one translation unit per (task, family) keeps the build parallel: pds_task_*.hip
 // Arguments of the fused rollout (csrc/pds_rollout.h).

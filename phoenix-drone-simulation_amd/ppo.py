@@ -261,8 +261,18 @@ class PPOTrainer:
         self.fused_rollout = fused_rollout
         if self.fused:
             from .fused import FusedMLP
-            self.fm_pi = FusedMLP(self.ac.pi.net, kw["pi"]["activation"])
-            self.fm_v = FusedMLP(self.ac.v.net, kw["val"]["activation"])
+            try:
+                self.fm_pi = FusedMLP(self.ac.pi.net, kw["pi"]["activation"])
+                self.fm_v = FusedMLP(self.ac.v.net, kw["val"]["activation"])
+            except (ValueError, NotImplementedError):
+                # outside the fused kernels' range -- more than 64 inputs (observation_history_size >= 4 on Hover,
+                # experiments/04_*: 4 x 17 = 68), other depths / activations: the networks run as PyTorch ops on the HIP
+                # envs (same update, the path the fused kernels are tested against); asked for explicitly, it is an error
+                if fused:
+                    raise
+                self.fused = False
+                self.graph_rollout = False
+        if self.fused:
             # Adam runs in pds_adam_step; the torch optimisers only carry the learning rate (LambdaLR)
             self.pi_opt._opt_called = True
         T, N, D = self.T, self.N, env.obs_dim

@@ -52,6 +52,23 @@ def test_bench_multi_rank_code_path_on_one_gpu():
     assert abs(d["value"] - 2 * 65536 * 20 / (d["ms_per_step"] * 20e-3)) < 1e-6 * d["value"]
 
 
+def test_bench_eight_ranks_on_one_device_p2p_gather():
+    """The multi-rank path at the node's real world size: `bench.py --gpus 8`, the eight ranks on
+    cuda:0 (--same-device, gloo control plane), 8 192 envs each, the peer-to-peer observation gather with HIP IPC memory
+    and event handles opened 8-way (bench.py checks the gathered rows against the owners' blocks before it times).
+    What stays unmeasured without an 8-GPU node: the xGMI links themselves and RCCL at 8 ranks."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "4",
+           "--envs-per-gpu", "8192", "--same-device", "--allgather-obs", "p2p", "--no-cpu-baseline", "--no-traffic"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    d = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 8 and d["ranks"] == 8 and len(d["per_rank_ms_per_step"]) == 8 and d["allgather_ms"] > 0
+    assert d["collective_backend"] == "gloo" and "p2p" in d["config"]["parallelism"] and d["scaling"] == "weak"
+    assert abs(d["value"] - 8 * 8192 * 20 / (d["ms_per_step"] * 20e-3)) < 1e-6 * d["value"]
+
+
 def test_bench_gpus_n_without_a_launcher_spawns_its_own_ranks():
     """`python bench.py --gpus 2` with WORLD_SIZE unset (no torch.distributed.run around it): bench.py starts
     the two ranks itself as a child launcher (the role of the reference's mpi_fork, utils/mpi_tools.py:47-99),

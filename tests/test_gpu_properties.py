@@ -121,6 +121,34 @@ def test_determinism_and_shard_invariance():
         e.close()
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(use_motor_dynamics=True, control_mode="AttitudeRate", aggregate_phy_steps=2)])
+def test_eight_way_ragged_sharding_equals_one_handle_bitwise(kw):
+    """The node's real world size: the reference-default (noisy, domain-randomised) batch cut into
+    EIGHT contiguous global-id blocks by sharding.shard_range -- ragged: 8 x 1031 + 5 envs, no block a multiple of the
+    64-env tile -- reproduces the single handle bit for bit over resets, steps, in-kernel auto-resets and truncations,
+    because every random draw is keyed by (seed, GLOBAL env id, tick)."""
+    import phoenix_drone_simulation_amd as pds
+    from phoenix_drone_simulation_amd.sharding import shard_range
+    world, n = 8, 8 * 1031 + 5
+    base = dict(seed=17, max_episode_steps=23)
+    base.update(kw)
+    one = pds.make(ENV_ID["hover"], num_envs=n, **base)
+    spans = [shard_range(n, r, world) for r in range(world)]
+    assert spans[0][0] == 0 and spans[-1][1] == n and len({b - a for a, b in spans}) == 2
+    shards = [pds.make(ENV_ID["hover"], num_envs=b - a, env_id_base=a, **base) for a, b in spans]
+    o1, _ = one.reset()
+    assert torch.equal(o1, torch.cat([s.reset()[0] for s in shards]))
+    for k in range(40):
+        a = _actions(n, o1.device, 300 + k)
+        r1 = one.step(a)
+        rs = [s.step(a[lo:hi].contiguous()) for s, (lo, hi) in zip(shards, spans)]
+        for j in range(4):
+            assert torch.equal(r1[j], torch.cat([r[j] for r in rs])), (k, j)
+        assert torch.equal(r1[4]["final_obs"], torch.cat([r[4]["final_obs"] for r in rs]))
+    for e in [one] + shards:
+        e.close()
+
+
 def test_reset_distribution_statistics():
     """In-kernel Philox reset distribution of Hover (envs/hover.py:201-229): ranges and moments."""
     import phoenix_drone_simulation_amd as pds

@@ -507,3 +507,27 @@ def test_ppo_learning_curve_matches_the_reference_trainers_run_distribution():
     # ... and it is the reference's curve: rise, dip while the noise anneals, rise
     ln = np.mean(np.array(curves["EpLen/Mean"]), axis=0)
     assert ln[:3].mean() < 16 and ln[9:13].mean() > 70 and ln[17:21].mean() < ln[9:13].mean() - 4 and ln[35:].mean() > ln[17:21].mean() + 10
+
+
+@pytest.mark.gpu
+def test_trainer_falls_back_to_torch_networks_beyond_the_fused_kernels_range():
+    """observation_history_size = 4 (experiments/04_*: the reference trains H = 1 .. 8, envs/base.py:303-319) gives Hover 4 x 17 =
+    68 network inputs, more than the fused MFMA kernels' 64: PPOTrainer keeps the HIP envs (with pds_history_advance) and runs
+    the two networks as PyTorch ops; asked for explicitly (fused=True) it refuses."""
+    import phoenix_drone_simulation_amd as pds
+    from phoenix_drone_simulation_amd.ppo import PPOTrainer
+    env = pds.make("DroneHoverSimpleEnv-v0", num_envs=256, seed=3, observation_history_size=4)
+    assert env.obs_dim == 68
+    tr = PPOTrainer(env, rollout_len=16, epochs=3, train_pi_iterations=4, train_v_iterations=1, seed=5)
+    assert tr.fused is False and tr.graph_rollout is False
+    info = tr.learn_one_epoch()
+    assert np.isfinite(info["loss_pi"]) and np.isfinite(info["loss_v"]) and info["episodes"] > 0
+    with pytest.raises(ValueError):
+        PPOTrainer(env, rollout_len=16, epochs=3, seed=5, fused=True)
+    env.close()
+    small = pds.make("DroneHoverSimpleEnv-v0", num_envs=256, seed=3, observation_history_size=3)  # 51 inputs: fused
+    tr = PPOTrainer(small, rollout_len=16, epochs=3, train_pi_iterations=4, train_v_iterations=1, seed=5)
+    assert tr.fused is True
+    info = tr.learn_one_epoch()
+    assert np.isfinite(info["loss_pi"]) and tr.fused_rollout is not True  # (no one-launch rollout for H != 2)
+    small.close()
