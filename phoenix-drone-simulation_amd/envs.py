@@ -372,8 +372,6 @@ class DroneVecEnv:
                                 dtype=torch.float32).to(self.device).contiguous()
         if a.dim() != 3 or tuple(a.shape[1:]) != self._shape:
             raise ValueError(f"actions must have shape (K, {self.num_envs}, 4), got {tuple(a.shape)}")
-        if self._hist is not None:
-            raise NotImplementedError("step_k with observation_history_size != 2")
         K, N, D = int(a.shape[0]), self.num_envs, 2 * self._half
         b = out if out is not None else self._kbufs.get(K)
         if b is None:
@@ -388,8 +386,31 @@ class DroneVecEnv:
                                  b["final_obs"].data_ptr(), self._raw_stream())
         if rc != 0:
             native.check(self._handle, rc, "pds_step_k")
-        return (b["obs"], b["reward"], b["terminated"].view(torch.bool), b["truncated"].view(torch.bool),
-                {"cost": b["cost"], "final_obs": b["final_obs"], "final_observation": b["final_obs"]})
+        obs, final = b["obs"], b["final_obs"]
+        if self._hist is not None:
+            # observation_history_size != 2: the K rows of the launch run through pds_history_advance one after the other
+            # (K more launches; the env state itself advanced in one)
+            H, half = self.observation_history_size, self._half
+            if "obs_hist" not in b:
+                b["obs_hist"] = torch.empty(K, N, H, half, dtype=torch.float32, device=self.device)
+                b["final_hist"] = torch.zeros(K, N, H, half, dtype=torch.float32, device=self.device)
+            hist = self._hist
+            with (_NULL_CTX if self.device.index == torch.cuda.current_device() else torch.cuda.device(self.device)):
+                for k in range(K):
+                    rc = self.lib.pds_history_advance(N, half, H, obs[k].data_ptr(), b["terminated"][k].data_ptr(),
+                                                      b["truncated"][k].data_ptr(),
+                                                      final[k].data_ptr() if self._auto_reset else None, int(self._auto_reset),
+                                                      hist.data_ptr(), b["obs_hist"][k].data_ptr(),
+                                                      b["final_hist"][k].data_ptr() if self._auto_reset else None,
+                                                      self._raw_stream())
+                    if rc != 0:
+                        native.check(self._handle, rc, "pds_history_advance")
+                    hist = b["obs_hist"][k]
+            self._hist = hist.clone()  # (the cached set is rewritten by the next call)
+            obs = b["obs_hist"].reshape(K, N, H * half)
+            final = b["final_hist"].reshape(K, N, H * half) if self._auto_reset else obs
+        return (obs, b["reward"], b["terminated"].view(torch.bool), b["truncated"].view(torch.bool),
+                {"cost": b["cost"], "final_obs": final, "final_observation": final})
 
     def set_latency(self, new_latency):
         """CrazyFlieAgent.set_latency (envs/agents.py:388-404): below one time step the delay is switched

@@ -161,3 +161,26 @@ def test_entry_points_keep_the_callers_current_device():
     env.reset(); env.step(torch.zeros(256, 4, device=env.device)); env.get_state("pos"); env.count_nonfinite()
     assert torch.cuda.current_device() == before
     env.close()
+
+
+@pytest.mark.parametrize("H,auto_reset", [(4, True), (1, True), (6, False)])
+def test_step_k_with_observation_history_other_than_two(H, auto_reset):
+    """observation_history_size != 2 (experiments/04_*, envs/base.py:303-319) through pds_step_k: the K rows of the launch run
+    through pds_history_advance one after the other -- bit for bit what K step() calls return, final histories included."""
+    import phoenix_drone_simulation_amd as pds
+    n, K = 3000, 7
+    kw = dict(seed=9, observation_history_size=H, max_episode_steps=5, auto_reset=auto_reset)
+    a, b = (pds.make("DroneHoverSimpleEnv-v0", num_envs=n, **kw) for _ in range(2))
+    oa, _ = a.reset(); ob, _ = b.reset()
+    assert torch.equal(oa, ob) and oa.shape == (n, H * 17)
+    g = torch.Generator(device=a.device); g.manual_seed(0)
+    for rnd in range(2):
+        acts = (-0.11 + 0.1 * torch.randn(K, n, 4, generator=g, device=a.device)).contiguous()
+        ko, kr, kt, ku, kinfo = a.step_k(acts)
+        for k in range(K):
+            o, r, t, u, info = b.step(acts[k])
+            assert torch.equal(ko[k], o) and torch.equal(kr[k], r) and torch.equal(kt[k], t) and torch.equal(ku[k], u), (rnd, k)
+            done = t | u
+            if auto_reset and bool(done.any()):
+                assert torch.equal(kinfo["final_obs"][k][done], info["final_obs"][done]), (rnd, k)
+    a.close(); b.close()
