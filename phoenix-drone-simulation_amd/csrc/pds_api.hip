@@ -490,8 +490,15 @@ extern "C" int pds_create(const pds_config *cfg, pds_handle **out) {
                     (long long)cfg->env_id_base, (long long)cfg->num_envs);
   if (cfg->device < 0) PDS_CREATE_FAIL(PDS_EINVAL, "device %d is negative", cfg->device);
   if (cfg->control_mode < 0 || cfg->control_mode > 2) PDS_CREATE_FAIL(PDS_EINVAL, "control_mode %d", cfg->control_mode);
-  if (cfg->control_mode != PDS_CTRL_PWM && (cfg->task == PDS_TASK_TAKEOFF || cfg->use_ground_effect))
-    PDS_CREATE_FAIL(PDS_EUNSUPPORTED, "control_mode %d: the PID modes exist for Hover/Circle without the ground-effect extension", cfg->control_mode);
+  if (cfg->control_mode != PDS_CTRL_PWM && cfg->task == PDS_TASK_TAKEOFF)
+    PDS_CREATE_FAIL(PDS_EUNSUPPORTED, "control_mode %d: the PID modes exist for Hover/Circle (TakeOff fixes control_mode PWM, envs/takeoff.py:225)", cfg->control_mode);
+  if (cfg->control_mode != PDS_CTRL_PWM && cfg->use_ground_effect) {
+    // round 5: PID + ground effect is built; not together with the latency ring or the Kalman hold
+    const int sf = (int)llround(1.0 / cfg->time_step);
+    const bool hold = cfg->observation_noise > 0 && cfg->observation_frequency > 0 && sf / cfg->observation_frequency != 1;
+    if (cfg->use_latency || hold)
+      PDS_CREATE_FAIL(PDS_EUNSUPPORTED, "control_mode %d with the ground-effect extension: not with use_latency or observation_frequency < sim_freq", cfg->control_mode);
+  }
   if (cfg->observation_frequency < 1) PDS_CREATE_FAIL(PDS_EINVAL, "observation_frequency %d", cfg->observation_frequency);
   if (cfg->task == PDS_TASK_CIRCLE && 3 * cfg->observation_frequency > PDS_MAX_REF_POINTS)
     PDS_CREATE_FAIL(PDS_EUNSUPPORTED, "Circle with observation_frequency %d needs %d reference points (limit %d)",
@@ -741,7 +748,10 @@ static void launch_family(pds_handle *h, int kind, const LaunchFlags &lf, dim3 g
     else if (task == PDS_TASK_CIRCLE) launch_circle_lat(kind, lf, grid, s, a);
     else launch_takeoff_lat(kind, lf, grid, s, a);
   } else if (lf.ctrl != 0 && kind != kLaunchReset) {
-    if (task == PDS_TASK_HOVER) launch_hover_pid(kind, lf, grid, s, a);
+    if (lf.ge) {
+      if (task == PDS_TASK_HOVER) launch_hover_pid_ge(kind, lf, grid, s, a);
+      else launch_circle_pid_ge(kind, lf, grid, s, a);
+    } else if (task == PDS_TASK_HOVER) launch_hover_pid(kind, lf, grid, s, a);
     else launch_circle_pid(kind, lf, grid, s, a);
   } else {
     if (task == PDS_TASK_HOVER) launch_hover(kind, lf, grid, s, a);

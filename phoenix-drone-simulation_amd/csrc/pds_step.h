@@ -1296,6 +1296,24 @@ inline void launch_pid(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s,
   if (f.ctrl == 1) VariantDispatch<TASK, 1, false, false>::run(kind, f.half_tile, grid, s, a, f.motor, f.dr, false, f.tn, f.on);
   else VariantDispatch<TASK, 2, false, false>::run(kind, f.half_tile, grid, s, a, f.motor, f.dr, false, f.tn, f.on);
 }
+// round 5: the PID modes with the ground-effect extension (envs/physics.py:27-58 x envs/control.py:120-287), a family (and a
+// translation unit, pds_task_*_pid_ge.hip) of its own: 2 x 16 variants; not with the latency ring or the Kalman hold
+template <int TASK, int CTRL>
+inline void launch_pid_ge_ctrl(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a) {
+#define PDS_PGE(M, R, T, O) launch_variant<Variant<TASK, M, R, true, T, O, CTRL, false, false>>(kind, f.half_tile, grid, s, a)
+#define PDS_PGE_O(M, R, T) do { if (f.on) PDS_PGE(M, R, T, true); else PDS_PGE(M, R, T, false); } while (0)
+#define PDS_PGE_T(M, R) do { if (f.tn) PDS_PGE_O(M, R, true); else PDS_PGE_O(M, R, false); } while (0)
+  if (f.motor) { if (f.dr) PDS_PGE_T(true, true); else PDS_PGE_T(true, false); }
+  else { if (f.dr) PDS_PGE_T(false, true); else PDS_PGE_T(false, false); }
+#undef PDS_PGE_T
+#undef PDS_PGE_O
+#undef PDS_PGE
+}
+template <int TASK>
+inline void launch_pid_ge(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a) {
+  if (f.ctrl == 1) launch_pid_ge_ctrl<TASK, 1>(kind, f, grid, s, a);
+  else launch_pid_ge_ctrl<TASK, 2>(kind, f, grid, s, a);
+}
 template <int TASK>
 inline void launch_lat(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a) {
   if (kind == kLaunchReset) { VariantDispatch<TASK, 0, true, false>::run(kind, false, grid, s, a, f.motor, f.dr, false, false, f.on); return; }

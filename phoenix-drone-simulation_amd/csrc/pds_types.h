@@ -402,6 +402,8 @@ void launch_circle(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, con
 void launch_takeoff(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
 void launch_hover_pid(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
 void launch_circle_pid(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
+void launch_hover_pid_ge(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
+void launch_circle_pid_ge(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
 void launch_hover_lat(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
 void launch_circle_lat(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);
 void launch_takeoff_lat(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a);

@@ -389,7 +389,9 @@ def _variant_grid(task):
     import itertools
     for motor, dr, tn, on, ge, ctrl, agg in itertools.product((0, 1), (0, 1), (0, 1), (0, 1), (0, 1),
                                                                 ("PWM", "AttitudeRate", "Attitude"), (1, 2)):
-        if ctrl != "PWM" and (task == "takeoff" or ge):
+        if ctrl != "PWM" and task == "takeoff":
+            continue
+        if ctrl != "PWM" and ge and (agg == 2 or (tn and not on)):  # round 5: PID + ground effect (thinned)
             continue
         if task == "takeoff" and agg != 1:  # envs/takeoff.py:224-225 fixes aggregate_phy_steps = 1
             continue

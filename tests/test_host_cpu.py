@@ -99,11 +99,11 @@ _BAD_CONFIGS = [
     (0, dict(observation_frequency=0), "EINVAL", b"observation_frequency"),
     (1, dict(observation_frequency=101), "EUNSUPPORTED", b"reference points"),
     (0, dict(observation_frequency=200), "EINVAL", b"obs_rate 0"),       # base.py:108 would divide by 0
-    # (round 4: the Kalman-hold branch with latency / a PID mode is built; what remains refused with it is the
-    #  ground-effect extension under a PID mode, like everywhere)
+    # (round 4: the Kalman-hold branch with latency / a PID mode is built; round 5: the ground-effect extension under a PID
+    #  mode too -- what remains refused is that pair together with the hold or the latency ring)
     (0, dict(observation_frequency=50, control_mode=1, use_ground_effect=1), "EUNSUPPORTED", b"ground"),
     (0, dict(use_latency=1, latency=0.10), "EUNSUPPORTED", b"latency"),  # 10 rows > PDS_MAX_LATENCY_STEPS
-    (0, dict(use_latency=1, use_ground_effect=1, control_mode=1), "EUNSUPPORTED", b"PID modes"),  # (latency + ground effect: PWM only)
+    (0, dict(use_latency=1, use_ground_effect=1, control_mode=1), "EUNSUPPORTED", b"ground"),  # (latency + ground effect: PWM only)
 ]
 
 
