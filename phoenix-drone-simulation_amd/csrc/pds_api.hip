@@ -207,11 +207,12 @@ __global__ __launch_bounds__(256) void latency_clear_kernel(DevState st, long lo
   st.ctr[i] = ctr_pack(ctr_step(c), ctr_sign(c), ctr_off(c), 0u) | (c & kCtrOhBit);
 }
 
-// In front of the K-step kernel of an observation-noise variant (regen_obs_variant): the kept noisy observation of every env
-// that does not have it in oh0-2 (i.e. every env after a pds_step, none after a pds_step_k) is regenerated there and flagged
-// in the counter word -- what the single-step kernels do in their prologue (init_kept_obs), as a pass of its own so that the
-// K-step kernel's loop is not compiled around it (csrc/pds_step.h, step_k_kernel).  Same function, same inputs, same bits.
-// 4 B per env when every env is flagged, 52 + 44 B otherwise.
+// The kept noisy observation of every env that does not have it in oh0-2 (i.e. every env after a pds_step, none after a
+// pds_step_k / pds_rollout / reset) is regenerated there and flagged in the counter word -- what the single-step kernels do in
+// their prologue (init_kept_obs), as a pass of its own: in front of the K-step and rollout kernels (so that their loops are not
+// compiled around it, csrc/pds_step.h step_k_kernel) and in front of every call that changes the regeneration's inputs without
+// stepping the env (materialize_kept_obs below).  Same function, same inputs, same bits.  4 B per env when every env is
+// flagged, 52 + 44 B otherwise.
 __global__ __launch_bounds__(kBlock) void materialize_oh_kernel(DevState st, Consts k, long long n, unsigned long long env_id_base,
                                                                 uint32_t seed_lo, uint32_t seed_hi) {
   const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
@@ -941,8 +942,9 @@ extern "C" int pds_rollout(pds_handle *h, int T, const pds_mlp *pi, const pds_ml
   const dim3 grid((unsigned)tiles);  // (the number of tiles: the launchers pick one or two tiles per block, csrc/pds_rollout.h)
   // support is decided BEFORE the handle is touched (a refused call leaves it as it was)
   if (!rollout_supported(h->cfg.task, h->flags))
-    return fail(h, PDS_EUNSUPPORTED, "pds_rollout: no kernel for this env configuration (ground effect; TakeOff with motor dynamics "
-                                     "and no latency ring)");
+    return fail(h, PDS_EUNSUPPORTED, "pds_rollout: no kernel for this env configuration (not built: the ground effect; the Kalman hold or "
+                                     "partial noise settings together with a PID mode or the latency ring; TakeOff with motor dynamics "
+                                     "without the latency ring) -- the per-step kernels give the same bits");
   // the env waves read the kept noisy observation from oh0-2 (StoredOh, like the K-step kernel)
   if (const int rc = materialize_kept_obs(h, (hipStream_t)stream)) return rc;
   bool ok;
