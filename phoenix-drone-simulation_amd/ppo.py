@@ -246,6 +246,9 @@ class PPOTrainer:
         self.fused = (dev.type == "cuda") if fused is None else bool(fused)
         self._sample_seed, self._sample_calls = (seed + 10000 * rank) & 0xFFFFFFFFFFFFFFFF, 0
         self._perm_calls = 0  # call counter of the mini-batch shuffles (pds_permutation)
+        # tests: a callable B -> int64 index tensor that replaces the value net's shuffle (the reference's np.random.shuffle
+        # sequences are replayed through it: tests/golden/update.npz)
+        self.perm_fn = None
         # hipGraph capture of the whole rollout (fused path, even rollout length so that the env's two output
         # sets line up from replay to replay): the env step is capturable (tick / parity in device memory), the
         # sampling call counter gets a device word that the graph advances once per replay
@@ -436,7 +439,7 @@ class PPOTrainer:
             return self._fused_update(data, raw_obs, disc_ret, B, mbs)
         loss_v_before = value_loss(ac, data["obs"], data["target_v"]).item()
         for _ in range(self.train_v_iterations):
-            perm = torch.randperm(B, device=obs.device)
+            perm = self.perm_fn(B) if self.perm_fn is not None else torch.randperm(B, device=obs.device)
             for s in range(0, mbs * self.num_mini_batches, mbs):
                 idx = perm[s:s + mbs]
                 self.vf_opt.zero_grad()
@@ -494,7 +497,8 @@ class PPOTrainer:
             for _ in range(self.train_v_iterations):
                 # one elementwise launch (pds_permutation) where torch.randperm sorts (~160 us at 2^19 samples, 5 x per epoch)
                 self._perm_calls += 1
-                perm = random_permutation(B, self._sample_seed ^ 0x5045524D, self._perm_calls, obs.device)
+                perm = (self.perm_fn(B) if self.perm_fn is not None else
+                        random_permutation(B, self._sample_seed ^ 0x5045524D, self._perm_calls, obs.device))
                 for s in range(0, mbs * self.num_mini_batches, mbs):
                     if world == 1:  # the Adam step rides on the gradient's partial-sum kernel (same bits, one launch less)
                         self.fm_v.value_grad(obs, target_v, index=perm[s:s + mbs], adam_lr=self.vf_opt.param_groups[0]["lr"])

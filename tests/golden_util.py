@@ -295,3 +295,54 @@ def compare_learning_curves(a, b, p_min=0.01):
     d = a[:, 19:40].mean(axis=0) - b[:, 19:40].mean(axis=0)
     report["sign count epochs 20-40 (reported only)"] = (int((d > 0).sum()), int((d < 0).sum()))
     return fails, report
+
+
+# ---- one full update() of the reference's trainer (tests/golden/update.npz, oracle/refgen/gen_golden_update.py) --------------
+def gae_torch(rew, val, terminated, truncated, final_val, last_val, gamma, lam, rew_scale=0.0, rew_clip=10.0):
+    """csrc/pds_gae.hip restated with torch ops on [T, N] tensors of any device (test infrastructure: the CPU test of the
+    trainer's update runs without the HIP library).  -> [adv, target_v, discounted_ret]"""
+    import torch
+    T, N = rew.shape
+    adv, tv, dr = torch.empty_like(rew), torch.empty_like(rew), torch.empty_like(rew)
+    zero = torch.zeros(N, dtype=rew.dtype, device=rew.device)
+    next_val, next_ret, next_adv = last_val.clone(), last_val.clone(), zero.clone()
+    gl = gamma * lam
+    for t in range(T - 1, -1, -1):
+        te, tr = terminated[t].bool(), truncated[t].bool()
+        end = te | tr
+        b = torch.where(te, zero, final_val[t] if final_val is not None else zero)
+        next_val, next_ret, next_adv = torch.where(end, b, next_val), torch.where(end, b, next_ret), torch.where(end, zero, next_adv)
+        rs = torch.clamp(rew[t] * rew_scale, -rew_clip, rew_clip) if rew_scale > 0 else rew[t]
+        a = (rs + gamma * next_val - val[t]) + gl * next_adv
+        g = rew[t] + gamma * next_ret
+        adv[t], tv[t], dr[t] = a, a + val[t], g
+        next_val, next_adv, next_ret = val[t], a, g
+    return [adv, tv, dr]
+
+
+def load_update_epoch(g, e, device):
+    """The reference's rollout of epoch `e` in PPOTrainer's [T, N = 1] buffer layout: a path that ended by termination
+    bootstraps with 0 (term = 1), one the epoch end or the TimeLimit cut with the recorded V (trunc = 1, fval = V; the last
+    path: last_val).  -> dict of tensors."""
+    import numpy as np
+    import torch
+    T = int(g["steps"])
+    term = g[f"e{e}_terminated"].astype(np.uint8).copy()
+    trunc = np.zeros(T, np.uint8)
+    fval = np.zeros(T, np.float32)
+    ends, lasts = g[f"e{e}_path_end"], g[f"e{e}_path_last_val"]
+    last_val = 0.0
+    for end, lv in zip(ends, lasts):
+        t = int(end) - 1
+        if end == T and not term[t]:
+            last_val = float(lv)          # epoch end: PPOTrainer's last_val (no flag on the last step)
+        elif term[t] and lv == 0.0:
+            pass                           # terminated: bootstrap 0
+        else:                              # the TimeLimit cut (or terminated AND cut: the reference takes V, iwpg.py:375-379)
+            term[t], trunc[t], fval[t] = 0, 1, lv
+    f = lambda x, dt=torch.float32: torch.as_tensor(np.asarray(x), dtype=dt, device=device)  # noqa: E731
+    return dict(obs=f(g[f"e{e}_obs_buf"])[:, None], act=f(g[f"e{e}_act_buf"])[:, None], rew=f(g[f"e{e}_rew_buf"])[:, None],
+                val=f(g[f"e{e}_val_buf"])[:, None], logp=f(g[f"e{e}_logp_buf"])[:, None], term=f(term, torch.uint8)[:, None],
+                trunc=f(trunc, torch.uint8)[:, None], fval=f(fval)[:, None], last_val=f([last_val]),
+                adv=f(g[f"e{e}_adv_buf"]), target_v=f(g[f"e{e}_target_val_buf"]), disc_ret=f(g[f"e{e}_discounted_ret_buf"]),
+                shuffles=[torch.as_tensor(p_, dtype=torch.int64, device=device) for p_ in g[f"e{e}_shuffles"]])

@@ -587,3 +587,80 @@ def test_trainer_falls_back_to_torch_networks_beyond_the_fused_kernels_range():
     info = tr.learn_one_epoch()
     assert np.isfinite(info["loss_pi"]) and tr.fused_rollout is not True  # (no one-launch rollout for H != 2)
     small.close()
+
+
+# ---- one full update() of the reference's trainer, replayed (tests/golden/update.npz) ------------------------------------------
+class _ReplayEnv:
+    """Stands in for a DroneVecEnv where only the trainer's update is exercised (CPU test): one env, no stepping."""
+
+    def __init__(self, obs_dim, device):
+        self.num_envs, self.obs_dim, self.act_dim, self.device = 1, int(obs_dim), 4, torch.device(device)
+        self.env_id_base = 0
+
+    def reset(self):
+        return torch.zeros(1, self.obs_dim, device=self.device), {}
+
+
+def _replay_reference_updates(env, fused, rtol, atol):
+    """Two consecutive update()s of the reference's own PPO run (oracle/refgen/gen_golden_update.py: its rollouts, path ends,
+    bootstrap values and np.random.shuffle sequences recorded) through PPOTrainer.update(): GAE / value targets / discounted
+    returns against the reference Buffer's, Loss/Pi and Loss/Value before the update, and EVERY entry of the ActorCritic
+    state_dict (both networks, obs / return statistics, log_std) after each update -- Adam's state and the LambdaLR schedule
+    carry over from the first update into the second (algs/iwpg/iwpg.py:282-485, algs/ppo/ppo.py:22-40)."""
+    import phoenix_drone_simulation_amd.ppo as ppo
+    g = np.load(os.path.join(os.path.dirname(GOLD), "update.npz"))
+    T, D = int(g["steps"]), int(g["obs_dim"])
+    tr = ppo.PPOTrainer(env, rollout_len=T, epochs=int(g["epochs_total"]), gamma=float(g["gamma"]), lam=float(g["lam"]),
+                        clip_ratio=float(g["clip_ratio"]), pi_lr=float(g["pi_lr"]), vf_lr=float(g["vf_lr"]),
+                        train_pi_iterations=int(g["train_pi_iterations"]), train_v_iterations=int(g["train_v_iterations"]),
+                        num_mini_batches=int(g["num_mini_batches"]), seed=0, fused=fused, graph_rollout=False)
+    dev = env.device
+    with torch.no_grad():
+        for k, p_ in tr.ac.state_dict().items():
+            p_.copy_(torch.as_tensor(g["sd_init__" + k], device=dev))
+    for e in range(2):
+        d = gu.load_update_epoch(g, e, dev)
+        assert abs(tr.pi_opt.param_groups[0]["lr"] - float(g[f"e{e}_lr"])) < 1e-12
+        tr.ac.update(frac=e / tr.epochs)
+        assert torch.allclose(tr.ac.pi.log_std.cpu(), torch.as_tensor(g[f"e{e}_log_std"], dtype=torch.float32), rtol=0, atol=1e-7)
+        tr.obs_buf.copy_(d["obs"]); tr.act_buf.copy_(d["act"]); tr.rew_buf.copy_(d["rew"]); tr.val_buf.copy_(d["val"])
+        tr.logp_buf.copy_(d["logp"]); tr.term_buf.copy_(d["term"]); tr.trunc_buf.copy_(d["trunc"]); tr.fval_buf.copy_(d["fval"])
+        tr.last_val = d["last_val"]
+        # the Buffer's own outputs (algs/core.py:461-533): reward scaling by the running return std of the epoch before
+        scale = float(1.0 / (tr.ac.ret_oms.std.item() + tr.ac.ret_oms.eps))
+        adv, tv, dr = ppo.gae(tr.rew_buf, tr.val_buf, tr.term_buf, tr.trunc_buf, tr.fval_buf, tr.last_val, tr.gamma, tr.lam,
+                              scale, float(tr.ac.ret_oms.bound))
+        for got, want, what in ((adv, d["adv"], "adv"), (tv, d["target_v"], "target_v"), (dr, d["disc_ret"], "discounted_ret")):
+            gu.assert_close(got.reshape(-1).cpu().numpy(), want.cpu().numpy(), 2e-5, 2e-5, f"epoch {e} {what}")
+        shuffles = iter(d["shuffles"])
+        tr.perm_fn = lambda B: next(shuffles)
+        info = tr.update()
+        assert next(shuffles, None) is None  # every recorded shuffle was consumed: train_v_iterations of them
+        assert abs(info["loss_pi"] - float(g[f"e{e}_loss_pi"])) < 1e-4 * max(1.0, abs(float(g[f"e{e}_loss_pi"]))), (e, info)
+        assert abs(info["loss_v"] - float(g[f"e{e}_loss_v"])) < 1e-4 * max(1.0, abs(float(g[f"e{e}_loss_v"]))), (e, info)
+        for k, p_ in tr.ac.state_dict().items():
+            gu.assert_close(p_.detach().cpu().numpy(), g[f"e{e}_sd_after__" + k], rtol, atol, f"epoch {e} after update: {k}")
+        tr.scheduler.step()  # learn_one_epoch
+        tr.epoch += 1
+    return tr
+
+
+def test_two_reference_updates_replayed_through_the_torch_path_on_cpu(monkeypatch):
+    """PPOTrainer.update() (PyTorch-op path, CPU tensors, the GAE kernel restated with torch ops) against two recorded updates
+    of the reference's own trainer: same parameters after each to 1e-5 relative."""
+    import phoenix_drone_simulation_amd.ppo as ppo
+    monkeypatch.setattr(ppo, "gae", gu.gae_torch)
+    g = np.load(os.path.join(os.path.dirname(GOLD), "update.npz"))
+    _replay_reference_updates(_ReplayEnv(int(g["obs_dim"]), "cpu"), False, 1e-5, 1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [True, False])
+def test_two_reference_updates_replayed_on_the_gpu(fused):
+    """The same replay on the HIP device: pds_gae, the fused MFMA gradient kernels with the Adam step riding on them and the
+    value steps on the second stream (fused=True), or PyTorch ops on the device (fused=False)."""
+    import phoenix_drone_simulation_amd as pds
+    env = pds.make("DroneHoverSimpleEnv-v0", num_envs=1, seed=0)
+    tr = _replay_reference_updates(env, fused, 2e-4, 2e-6)
+    assert tr.fused is fused
+    env.close()
