@@ -97,8 +97,9 @@ def main():
         assert old["epochs"] == a.epochs and old["steps_per_epoch"] == a.steps_per_epoch and old["env_id"] == a.env
     out = dict(
         what="per-epoch log of the reference's ProximalPolicyOptimizationAlgorithm.learn() on its own env, one entry per "
-             "seed.  STATISTICAL SAMPLE, NOT BIT-REPRODUCIBLE: re-running a seed reproduces epoch 1 and diverges from the "
-             "first update on (same distribution, different trajectory); use it for two-sample tests only",
+             "seed.  STATISTICAL SAMPLE of the trainer's run distribution, not a known answer: use it for two-sample tests "
+             "only.  A run is a function of its seed since numpy is seeded before the env is built (the reference seeds it "
+             "after the env's constructor has drawn from it)",
         generator="oracle/refgen/gen_golden_learning.py", env_id=a.env, epochs=a.epochs, steps_per_epoch=a.steps_per_epoch,
         obs_dim=res[0]["obs_dim"], hyper=res[0]["hyper"], columns=COLUMNS,
         seeds=[r["seed"] for r in res], wall_s=[round(r["wall_s"], 1) for r in res],
