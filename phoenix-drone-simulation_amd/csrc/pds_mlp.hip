@@ -112,6 +112,9 @@ __host__ __device__ inline Offsets offsets(const pds_mlp &m) {
 #define PDS_FPRIO_MFMA() do { } while (0)
 #define PDS_FPRIO_VALU() do { } while (0)
 #endif
+#ifndef PDS_SPLIT_SIMD_ROLES
+#define PDS_SPLIT_SIMD_ROLES 0
+#endif
 #ifndef PDS_SPLIT_GPRIO
 #define PDS_SPLIT_GPRIO 0
 #endif
@@ -742,8 +745,17 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
   const pds_mlp &m = a.m;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // Which waves share a SIMD: w and w + 4 (profiles/r03_mlp_microbench.txt).  PDS_SPLIT_SIMD_ROLES = 0 (rounds 3-4): F_p = wave p,
+  // G_p = wave p + 4 -- every SIMD hosts one F and one G.  1: the two F waves of pairs (p, p + 2) on one SIMD and their G waves
+  // on another -- SIMDs 0, 1 run forward roles only, SIMDs 2, 3 weight-gradient roles only (NG == 1).  Same tiles per pair and the
+  // same reduction order by pair index: bit-identical results either way.
+#if PDS_SPLIT_SIMD_ROLES
+  const int pair = NG == 1 ? ((wave & 1) | ((wave >> 2) << 1)) : (wave & 3);
+  const int role = NG == 1 ? ((wave >> 1) & 1) : (wave >> 2);
+#else
   const int pair = wave & 3;
   const int role = wave >> 2;  // 0: F, 1: G (NG = 1) or G1, 2: G2
+#endif
   const int n = lane & 15, g = lane >> 4;
   stage_weights<kW1Rows, kThreads>(m, W1s, W2s, W3s, tid);
   if (tid < kMaxDim) {
