@@ -664,3 +664,54 @@ def test_two_reference_updates_replayed_on_the_gpu(fused):
     tr = _replay_reference_updates(env, fused, 2e-4, 2e-6)
     assert tr.fused is fused
     env.close()
+
+
+_GPU_DDP_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+import phoenix_drone_simulation_amd as pds
+from phoenix_drone_simulation_amd.ppo import PPOTrainer
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+env = pds.make_sharded("DroneHoverSimpleEnv-v0", 4096, rank=rank, world_size=world, device="cuda:0", seed=7)
+assert env.num_envs == 4096 // world and env.env_id_base == rank * (4096 // world)
+tr = PPOTrainer(env, rollout_len=16, epochs=4, train_pi_iterations=6, train_v_iterations=2, num_mini_batches=4, seed=7, fused=True)
+for _ in range(2):
+    info = tr.learn_one_epoch()
+torch.cuda.synchronize()
+# every rank holds the same parameters and the same running statistics after two epochs of averaged gradients
+flat = torch.cat([p.detach().reshape(-1).float().cpu() for p in tr.ac.state_dict().values()])
+both = [torch.zeros_like(flat) for _ in range(world)]
+dist.all_gather(both, flat)
+for r in range(world):
+    assert torch.equal(both[r], both[0]), (rank, r, float((both[r] - both[0]).abs().max()))
+assert bool(torch.isfinite(flat).all()) and info["episodes"] > 0
+assert info["total_env_steps"] == 2 * 16 * 4096  # the whole job's steps
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok", info["ep_len"])
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 8])
+def test_multi_rank_trainer_on_one_device_keeps_the_ranks_in_step(world, tmp_path):
+    """The trainer's multi-rank path with the FUSED kernels (one process per GPU; mpi_avg_grads / sync_params /
+    the MPI-averaged OnlineMeanStd of utils/mpi_tools.py:30-44, utils/online_mean_std.py:76-83): two / eight ranks, each with its
+    shard of the envs, all on cuda:0 with gloo as the collective backend (the 1-GPU stand-in for RCCL): parameter broadcast, one
+    flattened gradient all-reduce per optimiser step, all-reduced batch moments, the MAX-reduced non-finite guard -- after two
+    epochs every rank holds bit-identical parameters and statistics."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "worker.py"
+    script.write_text(_GPU_DDP_WORKER.format(root=root))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29670 + world), WORLD_SIZE=str(world),
+               HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o[-3000:]
+        assert f"rank {r} ok" in o
