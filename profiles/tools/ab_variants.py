@@ -44,7 +44,8 @@ def main():
     settings = []
     for lib in libs:
         settings.append((lib, {}))
-    settings.append((libs[-1] + " regen@agg>=2", {"PDS_STORED_OH_FROM_AGG": "0"}))
+    if os.environ.get("AB_STORED"):  # (builds with PDS_STORED_OH_FROM_AGG > 0 only)
+        settings.append((libs[-1] + " regen@agg>=2", {"PDS_STORED_OH_FROM_AGG": "0"}))
     N, steps = 1 << 20, 300
     for name, task, kw in CASES:
         for rep in range(2):
