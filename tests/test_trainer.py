@@ -522,8 +522,8 @@ def test_ppo_learning_curve_matches_the_reference_trainers_run_distribution():
     the round-4 offset to be sampling noise: the six reference seeds of round 4 average 89.2 steps in epochs 24-40, the 24 of
     this fixture 94.3 +- 2.6 (seed-to-seed SD 12.6; its own second dozen sits 7.6 above its first); HIP 1 x 32 000:
     93.3 +- 2.9 (-0.25 standard errors of the difference), HIP 8 x 4 000: 95.8 +- 2.4 (+0.45).  What the layout DOES change is
-    the first peak (epochs 9-16): 88.7 (reference) / 85.1 (1 env) / 82.4 (8 envs) / 71.2 (32 envs x 1 000 steps) -- every env's
-    episode is cut and bootstrapped at the rollout end -- which is why the pin runs the reference's layout.
+    the first peak (epochs 9-16): 88.7 (reference) / 85.1 (1 env) / 82.4 (8 envs) / 71.2 (32 envs x 1 000 steps) -- presumably
+    because every env's episode is cut and bootstrapped at the rollout end -- which is why the pin runs the reference's layout.
     The trainer is deterministic for fixed seeds (also side by side), so this test does not flake: it fails when the code
     changes the numbers."""
     ref, rcur = _reference_learning_curves()
