@@ -427,9 +427,9 @@ def test_fused_rollout_refuses_what_it_is_not_built_for_and_the_trainer_falls_ba
     env.close(); env2.close()
 
 
-def _reference_learning_curves():
+def _reference_learning_curves(name="learning_curve.json"):
     import json
-    ref = json.load(open(os.path.join(os.path.dirname(GOLD), "learning_curve.json")))
+    ref = json.load(open(os.path.join(os.path.dirname(GOLD), name)))
     seeds = [str(s_) for s_ in ref["seeds"]]
     return ref, {k: np.array([ref["curves"][s_][k] for s_ in seeds]) for k in ("EpRet/Mean", "EpLen/Mean")}
 
@@ -546,6 +546,22 @@ def test_ppo_learning_curve_matches_the_reference_trainers_run_distribution():
     # ... and it is the reference's curve: rise, dip while the noise anneals, rise
     ln = curves["EpLen/Mean"].mean(axis=0)
     assert ln[:3].mean() < 16 and ln[9:13].mean() > 70 and ln[17:21].mean() < ln[9:13].mean() - 4 and ln[35:].mean() > ln[17:21].mean() + 10
+
+
+@pytest.mark.gpu
+def test_ppo_learning_curve_on_circle_matches_the_reference_trainers_run_distribution():
+    """The same pin on the second task: DroneCircleSimpleEnv-v0 (other reward, termination and observation; env defaults), the
+    reference's own learn() for 12 seeds x 40 epochs x 32 000 steps (tests/golden/learning_curve_circle.json) against 8
+    PPOTrainer runs at the reference's layout, compared seed-wise like the Hover runs (p > 0.01 on the four phases and per
+    epoch, EpLen and EpRet)."""
+    ref, rcur = _reference_learning_curves("learning_curve_circle.json")
+    assert (ref["epochs"], ref["steps_per_epoch"], ref["env_id"]) == (40, 32000, "DroneCircleSimpleEnv-v0") and len(ref["seeds"]) >= 12
+    seeds = list(range(100, 108))
+    runs = _train_runs_side_by_side(ref["env_id"], seeds, 1, ref["steps_per_epoch"], ref["epochs"], {})
+    for key, col in (("EpRet/Mean", 0), ("EpLen/Mean", 1)):
+        mine = np.array([runs[s_][col] for s_ in seeds])
+        fails, report = gu.compare_learning_curves(mine, rcur[key])
+        assert not fails, (key, fails, report)
 
 
 @pytest.mark.gpu
