@@ -504,6 +504,19 @@ def _train_runs_side_by_side(env_id, seeds, num_envs, steps_per_epoch, epochs, k
     return out
 
 
+def test_circle_learning_curve_fixture_is_a_sample_of_the_reference():
+    """tests/golden/learning_curve_circle.json: 12 runs of the reference's learn() on DroneCircleSimpleEnv-v0 (same generator,
+    `--env`); halves of it pass the comparison against each other."""
+    ref, cur = _reference_learning_curves("learning_curve_circle.json")
+    n = len(ref["seeds"])
+    assert "STATISTICAL SAMPLE" in ref["what"] and n >= 12 and ref["obs_dim"] == 40
+    assert (ref["epochs"], ref["steps_per_epoch"], ref["env_id"]) == (40, 32000, "DroneCircleSimpleEnv-v0")
+    for key, x in cur.items():
+        fails, _ = gu.compare_learning_curves(x[: n // 2], x[n // 2:])
+        assert not fails, (key, fails)
+    assert cur["EpLen/Mean"][:, :3].mean() < 40 and cur["EpLen/Mean"][:, -3:].mean() > 150  # the task is learned
+
+
 @pytest.mark.gpu
 def test_ppo_learning_curve_matches_the_reference_trainers_run_distribution():
     """End-to-end pin of the caller ("Hover return vs epochs"): tests/golden/learning_curve.json holds the
