@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Sim-to-sim transfer check (build container only): two policies TRAINED ON THE HIP ENVS (tests/golden/hip_policy_{early,late}.npz,
+the reference's ActorCritic state_dict layout; profiles/tools/train_export_policies.py) are loaded into the REFERENCE's own
+`core.ActorCritic` (algs/core.py:313-412) and evaluated in the REFERENCE's own DroneHoverSimpleEnv-v0 (env defaults: sensor noise,
+thrust noise, 10 % domain randomisation, reset distribution) the way `EnvironmentEvaluator.eval_once` does (utils/evaluation.py:
+reset, act deterministically until terminated or truncated): per-episode length and return for EPISODES episodes each.
+Only data is written: tests/golden/policy_eval_stats.json.  tests/test_gpu_noise.py plays the same policies in the HIP envs.
+Stand-ins as for the other generators (pybullet*, gymnasium, mpi4py, tensorboard)."""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "standins"))
+sys.path.insert(0, "/root/reference")
+_tb = types.ModuleType("torch.utils.tensorboard")
+_tb.SummaryWriter = object
+sys.modules["torch.utils.tensorboard"] = _tb
+
+import gymnasium as gym  # noqa: E402  (stand-in)
+import phoenix_drone_simulation  # noqa: E402,F401
+import phoenix_drone_simulation.algs.core as core  # noqa: E402
+
+ENV_ID, EPISODES = "DroneHoverSimpleEnv-v0", {"early": 5000, "late": 600}
+GOLD = os.path.join(HERE, "..", "..", "tests", "golden")
+
+
+def main():
+    torch.set_num_threads(1)
+    out = dict(what="per-episode length / return of two HIP-trained policies played deterministically in the reference's own "
+                    "DroneHoverSimpleEnv-v0 (env defaults); a statistical sample, reproducible (numpy seeded before the env is built)",
+               generator="oracle/refgen/gen_golden_policy_stats.py", env_id=ENV_ID)
+    for name, episodes in EPISODES.items():
+        np.random.seed(4321)
+        env = gym.make(ENV_ID)
+        ac = core.ActorCritic('mlp', env.observation_space, env.action_space, use_standardized_obs=True, use_scaled_rewards=True,
+                              use_shared_weights=False,
+                              ac_kwargs={'pi': {'hidden_sizes': (50, 50), 'activation': 'relu'},
+                                         'val': {'hidden_sizes': (64, 64), 'activation': 'tanh'}})
+        sd = np.load(os.path.join(GOLD, f"hip_policy_{name}.npz"))
+        ac.load_state_dict({k: torch.as_tensor(sd[k]) for k in sd.files}, strict=True)
+        ac.eval()  # EnvironmentEvaluator: no exploration noise
+        lens, rets, terms = [], [], []
+        for ep in range(episodes):
+            o, _ = env.reset()
+            n, ret, term = 0, 0.0, False
+            while True:
+                a, _, _ = ac.step(torch.as_tensor(o, dtype=torch.float32))
+                o, r, te, tr, _ = env.step(a)
+                n += 1; ret += float(r)
+                if te or tr or n >= 500:
+                    term = bool(te)
+                    break
+            lens.append(n); rets.append(ret); terms.append(term)
+        out[name] = dict(episodes=episodes, ep_len=lens, ep_ret=[round(x, 4) for x in rets], terminated=[int(t) for t in terms])
+        print(name, "len", np.mean(lens), "+-", np.std(lens) / np.sqrt(episodes), "ret", np.mean(rets), "terminated", np.mean(terms))
+    with open(os.path.join(GOLD, "policy_eval_stats.json"), "w") as f:
+        json.dump(out, f)
+    print("wrote policy_eval_stats.json")
+
+
+if __name__ == "__main__":
+    main()

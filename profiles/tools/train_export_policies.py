@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Train PPO on the HIP Hover envs (reference default config) and export two checkpoints in the reference's state_dict layout
+(tests/golden/hip_policy_{early,late}.npz): an early policy whose episodes still end by termination (sensitive to the
+env's dynamics and noise) and a late one that hovers to the TimeLimit.  oracle/refgen/gen_golden_policy_stats.py evaluates
+both in the REFERENCE's envs; tests/test_gpu_noise.py evaluates them in the HIP envs.  Deterministic for the fixed seed.
+usage (GPU box): python profiles/tools/train_export_policies.py gpurun_out/"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import phoenix_drone_simulation_amd as pds  # noqa: E402
+from phoenix_drone_simulation_amd.ppo import PPOTrainer  # noqa: E402
+
+
+def main():
+    out = sys.argv[1] if len(sys.argv) > 1 else "."
+    env = pds.make("DroneHoverSimpleEnv-v0", num_envs=8192, seed=11)
+    tr = PPOTrainer(env, rollout_len=64, epochs=200, seed=11)
+    for e in range(200):
+        info = tr.learn_one_epoch()
+        if e + 1 in (14, 200):
+            name = "early" if e + 1 == 14 else "late"
+            sd = {k: v.detach().cpu().numpy() for k, v in tr.ac.state_dict().items()}
+            np.savez_compressed(os.path.join(out, f"hip_policy_{name}.npz"), **sd)
+            print(f"epoch {e + 1}: ep_len {info['ep_len']:.1f} ep_ret {info['ep_ret']:.1f} noise {info['noise_std']:.3f} -> hip_policy_{name}.npz")
+    torch.cuda.synchronize()
+    env.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -290,3 +290,38 @@ def test_step_noise_normals_against_the_normal_distribution():
         assert lib.pds_noise_normals(*args, n, C.c_void_p(z2.data_ptr()), None) == 0
         assert abs(float((z * z2).double().mean())) < 5 / np.sqrt(m)
     assert abs(float((z[:-1] * z[1:]).double().mean())) < 5 / np.sqrt(m)
+
+
+@pytest.mark.parametrize("name", ["early", "late"])
+def test_hip_trained_policies_fly_the_same_in_the_reference_envs(name):
+    """Sim-to-sim transfer, the drop-in claim end to end: two policies trained by PPOTrainer ON THE HIP ENVS
+    (tests/golden/hip_policy_{early,late}.npz, profiles/tools/train_export_policies.py: after 14 epochs -- every episode still
+    ends by termination -- and after 200 -- hovers to the TimeLimit) were loaded into the REFERENCE's ActorCritic and played
+    deterministically in the REFERENCE's own stochastic DroneHoverSimpleEnv-v0 (oracle/refgen/gen_golden_policy_stats.py:
+    5 000 / 600 episodes, EnvironmentEvaluator's loop, utils/evaluation.py:15-117).  The same policies in the HIP envs under
+    Philox (evaluation.evaluate, 8 192 episodes): episode length and return have the same distribution -- Welch's t-test
+    p > 0.01 on both, the same spread, the same share of terminated episodes (measured: 133.36 +- 0.62 vs 133.08 +- 0.49 steps and
+    491.7 +- 2.6 vs 492.9 +- 0.7; profiles/r05_policy_transfer.txt)."""
+    import json
+    import os
+    from scipy import stats
+    import phoenix_drone_simulation_amd as pds
+    from phoenix_drone_simulation_amd.evaluation import evaluate
+    from phoenix_drone_simulation_amd.ppo import ActorCritic
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    ref = json.load(open(os.path.join(gold, "policy_eval_stats.json")))[name]
+    sd = np.load(os.path.join(gold, f"hip_policy_{name}.npz"))
+    env = pds.make("DroneHoverSimpleEnv-v0", num_envs=8192, seed=5)
+    ac = ActorCritic.from_reference_state_dict({k: sd[k] for k in sd.files}).to(env.device)
+    ret, length, _ = evaluate(env, ac)
+    ret, length = ret.numpy().astype(np.float64), length.numpy().astype(np.float64)
+    rl, rr = np.array(ref["ep_len"], dtype=np.float64), np.array(ref["ep_ret"], dtype=np.float64)
+    for mine, theirs, what in ((length, rl, "episode length"), (ret, rr, "episode return")):
+        t, p = stats.ttest_ind(mine, theirs, equal_var=False)
+        assert p > 0.01, (name, what, mine.mean(), theirs.mean(), t, p)
+        assert 0.8 < mine.std() / max(theirs.std(), 1e-9) < 1.25, (name, what, mine.std(), theirs.std())
+    term_ref = float(np.mean(ref["terminated"]))
+    term_mine = float((length < env._max_episode_steps).mean())
+    se = np.sqrt(max(term_ref * (1 - term_ref), 1e-4) / len(rl))
+    assert abs(term_mine - term_ref) < 4 * se + 1e-3, (name, term_mine, term_ref)
+    env.close()
