@@ -58,6 +58,33 @@ def main():
             lens.append(n); rets.append(ret); terms.append(term)
         out[name] = dict(episodes=episodes, ep_len=lens, ep_ret=[round(x, 4) for x in rets], terminated=[int(t) for t in terms])
         print(name, "len", np.mean(lens), "+-", np.std(lens) / np.sqrt(episodes), "ret", np.mean(rets), "terminated", np.mean(terms))
+    # ---- the other direction: a policy trained BY THE REFERENCE (exp-07 control_mode PWM, 2 physics sub-steps per step,
+    # experiments/07_control_structure_hypothesis/run_control_structures.py:53-61; bundled JSON, tests/golden/
+    # policy_PWM_seed_00000_model.json) loaded with the reference's own utils.load_network_json and flown in the reference's
+    # stochastic DroneCircleSimpleEnv-v0 at that experiment's env settings
+    from phoenix_drone_simulation.utils import utils
+    fix = os.path.join(GOLD, "policy_PWM_seed_00000_model.json")
+    net = utils.load_network_json(fix)
+    sp = np.array(json.load(open(fix))["scaling_parameters"])
+    mean, std = torch.as_tensor(sp[0], dtype=torch.float32), torch.as_tensor(sp[1], dtype=torch.float32)
+    kw = dict(aggregate_phy_steps=2, domain_randomization=0.10, observation_noise=1, motor_thrust_noise=0.05)
+    np.random.seed(4321)
+    env = gym.make("DroneCircleSimpleEnv-v0", **kw)
+    episodes, lens, rets, terms = 400, [], [], []
+    for ep in range(episodes):
+        o, _ = env.reset()
+        n, ret = 0, 0.0
+        while True:
+            with torch.no_grad():
+                a = net((torch.as_tensor(o, dtype=torch.float32) - mean) / (std + 1e-5)).numpy()  # utils/export.py:88-92 scaling
+            o, r, te, tr, _ = env.step(a)
+            n += 1; ret += float(r)
+            if te or tr or n >= 500:
+                break
+        lens.append(n); rets.append(ret); terms.append(bool(te))
+    out["circle_reference_policy"] = dict(episodes=episodes, env_id="DroneCircleSimpleEnv-v0", env_kwargs=kw, ep_len=lens,
+                                          ep_ret=[round(x, 4) for x in rets], terminated=[int(t) for t in terms])
+    print("circle reference policy: len", np.mean(lens), "ret", np.mean(rets), "+-", np.std(rets) / np.sqrt(episodes), "terminated", np.mean(terms))
     with open(os.path.join(GOLD, "policy_eval_stats.json"), "w") as f:
         json.dump(out, f)
     print("wrote policy_eval_stats.json")

@@ -19,3 +19,14 @@ for name in ("early", "late"):
         print(f"{name:5s} {what:15s}: reference {theirs.mean():9.2f} +- {theirs.std()/np.sqrt(len(theirs)):5.2f} (SD {theirs.std():6.2f}, {len(theirs)} episodes) | HIP {mine.mean():9.2f} +- {mine.std()/np.sqrt(len(mine)):5.2f} (SD {mine.std():6.2f}) | Welch t {t:+.2f} p {p:.3f}")
     print(f"{name:5s} terminated share: reference {np.mean(ref[name]['terminated']):.4f} | HIP {(length < 500).mean():.4f}")
     env.close()
+from phoenix_drone_simulation_amd.policy_io import load_network_json
+r = ref["circle_reference_policy"]
+env = pds.make(r["env_id"], num_envs=4096, seed=6, **r["env_kwargs"])
+pol = load_network_json('tests/golden/policy_PWM_seed_00000_model.json').to(env.device)
+ret, length, _ = evaluate(env, pol)
+ret, length = ret.numpy().astype(float), length.numpy().astype(float)
+print("# a policy trained BY THE REFERENCE (exp-07 PWM, bundled JSON) in DroneCircleSimpleEnv-v0 at that experiment's settings (2 sub-steps, noise, 10 % DR):")
+for mine, theirs, what in ((length, np.array(r["ep_len"], float), "episode length"), (ret, np.array(r["ep_ret"], float), "episode return")):
+    t, p = stats.ttest_ind(mine, theirs, equal_var=False)
+    print(f"circle {what:15s}: reference {theirs.mean():9.2f} +- {theirs.std()/np.sqrt(len(theirs)):5.2f} (SD {theirs.std():6.2f}, {len(theirs)} episodes) | HIP {mine.mean():9.2f} +- {mine.std()/np.sqrt(len(mine)):5.2f} (SD {mine.std():6.2f}) | Welch t {t:+.2f} p {p:.3f}")
+print(f"circle terminated share: reference {np.mean(r['terminated']):.4f} | HIP {(length < 500).mean():.4f}")

@@ -325,3 +325,29 @@ def test_hip_trained_policies_fly_the_same_in_the_reference_envs(name):
     se = np.sqrt(max(term_ref * (1 - term_ref), 1e-4) / len(rl))
     assert abs(term_mine - term_ref) < 4 * se + 1e-3, (name, term_mine, term_ref)
     env.close()
+
+
+def test_reference_trained_policy_flies_the_same_in_the_hip_envs():
+    """The other direction of the transfer: a policy trained BY THE REFERENCE (exp-07, control_mode PWM, the bundled
+    tests/golden/policy_PWM_seed_00000_model.json) flown in the reference's stochastic DroneCircleSimpleEnv-v0 at that
+    experiment's env settings (2 physics sub-steps, 10 % domain randomisation, sensor and thrust noise; 400 episodes through
+    the reference's own utils.load_network_json, oracle/refgen/gen_golden_policy_stats.py) and in the HIP envs under Philox
+    (4 096 episodes through policy_io.load_network_json): same distribution of episode return and length."""
+    import json
+    import os
+    from scipy import stats
+    import phoenix_drone_simulation_amd as pds
+    from phoenix_drone_simulation_amd.evaluation import evaluate
+    from phoenix_drone_simulation_amd.policy_io import load_network_json
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    ref = json.load(open(os.path.join(gold, "policy_eval_stats.json")))["circle_reference_policy"]
+    env = pds.make(ref["env_id"], num_envs=4096, seed=6, **ref["env_kwargs"])
+    pol = load_network_json(os.path.join(gold, "policy_PWM_seed_00000_model.json")).to(env.device)
+    ret, length, _ = evaluate(env, pol)
+    ret, length = ret.numpy().astype(np.float64), length.numpy().astype(np.float64)
+    rl, rr = np.array(ref["ep_len"], dtype=np.float64), np.array(ref["ep_ret"], dtype=np.float64)
+    t, p = stats.ttest_ind(ret, rr, equal_var=False)
+    assert p > 0.01, ("episode return", ret.mean(), rr.mean(), t, p)
+    assert 0.8 < ret.std() / max(rr.std(), 1e-9) < 1.25, (ret.std(), rr.std())
+    assert abs(length.mean() - rl.mean()) < 4 * np.sqrt(rl.var() / len(rl) + length.var() / len(length)) + 0.5, (length.mean(), rl.mean())
+    env.close()
