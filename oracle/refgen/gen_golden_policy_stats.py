@@ -34,7 +34,13 @@ def main():
     out = dict(what="per-episode length / return of two HIP-trained policies played deterministically in the reference's own "
                     "DroneHoverSimpleEnv-v0 (env defaults); a statistical sample, reproducible (numpy seeded before the env is built)",
                generator="oracle/refgen/gen_golden_policy_stats.py", env_id=ENV_ID)
+    path = os.path.join(GOLD, "policy_eval_stats.json")
+    only = os.environ.get("PO_ONLY")  # regenerate one part, keep the others from the existing file (they are deterministic)
+    if only and os.path.exists(path):
+        out.update({k: v for k, v in json.load(open(path)).items() if k in ("early", "late", "circle_reference_policy")})
     for name, episodes in EPISODES.items():
+        if only and only != "hover":
+            continue
         np.random.seed(4321)
         env = gym.make(ENV_ID)
         ac = core.ActorCritic('mlp', env.observation_space, env.action_space, use_standardized_obs=True, use_scaled_rewards=True,
@@ -62,6 +68,10 @@ def main():
     # experiments/07_control_structure_hypothesis/run_control_structures.py:53-61; bundled JSON, tests/golden/
     # policy_PWM_seed_00000_model.json) loaded with the reference's own utils.load_network_json and flown in the reference's
     # stochastic DroneCircleSimpleEnv-v0 at that experiment's env settings
+    if only and only != "circle":
+        with open(path, "w") as f:
+            json.dump(out, f)
+        return
     from phoenix_drone_simulation.utils import utils
     fix = os.path.join(GOLD, "policy_PWM_seed_00000_model.json")
     net = utils.load_network_json(fix)
@@ -70,7 +80,7 @@ def main():
     kw = dict(aggregate_phy_steps=2, domain_randomization=0.10, observation_noise=1, motor_thrust_noise=0.05)
     np.random.seed(4321)
     env = gym.make("DroneCircleSimpleEnv-v0", **kw)
-    episodes, lens, rets, terms = 400, [], [], []
+    episodes, lens, rets, terms = 2400, [], [], []
     for ep in range(episodes):
         o, _ = env.reset()
         n, ret = 0, 0.0

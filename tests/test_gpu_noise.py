@@ -330,7 +330,7 @@ def test_hip_trained_policies_fly_the_same_in_the_reference_envs(name):
 def test_reference_trained_policy_flies_the_same_in_the_hip_envs():
     """The other direction of the transfer: a policy trained BY THE REFERENCE (exp-07, control_mode PWM, the bundled
     tests/golden/policy_PWM_seed_00000_model.json) flown in the reference's stochastic DroneCircleSimpleEnv-v0 at that
-    experiment's env settings (2 physics sub-steps, 10 % domain randomisation, sensor and thrust noise; 400 episodes through
+    experiment's env settings (2 physics sub-steps, 10 % domain randomisation, sensor and thrust noise; 2 400 episodes through
     the reference's own utils.load_network_json, oracle/refgen/gen_golden_policy_stats.py) and in the HIP envs under Philox
     (4 096 episodes through policy_io.load_network_json): same distribution of episode return and length."""
     import json
