@@ -29,6 +29,32 @@ ENV_ID, EPISODES = "DroneHoverSimpleEnv-v0", {"early": 5000, "late": 600}
 GOLD = os.path.join(HERE, "..", "..", "tests", "golden")
 
 
+def _circle_reference_policy(out):
+    from phoenix_drone_simulation.utils import utils
+    fix = os.path.join(GOLD, "policy_PWM_seed_00000_model.json")
+    net = utils.load_network_json(fix)
+    sp = np.array(json.load(open(fix))["scaling_parameters"])
+    mean, std = torch.as_tensor(sp[0], dtype=torch.float32), torch.as_tensor(sp[1], dtype=torch.float32)
+    kw = dict(aggregate_phy_steps=2, domain_randomization=0.10, observation_noise=1, motor_thrust_noise=0.05)
+    np.random.seed(4321)
+    env = gym.make("DroneCircleSimpleEnv-v0", **kw)
+    episodes, lens, rets, terms = 2400, [], [], []
+    for ep in range(episodes):
+        o, _ = env.reset()
+        n, ret = 0, 0.0
+        while True:
+            with torch.no_grad():
+                a = net((torch.as_tensor(o, dtype=torch.float32) - mean) / (std + 1e-5)).numpy()  # utils/export.py:88-92 scaling
+            o, r, te, tr, _ = env.step(a)
+            n += 1; ret += float(r)
+            if te or tr or n >= 500:
+                break
+        lens.append(n); rets.append(ret); terms.append(bool(te))
+    out["circle_reference_policy"] = dict(episodes=episodes, env_id="DroneCircleSimpleEnv-v0", env_kwargs=kw, ep_len=lens,
+                                          ep_ret=[round(x, 4) for x in rets], terminated=[int(t) for t in terms])
+    print("circle reference policy: len", np.mean(lens), "ret", np.mean(rets), "+-", np.std(rets) / np.sqrt(episodes), "terminated", np.mean(terms))
+
+
 def main():
     torch.set_num_threads(1)
     out = dict(what="per-episode length / return of two HIP-trained policies played deterministically in the reference's own "
@@ -37,7 +63,7 @@ def main():
     path = os.path.join(GOLD, "policy_eval_stats.json")
     only = os.environ.get("PO_ONLY")  # regenerate one part, keep the others from the existing file (they are deterministic)
     if only and os.path.exists(path):
-        out.update({k: v for k, v in json.load(open(path)).items() if k in ("early", "late", "circle_reference_policy")})
+        out.update({k: v for k, v in json.load(open(path)).items() if k in ("early", "late", "circle_reference_policy", "circle_attrate")})
     for name, episodes in EPISODES.items():
         if only and only != "hover":
             continue
@@ -68,33 +94,35 @@ def main():
     # experiments/07_control_structure_hypothesis/run_control_structures.py:53-61; bundled JSON, tests/golden/
     # policy_PWM_seed_00000_model.json) loaded with the reference's own utils.load_network_json and flown in the reference's
     # stochastic DroneCircleSimpleEnv-v0 at that experiment's env settings
-    if only and only != "circle":
-        with open(path, "w") as f:
-            json.dump(out, f)
-        return
-    from phoenix_drone_simulation.utils import utils
-    fix = os.path.join(GOLD, "policy_PWM_seed_00000_model.json")
-    net = utils.load_network_json(fix)
-    sp = np.array(json.load(open(fix))["scaling_parameters"])
-    mean, std = torch.as_tensor(sp[0], dtype=torch.float32), torch.as_tensor(sp[1], dtype=torch.float32)
-    kw = dict(aggregate_phy_steps=2, domain_randomization=0.10, observation_noise=1, motor_thrust_noise=0.05)
-    np.random.seed(4321)
-    env = gym.make("DroneCircleSimpleEnv-v0", **kw)
-    episodes, lens, rets, terms = 2400, [], [], []
-    for ep in range(episodes):
-        o, _ = env.reset()
-        n, ret = 0, 0.0
-        while True:
-            with torch.no_grad():
-                a = net((torch.as_tensor(o, dtype=torch.float32) - mean) / (std + 1e-5)).numpy()  # utils/export.py:88-92 scaling
-            o, r, te, tr, _ = env.step(a)
-            n += 1; ret += float(r)
-            if te or tr or n >= 500:
-                break
-        lens.append(n); rets.append(ret); terms.append(bool(te))
-    out["circle_reference_policy"] = dict(episodes=episodes, env_id="DroneCircleSimpleEnv-v0", env_kwargs=kw, ep_len=lens,
-                                          ep_ret=[round(x, 4) for x in rets], terminated=[int(t) for t in terms])
-    print("circle reference policy: len", np.mean(lens), "ret", np.mean(rets), "+-", np.std(rets) / np.sqrt(episodes), "terminated", np.mean(terms))
+    if not only or only == "circle":
+        _circle_reference_policy(out)
+    if not only or only == "circle_attrate":
+        # ---- a HIP-trained policy on exp-07's AttitudeRate configuration (PID rate controller under the policy, 4 physics
+        # sub-steps per step: envs/control.py:120-287, run_control_structures.py:53-61) in the reference's Circle env
+        kw = dict(control_mode="AttitudeRate", aggregate_phy_steps=4)
+        np.random.seed(4321)
+        env = gym.make("DroneCircleSimpleEnv-v0", **kw)
+        ac = core.ActorCritic('mlp', env.observation_space, env.action_space, use_standardized_obs=True, use_scaled_rewards=True,
+                              use_shared_weights=False,
+                              ac_kwargs={'pi': {'hidden_sizes': (50, 50), 'activation': 'relu'},
+                                         'val': {'hidden_sizes': (64, 64), 'activation': 'tanh'}})
+        sd = np.load(os.path.join(GOLD, "hip_policy_circle_attrate_late.npz"))
+        ac.load_state_dict({k: torch.as_tensor(sd[k]) for k in sd.files}, strict=True)
+        ac.eval()
+        episodes, lens, rets, terms = 800, [], [], []
+        for ep in range(episodes):
+            o, _ = env.reset()
+            n, ret = 0, 0.0
+            while True:
+                a, _, _ = ac.step(torch.as_tensor(o, dtype=torch.float32))
+                o, r, te, tr, _ = env.step(a)
+                n += 1; ret += float(r)
+                if te or tr or n >= 500:
+                    break
+            lens.append(n); rets.append(ret); terms.append(bool(te))
+        out["circle_attrate"] = dict(episodes=episodes, env_id="DroneCircleSimpleEnv-v0", env_kwargs=kw, ep_len=lens,
+                                     ep_ret=[round(x, 4) for x in rets], terminated=[int(t) for t in terms])
+        print("circle AttitudeRate HIP policy: len", np.mean(lens), "ret", np.mean(rets), "+-", np.std(rets) / np.sqrt(episodes), "terminated", np.mean(terms))
     with open(os.path.join(GOLD, "policy_eval_stats.json"), "w") as f:
         json.dump(out, f)
     print("wrote policy_eval_stats.json")

@@ -7,17 +7,19 @@ from phoenix_drone_simulation_amd.ppo import ActorCritic
 ref = json.load(open('tests/golden/policy_eval_stats.json'))
 print("# HIP-trained policies (tests/golden/hip_policy_{early,late}.npz) played deterministically: the REFERENCE's DroneHoverSimpleEnv-v0 (CPU, numpy randomness;")
 print("# oracle/refgen/gen_golden_policy_stats.py) vs the HIP envs (Philox, 8 192 episodes); env defaults (sensor + thrust noise, 10 % DR, reset distribution)")
-for name in ("early", "late"):
-    sd = np.load(f'tests/golden/hip_policy_{name}.npz')
-    env = pds.make("DroneHoverSimpleEnv-v0", num_envs=8192, seed=5)
+for name in ("early", "late", "circle_attrate"):
+    sd = np.load('tests/golden/hip_policy_circle_attrate_late.npz' if name == "circle_attrate" else f'tests/golden/hip_policy_{name}.npz')
+    env = pds.make(ref[name].get("env_id", "DroneHoverSimpleEnv-v0"), num_envs=8192, seed=5, **ref[name].get("env_kwargs", {}))
     ac = ActorCritic.from_reference_state_dict({k: sd[k] for k in sd.files}).to(env.device)
     ret, length, _ = evaluate(env, ac)
     ret, length = ret.numpy().astype(float), length.numpy().astype(float)
     rl, rr = np.array(ref[name]["ep_len"], float), np.array(ref[name]["ep_ret"], float)
     for mine, theirs, what in ((length, rl, "episode length"), (ret, rr, "episode return")):
         t, p = stats.ttest_ind(mine, theirs, equal_var=False)
-        print(f"{name:5s} {what:15s}: reference {theirs.mean():9.2f} +- {theirs.std()/np.sqrt(len(theirs)):5.2f} (SD {theirs.std():6.2f}, {len(theirs)} episodes) | HIP {mine.mean():9.2f} +- {mine.std()/np.sqrt(len(mine)):5.2f} (SD {mine.std():6.2f}) | Welch t {t:+.2f} p {p:.3f}")
+        print(f"{name:14s} {what:15s}: reference {theirs.mean():9.2f} +- {theirs.std()/np.sqrt(len(theirs)):5.2f} (SD {theirs.std():6.2f}, {len(theirs)} episodes) | HIP {mine.mean():9.2f} +- {mine.std()/np.sqrt(len(mine)):5.2f} (SD {mine.std():6.2f}) | Welch t {t:+.2f} p {p:.3f}")
     print(f"{name:5s} terminated share: reference {np.mean(ref[name]['terminated']):.4f} | HIP {(length < 500).mean():.4f}")
+    if name == "late":
+        print("# a HIP-trained policy on exp-07's AttitudeRate configuration (PID rate loop under the policy, 4 sub-steps per step), Circle task:")
     env.close()
 from phoenix_drone_simulation_amd.policy_io import load_network_json
 r = ref["circle_reference_policy"]

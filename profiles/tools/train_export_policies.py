@@ -29,6 +29,19 @@ def main():
             print(f"epoch {e + 1}: ep_len {info['ep_len']:.1f} ep_ret {info['ep_ret']:.1f} noise {info['noise_std']:.3f} -> hip_policy_{name}.npz")
     torch.cuda.synchronize()
     env.close()
+    # exp-07's AttitudeRate configuration (run_control_structures.py:53-61: 4 physics sub-steps per step) on the Circle task
+    kw = dict(control_mode="AttitudeRate", aggregate_phy_steps=4)
+    env = pds.make("DroneCircleSimpleEnv-v0", num_envs=8192, seed=12, **kw)
+    tr = PPOTrainer(env, rollout_len=64, epochs=120, seed=12)
+    for e in range(120):
+        info = tr.learn_one_epoch()
+        if e + 1 in (30, 120):
+            name = "circle_attrate_mid" if e + 1 == 30 else "circle_attrate_late"
+            sd = {k: v.detach().cpu().numpy() for k, v in tr.ac.state_dict().items()}
+            np.savez_compressed(os.path.join(out, f"hip_policy_{name}.npz"), **sd)
+            print(f"epoch {e + 1}: ep_len {info['ep_len']:.1f} ep_ret {info['ep_ret']:.1f} noise {info['noise_std']:.3f} -> hip_policy_{name}.npz")
+    torch.cuda.synchronize()
+    env.close()
 
 
 if __name__ == "__main__":
