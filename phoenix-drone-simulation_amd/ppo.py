@@ -646,3 +646,47 @@ class PPOTrainer:
             if verbose:
                 print({k: (round(v, 4) if isinstance(v, float) else v) for k, v in info.items()})
         return self.ac, self.env
+
+
+def train_runs_side_by_side(env_id, seeds, num_envs, rollout_len, epochs, threads=8, env_kwargs=None, trainer_kwargs=None):
+    """Independent PPO runs for `seeds` on ONE GPU, `threads` of them at a time (one Python thread and one HIP stream per run) --
+    the role of the reference's Benchmark loop over `num_runs` seeds, which spreads them over MPI cores (benchmark.py:60-130).
+    A run at the reference's layout (one env, 32 000 steps per epoch) keeps one of the 256 CUs busy, so runs overlap almost for
+    free: 12.4 s -> 1.9 s per 40-epoch run with 8 threads -- PROVIDED the HIP runtime has enough hardware queues: export
+    GPU_MAX_HW_QUEUES=16 before the process first touches the GPU (the default of 4 serialises streams that share a queue:
+    5.2 s per run).  Results are bit-identical to running the seeds one after the other (every random draw is keyed by the run's
+    seed; only the construction of a trainer is serialised, because torch.manual_seed and the networks' initialisation use
+    torch's global generator).  -> {seed: PPOTrainer.log (list of per-epoch dicts)}"""
+    import threading
+    from .envs import make
+    env_kwargs, trainer_kwargs = dict(env_kwargs or {}), dict(trainer_kwargs or {})
+    build, pick = threading.Lock(), threading.Lock()
+    pending, logs, errors = list(seeds), {}, []
+
+    def worker():
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                while True:
+                    with pick:
+                        if not pending or errors:
+                            return
+                        seed = pending.pop(0)
+                    with build:
+                        env = make(env_id, num_envs=num_envs, seed=seed, **env_kwargs)
+                        tr = PPOTrainer(env, rollout_len=rollout_len, epochs=epochs, seed=seed, **trainer_kwargs)
+                        torch.cuda.current_stream().synchronize()
+                    tr.learn()
+                    torch.cuda.current_stream().synchronize()
+                    logs[seed] = tr.log
+                    env.close()
+        except BaseException as e:  # noqa: BLE001  (re-raised in the caller's thread)
+            errors.append(e)
+
+    ts = [threading.Thread(target=worker) for _ in range(max(1, min(int(threads), len(pending))))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    if errors:
+        raise errors[0]
+    return logs

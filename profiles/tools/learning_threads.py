@@ -7,7 +7,6 @@ usage: GPU_MAX_HW_QUEUES=16 python profiles/tools/learning_threads.py [--seeds 8
 import argparse
 import os
 import sys
-import threading
 import time
 
 import numpy as np
@@ -16,22 +15,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 
-BUILD = threading.Lock()  # torch.manual_seed + the networks' initialisation use torch's GLOBAL generator
-
-
-def run(seed, num_envs, out, epochs=40, spe=32000, env_id="DroneHoverSimpleEnv-v0"):
-    import torch
-    import phoenix_drone_simulation_amd as pds
-    from phoenix_drone_simulation_amd.ppo import PPOTrainer
-    with torch.cuda.stream(torch.cuda.Stream()):
-        with BUILD:
-            env = pds.make(env_id, num_envs=num_envs, seed=seed)
-            tr = PPOTrainer(env, rollout_len=spe // num_envs, epochs=epochs, seed=seed, reset_each_rollout=True)
-            torch.cuda.current_stream().synchronize()
-        tr.learn()
-        torch.cuda.current_stream().synchronize()
-        out[seed] = (np.array([r["ep_len"] for r in tr.log]), np.array([r["ep_ret"] for r in tr.log]))
-        env.close()
+def run_all(seeds, num_envs, threads, env_id, epochs=40, spe=32000):
+    """-> {seed: (EpLen/Mean [epochs], EpRet/Mean [epochs])} through ppo.train_runs_side_by_side"""
+    from phoenix_drone_simulation_amd.ppo import train_runs_side_by_side
+    logs = train_runs_side_by_side(env_id, seeds, num_envs, spe // num_envs, epochs, threads=threads,
+                                   trainer_kwargs=dict(reset_each_rollout=True))
+    return {s: (np.array([r["ep_len"] for r in logs[s]]), np.array([r["ep_ret"] for r in logs[s]])) for s in seeds}
 
 
 def main():
@@ -49,22 +38,8 @@ def main():
     from phoenix_drone_simulation_amd.ppo import PPOTrainer  # noqa: F401
     torch.cuda.init()
     seeds = list(range(a.first_seed, a.first_seed + a.seeds))
-    out = {}
     t0 = time.time()
-    pending = list(seeds)
-    lock = threading.Lock()
-
-    def worker():
-        while True:
-            with lock:
-                if not pending:
-                    return
-                s = pending.pop(0)
-            run(s, a.envs, out, env_id=a.env_id)
-
-    ts = [threading.Thread(target=worker) for _ in range(a.threads)]
-    [t.start() for t in ts]
-    [t.join() for t in ts]
+    out = run_all(seeds, a.envs, a.threads, a.env_id)
     dt = time.time() - t0
     print(f"{a.seeds} seeds x {a.envs} envs in {a.threads} threads: {dt:.1f} s = {dt / a.seeds:.1f} s per seed")
     if a.out:
@@ -72,10 +47,8 @@ def main():
         json.dump({str(s): [out[s][0].tolist(), out[s][1].tolist()] for s in seeds}, open(a.out, "w"))
     if a.no_check:
         return
-    seq = {}
     t0 = time.time()
-    for s in seeds[:2]:
-        run(s, a.envs, seq, env_id=a.env_id)
+    seq = run_all(seeds[:2], a.envs, 1, a.env_id)
     print(f"sequential: {(time.time() - t0) / 2:.1f} s per seed; identical to the threaded runs: "
           f"{all(np.array_equal(seq[s][0], out[s][0]) and np.array_equal(seq[s][1], out[s][1]) for s in seeds[:2])}")
     print("late EpLen per seed", [round(float(out[s][0][23:].mean()), 1) for s in seeds])
