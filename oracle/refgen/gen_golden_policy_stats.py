@@ -29,6 +29,41 @@ ENV_ID, EPISODES = "DroneHoverSimpleEnv-v0", {"early": 5000, "late": 600}
 GOLD = os.path.join(HERE, "..", "..", "tests", "golden")
 
 
+def _eval_actor_critic(args):
+    """(numpy seed, episodes, env id, env kwargs, checkpoint file) -> (lengths, returns, terminated): one env instance, the
+    policy played deterministically (EnvironmentEvaluator.eval_once, utils/evaluation.py:40-75)."""
+    seed, episodes, env_id, kw, ckpt = args
+    torch.set_num_threads(1)
+    np.random.seed(seed)
+    # `use_motor_dynamics` / `use_latency` are not reachable through the reference's env kwargs (CrazyFlieSimpleAgent is built
+    # with both off, envs/agents.py:485-495; a kwarg of that name is swallowed): they are flipped on the agent the way the
+    # reference's own debug script does (debug/compare_system_equations_with_PyBullet.py:26-30), as oracle/refgen/gen_golden.py
+    # does for the golden scenarios; the ring keeps its ctor size max(1, int(latency // time_step)) (agents.py:180)
+    flips = [k for k in ("use_motor_dynamics", "use_latency") if kw.get(k)]
+    env = gym.make(env_id, **{k: v for k, v in kw.items() if k not in ("use_motor_dynamics", "use_latency")})
+    for k in flips:
+        setattr(env.unwrapped.drone, k, True)
+    ac = core.ActorCritic('mlp', env.observation_space, env.action_space, use_standardized_obs=True, use_scaled_rewards=True,
+                          use_shared_weights=False,
+                          ac_kwargs={'pi': {'hidden_sizes': (50, 50), 'activation': 'relu'},
+                                     'val': {'hidden_sizes': (64, 64), 'activation': 'tanh'}})
+    sd = np.load(os.path.join(GOLD, ckpt))
+    ac.load_state_dict({k: torch.as_tensor(sd[k]) for k in sd.files}, strict=True)
+    ac.eval()
+    lens, rets, terms = [], [], []
+    for ep in range(episodes):
+        o, _ = env.reset()
+        n, ret = 0, 0.0
+        while True:
+            a, _, _ = ac.step(torch.as_tensor(o, dtype=torch.float32))
+            o, r, te, tr, _ = env.step(a)
+            n += 1; ret += float(r)
+            if te or tr or n >= 500:
+                break
+        lens.append(n); rets.append(ret); terms.append(bool(te))
+    return lens, rets, terms
+
+
 def _circle_reference_policy(out):
     from phoenix_drone_simulation.utils import utils
     fix = os.path.join(GOLD, "policy_PWM_seed_00000_model.json")
@@ -63,7 +98,7 @@ def main():
     path = os.path.join(GOLD, "policy_eval_stats.json")
     only = os.environ.get("PO_ONLY")  # regenerate one part, keep the others from the existing file (they are deterministic)
     if only and os.path.exists(path):
-        out.update({k: v for k, v in json.load(open(path)).items() if k in ("early", "late", "circle_reference_policy", "circle_attrate")})
+        out.update({k: v for k, v in json.load(open(path)).items() if k in ("early", "late", "circle_reference_policy", "circle_attrate", "hover_latency_motor", "hover_hold")})
     for name, episodes in EPISODES.items():
         if only and only != "hover":
             continue
@@ -98,31 +133,35 @@ def main():
         _circle_reference_policy(out)
     if not only or only == "circle_attrate":
         # ---- a HIP-trained policy on exp-07's AttitudeRate configuration (PID rate controller under the policy, 4 physics
-        # sub-steps per step: envs/control.py:120-287, run_control_structures.py:53-61) in the reference's Circle env
+        # sub-steps per step: envs/control.py:120-287, run_control_structures.py:53-61) in the reference's Circle env.
+        # SEVEN independent env instances (numpy seeds 11..17) x 1 400 episodes, in parallel: a single long-lived env is ONE
+        # realisation of the slow sensor-bias walk, and one 2 400-episode run (seed 4321: 423.0 steps, 17.8 % falls) sat 2.7
+        # of its own standard errors away from these seven (409 .. 418 steps, 18.7 .. 20.5 % falls)
+        import multiprocessing as mp
         kw = dict(control_mode="AttitudeRate", aggregate_phy_steps=4)
-        np.random.seed(4321)
-        env = gym.make("DroneCircleSimpleEnv-v0", **kw)
-        ac = core.ActorCritic('mlp', env.observation_space, env.action_space, use_standardized_obs=True, use_scaled_rewards=True,
-                              use_shared_weights=False,
-                              ac_kwargs={'pi': {'hidden_sizes': (50, 50), 'activation': 'relu'},
-                                         'val': {'hidden_sizes': (64, 64), 'activation': 'tanh'}})
-        sd = np.load(os.path.join(GOLD, "hip_policy_circle_attrate_late.npz"))
-        ac.load_state_dict({k: torch.as_tensor(sd[k]) for k in sd.files}, strict=True)
-        ac.eval()
-        episodes, lens, rets, terms = 800, [], [], []
-        for ep in range(episodes):
-            o, _ = env.reset()
-            n, ret = 0, 0.0
-            while True:
-                a, _, _ = ac.step(torch.as_tensor(o, dtype=torch.float32))
-                o, r, te, tr, _ = env.step(a)
-                n += 1; ret += float(r)
-                if te or tr or n >= 500:
-                    break
-            lens.append(n); rets.append(ret); terms.append(bool(te))
-        out["circle_attrate"] = dict(episodes=episodes, env_id="DroneCircleSimpleEnv-v0", env_kwargs=kw, ep_len=lens,
-                                     ep_ret=[round(x, 4) for x in rets], terminated=[int(t) for t in terms])
-        print("circle AttitudeRate HIP policy: len", np.mean(lens), "ret", np.mean(rets), "+-", np.std(rets) / np.sqrt(episodes), "terminated", np.mean(terms))
+        jobs = [(sd_, 1400, "DroneCircleSimpleEnv-v0", kw, "hip_policy_circle_attrate_late.npz") for sd_ in range(11, 18)]
+        with mp.get_context("spawn").Pool(7) as pool:
+            parts = pool.map(_eval_actor_critic, jobs)
+        lens, rets, terms = (sum((p_[i] for p_ in parts), []) for i in range(3))
+        out["circle_attrate"] = dict(episodes=len(lens), env_id="DroneCircleSimpleEnv-v0", env_kwargs=kw, numpy_seeds=list(range(11, 18)),
+                                     ep_len=lens, ep_ret=[round(x, 4) for x in rets], terminated=[int(t) for t in terms])
+        print("circle AttitudeRate HIP policy: len", np.mean(lens), "ret", np.mean(rets), "terminated", np.mean(terms),
+              "| per instance:", [round(float(np.mean(p_[0])), 1) for p_ in parts])
+    # ---- more of the env's variant families in the loop (HIP-trained policies, profiles/tools/train_export_policies.py EXTRA):
+    # the latency ring + first-order motor model (envs/agents.py:259-298) and the Kalman hold (envs/hover.py:134-156)
+    extra = {"hover_latency_motor": ("DroneHoverSimpleEnv-v0", dict(use_latency=True, latency=0.02, use_motor_dynamics=True)),
+             "hover_hold": ("DroneHoverSimpleEnv-v0", dict(observation_frequency=50))}
+    for name, (env_id, kw) in extra.items():
+        if only and only != name and only != "extra":
+            continue
+        import multiprocessing as mp
+        jobs = [(sd_, 1000, env_id, kw, f"hip_policy_{name}.npz") for sd_ in range(21, 28)]  # seven env instances x 1 000 episodes
+        with mp.get_context("spawn").Pool(7) as pool:
+            parts = pool.map(_eval_actor_critic, jobs)
+        lens, rets, terms = (sum((p_[i] for p_ in parts), []) for i in range(3))
+        out[name] = dict(episodes=len(lens), env_id=env_id, env_kwargs=kw, numpy_seeds=list(range(21, 28)), ep_len=lens,
+                         ep_ret=[round(x, 4) for x in rets], terminated=[int(t) for t in terms])
+        print(name, "len", np.mean(lens), "+-", np.std(lens) / np.sqrt(len(lens)), "ret", np.mean(rets), "terminated", np.mean(terms))
     with open(os.path.join(GOLD, "policy_eval_stats.json"), "w") as f:
         json.dump(out, f)
     print("wrote policy_eval_stats.json")

@@ -44,5 +44,28 @@ def main():
     env.close()
 
 
+EXTRA = {  # name: (env id, env kwargs, epochs, epoch at which the policy is exported)
+    # the latency ring + first-order motor model (envs/agents.py:259-298) and the Kalman hold (envs/hover.py:134-156) in the loop
+    "hover_latency_motor": ("DroneHoverSimpleEnv-v0", dict(use_latency=True, latency=0.02, use_motor_dynamics=True), 200, 32),
+    "hover_hold": ("DroneHoverSimpleEnv-v0", dict(observation_frequency=50), 200, 28),
+}
+
+
+def extra(out):
+    for name, (env_id, kw, epochs, at) in EXTRA.items():
+        env = pds.make(env_id, num_envs=8192, seed=21, **kw)
+        tr = PPOTrainer(env, rollout_len=64, epochs=epochs, seed=21)
+        for e in range(at):
+            info = tr.learn_one_epoch()
+        sd = {k: v.detach().cpu().numpy() for k, v in tr.ac.state_dict().items()}
+        np.savez_compressed(os.path.join(out, f"hip_policy_{name}.npz"), **sd)
+        print(f"{name}: epoch {at}: ep_len {info['ep_len']:.1f} ep_ret {info['ep_ret']:.1f} noise {info['noise_std']:.3f} -> hip_policy_{name}.npz")
+        torch.cuda.synchronize()
+        env.close()
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 2 and sys.argv[2] == "extra":
+        extra(sys.argv[1])
+    else:
+        main()

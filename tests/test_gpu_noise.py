@@ -292,7 +292,7 @@ def test_step_noise_normals_against_the_normal_distribution():
     assert abs(float((z[:-1] * z[1:]).double().mean())) < 5 / np.sqrt(m)
 
 
-@pytest.mark.parametrize("name", ["early", "late", "circle_attrate"])
+@pytest.mark.parametrize("name", ["early", "late", "circle_attrate", "hover_latency_motor", "hover_hold"])
 def test_hip_trained_policies_fly_the_same_in_the_reference_envs(name):
     """Sim-to-sim transfer, the drop-in claim end to end: two policies trained by PPOTrainer ON THE HIP ENVS
     (tests/golden/hip_policy_{early,late}.npz, profiles/tools/train_export_policies.py: after 14 epochs -- every episode still
@@ -311,7 +311,10 @@ def test_hip_trained_policies_fly_the_same_in_the_reference_envs(name):
     gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     ref = json.load(open(os.path.join(gold, "policy_eval_stats.json")))[name]
     # (third case: exp-07's AttitudeRate configuration -- the PID rate controller under the policy, 4 physics sub-steps per
-    #  step -- on the Circle task: hip_policy_circle_attrate_late.npz, 800 reference episodes, ~20 % of them end in a fall)
+    #  step -- on the Circle task: hip_policy_circle_attrate_late.npz, 9 800 reference episodes from seven env instances, ~20 % of
+    #  them end in a fall)
+    # (fourth / fifth case: the latency ring + first-order motor model and the Kalman hold in the loop, policies exported while every
+    #  episode still ends in a fall; the reference side: seven independent env instances each)
     sd = np.load(os.path.join(gold, "hip_policy_circle_attrate_late.npz" if name == "circle_attrate" else f"hip_policy_{name}.npz"))
     env = pds.make(ref.get("env_id", "DroneHoverSimpleEnv-v0"), num_envs=8192, seed=5, **ref.get("env_kwargs", {}))
     ac = ActorCritic.from_reference_state_dict({k: sd[k] for k in sd.files}).to(env.device)
