@@ -48,6 +48,8 @@ EXTRA = {  # name: (env id, env kwargs, epochs, epoch at which the policy is exp
     # the latency ring + first-order motor model (envs/agents.py:259-298) and the Kalman hold (envs/hover.py:134-156) in the loop
     "hover_latency_motor": ("DroneHoverSimpleEnv-v0", dict(use_latency=True, latency=0.02, use_motor_dynamics=True), 200, 32),
     "hover_hold": ("DroneHoverSimpleEnv-v0", dict(observation_frequency=50), 200, 28),
+    # the Circle task at its defaults (other reward / termination / reference trajectory), while episodes still end in falls
+    "circle_default": ("DroneCircleSimpleEnv-v0", dict(), 200, 16),
 }
 
 
