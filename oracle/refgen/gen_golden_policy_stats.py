@@ -98,7 +98,7 @@ def main():
     path = os.path.join(GOLD, "policy_eval_stats.json")
     only = os.environ.get("PO_ONLY")  # regenerate one part, keep the others from the existing file (they are deterministic)
     if only and os.path.exists(path):
-        out.update({k: v for k, v in json.load(open(path)).items() if k in ("early", "late", "circle_reference_policy", "circle_attrate", "hover_latency_motor", "hover_hold", "circle_default")})
+        out.update({k: v for k, v in json.load(open(path)).items() if k in ("early", "late", "circle_reference_policy", "circle_attrate", "hover_latency_motor", "hover_hold", "circle_default", "hover_history4")})
     for name, episodes in EPISODES.items():
         if only and only != "hover":
             continue
@@ -151,7 +151,8 @@ def main():
     # the latency ring + first-order motor model (envs/agents.py:259-298) and the Kalman hold (envs/hover.py:134-156)
     extra = {"hover_latency_motor": ("DroneHoverSimpleEnv-v0", dict(use_latency=True, latency=0.02, use_motor_dynamics=True)),
              "hover_hold": ("DroneHoverSimpleEnv-v0", dict(observation_frequency=50)),
-             "circle_default": ("DroneCircleSimpleEnv-v0", dict())}
+             "circle_default": ("DroneCircleSimpleEnv-v0", dict()),
+             "hover_history4": ("DroneHoverSimpleEnv-v0", dict(observation_history_size=4))}
     for name, (env_id, kw) in extra.items():
         if only and only != name and only != "extra":
             continue

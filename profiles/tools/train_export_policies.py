@@ -50,6 +50,8 @@ EXTRA = {  # name: (env id, env kwargs, epochs, epoch at which the policy is exp
     "hover_hold": ("DroneHoverSimpleEnv-v0", dict(observation_frequency=50), 200, 28),
     # the Circle task at its defaults (other reward / termination / reference trajectory), while episodes still end in falls
     "circle_default": ("DroneCircleSimpleEnv-v0", dict(), 200, 16),
+    # observation_history_size = 4 (experiments/04_*): 68 network inputs -- the trainer's PyTorch-network path, pds_history_advance
+    "hover_history4": ("DroneHoverSimpleEnv-v0", dict(observation_history_size=4), 200, 30),
 }
 
 

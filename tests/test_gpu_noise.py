@@ -292,7 +292,7 @@ def test_step_noise_normals_against_the_normal_distribution():
     assert abs(float((z[:-1] * z[1:]).double().mean())) < 5 / np.sqrt(m)
 
 
-@pytest.mark.parametrize("name", ["early", "late", "circle_attrate", "hover_latency_motor", "hover_hold", "circle_default"])
+@pytest.mark.parametrize("name", ["early", "late", "circle_attrate", "hover_latency_motor", "hover_hold", "circle_default", "hover_history4"])
 def test_hip_trained_policies_fly_the_same_in_the_reference_envs(name):
     """Sim-to-sim transfer, the drop-in claim end to end: two policies trained by PPOTrainer ON THE HIP ENVS
     (tests/golden/hip_policy_{early,late}.npz, profiles/tools/train_export_policies.py: after 14 epochs -- every episode still
