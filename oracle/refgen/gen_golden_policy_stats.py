@@ -64,6 +64,25 @@ def _eval_actor_critic(args):
     return lens, rets, terms
 
 
+def _eval_constant_action(args):
+    """(numpy seed, episodes, env id, env kwargs, offset) -> (lengths, returns): a = HOVER_ACTION + offset on all four motors"""
+    seed, episodes, env_id, kw, offset = args
+    np.random.seed(seed)
+    env = gym.make(env_id, **kw)
+    a = np.full(4, env.unwrapped.drone.HOVER_ACTION + offset)
+    lens, rets = [], []
+    for ep in range(episodes):
+        env.reset()
+        n, ret = 0, 0.0
+        while True:
+            o, r, te, tr, _ = env.step(a)
+            n += 1; ret += float(r)
+            if te or tr or n >= 500:
+                break
+        lens.append(n); rets.append(ret)
+    return lens, rets
+
+
 def _circle_reference_policy(out):
     from phoenix_drone_simulation.utils import utils
     fix = os.path.join(GOLD, "policy_PWM_seed_00000_model.json")
@@ -98,7 +117,7 @@ def main():
     path = os.path.join(GOLD, "policy_eval_stats.json")
     only = os.environ.get("PO_ONLY")  # regenerate one part, keep the others from the existing file (they are deterministic)
     if only and os.path.exists(path):
-        out.update({k: v for k, v in json.load(open(path)).items() if k in ("early", "late", "circle_reference_policy", "circle_attrate", "hover_latency_motor", "hover_hold", "circle_default", "hover_history4")})
+        out.update({k: v for k, v in json.load(open(path)).items() if k in ("early", "late", "circle_reference_policy", "circle_attrate", "hover_latency_motor", "hover_hold", "circle_default", "hover_history4", "takeoff_const")})
     for name, episodes in EPISODES.items():
         if only and only != "hover":
             continue
@@ -164,6 +183,18 @@ def main():
         out[name] = dict(episodes=len(lens), env_id=env_id, env_kwargs=kw, numpy_seeds=list(range(21, 28)), ep_len=lens,
                          ep_ret=[round(x, 4) for x in rets], terminated=[int(t) for t in terms])
         print(name, "len", np.mean(lens), "+-", np.std(lens) / np.sqrt(len(lens)), "ret", np.mean(rets), "terminated", np.mean(terms))
+    if not only or only == "takeoff_const":
+        # ---- the third task under a fixed open-loop command (no termination in TakeOff, envs/takeoff.py:100: every episode
+        # runs 500 steps; PPO on it overflows early in training): all four motors at HOVER_ACTION + 0.04 --
+        # lift-off, climb through the target height; the return depends on the randomised mass / thrust-to-weight / motor
+        # noise and on the noisy observations only through the reward's state terms
+        import multiprocessing as mp
+        with mp.get_context("spawn").Pool(7) as pool:
+            parts = pool.map(_eval_constant_action, [(sd_, 300, "DroneTakeOffSimpleEnv-v0", {}, 0.04) for sd_ in range(51, 58)])
+        lens, rets = (sum((p_[i] for p_ in parts), []) for i in range(2))
+        out["takeoff_const"] = dict(episodes=len(lens), env_id="DroneTakeOffSimpleEnv-v0", env_kwargs={}, action_offset=0.04,
+                                    numpy_seeds=list(range(51, 58)), ep_len=lens, ep_ret=[round(x, 4) for x in rets])
+        print("takeoff constant action: len", np.mean(lens), "ret", np.mean(rets), "+-", np.std(rets) / np.sqrt(len(rets)), "sd", np.std(rets))
     with open(os.path.join(GOLD, "policy_eval_stats.json"), "w") as f:
         json.dump(out, f)
     print("wrote policy_eval_stats.json")

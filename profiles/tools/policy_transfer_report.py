@@ -32,3 +32,13 @@ for mine, theirs, what in ((length, np.array(r["ep_len"], float), "episode lengt
     t, p = stats.ttest_ind(mine, theirs, equal_var=False)
     print(f"circle {what:15s}: reference {theirs.mean():9.2f} +- {theirs.std()/np.sqrt(len(theirs)):5.2f} (SD {theirs.std():6.2f}, {len(theirs)} episodes) | HIP {mine.mean():9.2f} +- {mine.std()/np.sqrt(len(mine)):5.2f} (SD {mine.std():6.2f}) | Welch t {t:+.2f} p {p:.3f}")
 print(f"circle terminated share: reference {np.mean(r['terminated']):.4f} | HIP {(length < 500).mean():.4f}")
+import torch
+r = ref["takeoff_const"]
+env = pds.make(r["env_id"], num_envs=8192, seed=8, **r["env_kwargs"])
+a = torch.full((env.num_envs, 4), -1.0 + 2.0 / 2.25 + r["action_offset"], device=env.device)
+ret, length, _ = evaluate(env, lambda obs: a)
+ret, theirs = ret.numpy().astype(float), np.array(r["ep_ret"], float)
+t, p = stats.ttest_ind(ret, theirs, equal_var=False)
+print("# DroneTakeOffSimpleEnv-v0 at its defaults under the open-loop command HOVER_ACTION + 0.04 (500 steps, no termination):")
+print(f"takeoff 500-step return: reference {theirs.mean():9.1f} +- {theirs.std()/np.sqrt(len(theirs)):5.1f} (SD {theirs.std():7.1f}, {len(theirs)} episodes) | HIP {ret.mean():9.1f} +- {ret.std()/np.sqrt(len(ret)):5.1f} (SD {ret.std():7.1f}) | Welch t {t:+.2f} p {p:.3f}")
+print("takeoff return quantiles 10/25/50/75/90 %: reference", np.round(np.quantile(theirs, [.1,.25,.5,.75,.9]), 0), "| HIP", np.round(np.quantile(ret, [.1,.25,.5,.75,.9]), 0))
