@@ -175,7 +175,7 @@ def test_noise_statistics_full_size():
 def test_episode_statistics_match_the_reference_under_its_own_randomness(task):
     """The stochastic DEFAULT configuration (sensor + thrust noise, 10 % domain randomisation, reset
     distribution) end to end: episode lengths / returns of the reference envs under numpy's MT19937
-    (tests/golden/episode_stats.json, 1500 episodes each, oracle/refgen/gen_golden_episode_stats.py)
+    (tests/golden/episode_stats.json, 21 000 episodes each from seven env instances, oracle/refgen/gen_golden_episode_stats.py)
     against the HIP envs under Philox, same action distribution a = HOVER_ACTION + 0.1 N(0,1)."""
     import json
     import os
@@ -200,18 +200,18 @@ def test_episode_statistics_match_the_reference_under_its_own_randomness(task):
             break
     length, ret, cost, first = length.cpu().numpy(), ret.cpu().numpy(), cost.cpu().numpy(), first.cpu().numpy()
 
-    def close(got_mean, got_std, ref_mean, ref_std, what, k=4.5):
+    def close(got_mean, got_std, ref_mean, ref_std, what, k=3.0):  # (round 5: 3 standard errors of 21 000 + 16 384 episodes; 4.5 of 1 500 before)
         se = np.sqrt(ref_std ** 2 / ref["episodes"] + got_std ** 2 / n)
-        assert abs(got_mean - ref_mean) < k * se + 1e-3 * abs(ref_mean), (what, got_mean, ref_mean, se)
+        assert abs(got_mean - ref_mean) < k * se + 2e-4 * abs(ref_mean), (what, got_mean, ref_mean, se)
 
     close(length.mean(), length.std(), ref["len_mean"], ref["len_std"], "episode length")
     close(ret.mean(), ret.std(), ref["ret_mean"], ref["ret_std"], "episode return")
     close((ret / length).mean(), (ret / length).std(), ref["ret_per_step_mean"], ref["ret_per_step_std"], "return per step")
     close(first.mean(), first.std(), ref["first_reward_mean"], ref["first_reward_std"], "first-step reward")
     assert abs((cost / length).mean() - ref["cost_per_step_mean"]) < 2e-3
-    assert abs(length.std() - ref["len_std"]) < 0.08 * ref["len_std"]
+    assert abs(length.std() - ref["len_std"]) < 0.03 * ref["len_std"]
     q = np.quantile(length, [0.1, 0.25, 0.5, 0.75, 0.9])
-    assert np.all(np.abs(q - np.array(ref["len_quantiles"])) <= np.maximum(2.0, 0.06 * np.array(ref["len_quantiles"]))), (q, ref["len_quantiles"])
+    assert np.all(np.abs(q - np.array(ref["len_quantiles"])) <= np.maximum(1.0, 0.03 * np.array(ref["len_quantiles"]))), (q, ref["len_quantiles"])
     env.close()
 
 
