@@ -179,6 +179,11 @@ def main():
                     help="TEST ONLY: every rank uses cuda:0 and the control collectives run over gloo, so that the "
                          "multi-rank code path (incl. --allgather-obs p2p) can be exercised on a 1-GPU box; "
                          "the numbers of such a run mean nothing")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the RCCL process group and run the collectives of the multi-GPU path even with ONE rank "
+                         "(started under torch.distributed.run --nproc-per-node 1): proves on a 1-GPU box that librccl loads, "
+                         "that the device_id binding works and that barrier / all_gather / all_gather_into_tensor / all_reduce "
+                         "run on this ROCm; says nothing about xGMI")
     ap.add_argument("--no-auto-reset", action="store_true", help="diagnostic only: INVALID as a benchmark number")
     args = ap.parse_args()
 
@@ -203,7 +208,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cdev = dev  # device of the small control tensors (timings)
-    if world > 1:
+    if args.force_dist and "WORLD_SIZE" not in os.environ:
+        raise SystemExit("--force-dist needs a launcher: python -m torch.distributed.run --nproc-per-node 1 bench.py --force-dist ...")
+    multi = world > 1 or args.force_dist  # the collectives of the multi-rank path run
+    if multi:
         if args.same_device:
             dist.init_process_group("gloo")
             cdev = torch.device("cpu")
@@ -249,7 +257,7 @@ def main():
     g.manual_seed(rank)
     hover = -1.0 + 2.0 / 2.25
     ring = (hover + act_center_shift) + 0.1 * torch.randn(T, n, 4, generator=g, device=dev, dtype=torch.float32)
-    gather_mode = args.allgather_obs if world > 1 else None
+    gather_mode = args.allgather_obs if multi else None
     gathered = torch.empty(world * n, env.obs_dim, device=dev) if gather_mode == "rccl" else None
     p2p = None
     if gather_mode == "p2p":
@@ -297,7 +305,7 @@ def main():
             one_step(s)
 
     def sync():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -314,7 +322,7 @@ def main():
     wall = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / (args.steps // K)  # average launch-to-launch duration on the stream
     per_rank_ms, gather_ms = None, None
-    if world > 1:
+    if multi:
         mine = torch.tensor([wall], device=cdev, dtype=torch.float64)
         allw = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allw, mine)
@@ -391,7 +399,7 @@ def main():
         line["ranks"] = world
         line["visible_devices"] = torch.cuda.device_count()
         line["device_name"] = torch.cuda.get_device_name(dev)
-        line["collective_backend"] = (dist.get_backend() if world > 1 else None)
+        line["collective_backend"] = (dist.get_backend() if multi else None)
         line["total_envs"] = total_envs
         if per_rank_ms is not None:
             line["per_rank_ms_per_step"] = per_rank_ms
@@ -407,7 +415,7 @@ def main():
     if p2p is not None:
         p2p.release()
     env.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -294,7 +294,7 @@ int pds_history_advance(int64_t n, int half, int history, const float *d_obs2, c
  * Replaces core.Buffer.finish_path / calculate_adv_and_value_targets (algs/core.py:461-533, one
  * scipy lfilter per finished path) for a [T, N] rollout: d_rew, d_val [T,N] f32; d_terminated,
  * d_truncated [T,N] u8 (the flags pds_step returned); d_final_val [T,N] = V(final_obs) read where
- * truncated (may be NULL); d_last_val [N] = V(o_T).  rew_scale = 1/(ret_std + eps) with clipping to
+ * truncated -- the cut wins over a termination on the same step, algs/iwpg/iwpg.py:374-379 -- (may be NULL); d_last_val [N] = V(o_T).  rew_scale = 1/(ret_std + eps) with clipping to
  * +-rew_clip (use_reward_scaling) or 0 for raw rewards.  Outputs [T,N]: advantages, value targets,
  * discounted returns.  Runs on the current device, asynchronously on `stream`. */
 int pds_gae(const float *d_rew, const float *d_val, const uint8_t *d_terminated, const uint8_t *d_truncated,
@@ -316,9 +316,9 @@ typedef struct pds_mlp {
  *   V(o) -> d_val_buf[t];  a = mu(o) + exp(log_std) z, log p -> d_act_buf[t], d_logp_buf[t] (the draws of
  *   pds_gaussian_sample with call = *d_call_base + call_offset + t + 1);  env.step(a) (bitwise pds_step) ->
  *   d_rew_buf[t], d_term_buf[t], d_trunc_buf[t], d_cost_buf[t], next observation -> d_obs_buf[t + 1];
- *   V(final observation) of the envs whose episode the TimeLimit cut at step t (truncated and not terminated: the
- *   bootstrap value of algs/iwpg/iwpg.py:375-385) -> d_fval_buf[t] (other entries are left alone: pds_gae never
- *   reads them);  episode return / length bookkeeping of pds_rollout_record -> d_ep_ret, d_ep_len, d_stats[3]
+ *   V(final observation) of the envs whose episode the TimeLimit cut at step t (truncated, terminated or not: the
+ *   bootstrap value of algs/iwpg/iwpg.py:374-379; at t = T - 1 also of the envs that only terminated, for a caller that
+ *   mirrors the reference's epoch-end cut) -> d_fval_buf[t] (other entries are left alone: pds_gae never reads them);  episode return / length bookkeeping of pds_rollout_record -> d_ep_ret, d_ep_len, d_stats[3]
  * -- and V(o(T)) -> d_last_val.  d_obs_buf is [T + 1, N, D]: row 0 holds o(0) on entry, rows 1..T are written.
  * Networks: actor d_in = D, d_out = 4; critic d_in = D, d_out = 1; hidden <= 64; inputs standardised with
  * d_mean / d_std / eps when given (OnlineMeanStd.forward).  All other buffers are [T, N] ([T, N, 4] actions).

@@ -34,7 +34,7 @@ def cpu_gae(rew, val, terminated, truncated, final_val, last_val, gamma, lam, re
     for t in range(T - 1, -1, -1):
         te, tr = terminated[t].bool(), truncated[t].bool()
         end = te | tr
-        b = torch.where(te, torch.zeros(N), final_val[t])
+        b = torch.where(tr, final_val[t], torch.zeros(N))  # (cut wins over terminated: iwpg.py:374-379)
         next_val = torch.where(end, b, next_val)
         next_ret = torch.where(end, b, next_ret)
         next_adv = torch.where(end, torch.zeros(N), next_adv)

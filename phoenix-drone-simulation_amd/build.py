@@ -63,7 +63,7 @@ def _signature(unit, flags):
     what it was compiled from changed, not when a file was touched or a header it never sees was edited."""
     h = hashlib.sha256(" ".join(flags).encode())
     for path in _closure(os.path.join(_CSRC, unit)):
-        h.update(path.encode())
+        h.update(os.path.relpath(path, _HERE).encode())  # (relative: the signature travels with the checkout)
         with open(path, "rb") as f:
             h.update(f.read())
     return h.hexdigest()
@@ -91,7 +91,7 @@ def build_library(force=False, verbose=False, extra_flags=(), out=None):
         if os.path.exists(lsig):
             if open(lsig).read().strip() == link_sig:
                 return out
-        elif not _stale(out, _DEPS):
+        elif not extra_flags and not _stale(out, _DEPS):
             return out  # (a library without its signature file: trust the time stamps)
     todo = [(u, o) for u, o in zip(_UNITS, objs) if force or not current(u, o)]
     if not os.path.exists(hipcc):

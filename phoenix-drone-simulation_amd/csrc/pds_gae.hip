@@ -8,8 +8,9 @@
 // coalesced 4 B/lane stream.  HBM-bound: ~26 B per (t, env).
 //
 // Path boundaries: an env that terminated at step t bootstraps with 0, one that was truncated
-// (TimeLimit) with V(final_obs) (algs/iwpg/iwpg.py:375-385); the last step of the rollout bootstraps
-// with V(o_T) unless the env finished exactly there.  Reward scaling (use_reward_scaling,
+// (TimeLimit) with V(final_obs) -- ALSO when it terminated on that very step: the reference tests
+// `if truncated or epoch_ended: v = V(o)` first (algs/iwpg/iwpg.py:374-379; tests/golden/rollout.npz holds nine such
+// paths); the last step of the rollout bootstraps with V(o_T) unless the env finished exactly there.  Reward scaling (use_reward_scaling,
 // algs/core.py:523-529): the rewards that enter the TD residuals are divided by the running std of
 // the discounted returns and clipped to +-10; the discounted returns themselves use raw rewards.
 #include <hip/hip_runtime.h>
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(256) void gae_kernel(const float *__restrict__ rew,
     const float r = rew[i], v = val[i];
     const bool te = term[i] != 0, tr = trunc[i] != 0;
     if (te || tr) {  // a path ends at t: finish_path(last_val)
-      const float b = te ? 0.f : (final_val != nullptr ? final_val[i] : 0.f);
+      const float b = (tr && final_val != nullptr) ? final_val[i] : 0.f;  // (cut wins over terminated: iwpg.py:374-379)
       next_val = b;
       next_ret = b;
       next_adv = 0.f;

@@ -223,10 +223,12 @@ __global__ __launch_bounds__(kRolloutThreads * TEAMS, 1) void rollout_kernel(con
         if (dn) { st0 += er; st1 += el; st2 += 1.f; }
         ep_ret = dn ? 0.f : er;
         ep_len = dn ? 0.f : el;
-        // V(final_obs) is the bootstrap of an episode the TimeLimit cut (algs/iwpg/iwpg.py:375-385); one that terminated
-        // bootstraps with 0 and pds_gae never reads its fval entry: only the truncated envs ask the network waves for a pass
-        // (a young policy ends ~5 % of its episodes per step, nearly all of them by termination)
-        done_all[grp][lane] = (so.trunc && !so.done && active) ? 1u : 0u;
+        // V(final_obs) is the bootstrap of an episode the TimeLimit cut (algs/iwpg/iwpg.py:374-379: also when it terminated
+        // on the same step); one that only terminated bootstraps with 0 and pds_gae never reads its fval entry: only the
+        // truncated envs ask the network waves for a pass (a young policy ends ~5 % of its episodes per step, nearly all of
+        // them by termination).  The LAST step of the rollout hands over every finished env: a caller that mirrors the
+        // reference's epoch-end cut (`epoch_ended` takes V(o) for a terminated path too; ppo.py reset_each_rollout) reads it.
+        done_all[grp][lane] = ((so.trunc || (so.done && s == T - 1)) && active) ? 1u : 0u;
       }
 #ifdef PDS_ROLLOUT_TIMING
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

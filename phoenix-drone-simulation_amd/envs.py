@@ -387,6 +387,7 @@ class DroneVecEnv:
         if rc != 0:
             native.check(self._handle, rc, "pds_step_k")
         obs, final = b["obs"], b["final_obs"]
+        self._last_obs = obs[K - 1]  # (what a masked reset() copies for the envs outside the mask)
         if self._hist is not None:
             # observation_history_size != 2: the K rows of the launch run through pds_history_advance one after the other
             # (K more launches; the env state itself advanced in one)
@@ -394,7 +395,18 @@ class DroneVecEnv:
             if "obs_hist" not in b:
                 b["obs_hist"] = torch.empty(K, N, H, half, dtype=torch.float32, device=self.device)
                 b["final_hist"] = torch.zeros(K, N, H, half, dtype=torch.float32, device=self.device)
-            hist = self._hist
+            # the history lives in ONE env-owned buffer across step_k calls (a hipGraph that captured a call re-reads and
+            # re-writes that address at every replay, so the history carries from replay to replay)
+            own = getattr(self, "_hist_own", None)
+            if own is None:
+                own = self._hist_own = torch.empty_like(self._hist)
+            if self._hist is not own:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("step_k with observation_history_size != 2: call it once eagerly before capturing it "
+                                       "(the history buffer is adopted at the first call)")
+                own.copy_(self._hist)
+                self._hist = own
+            hist = own
             with (_NULL_CTX if self.device.index == torch.cuda.current_device() else torch.cuda.device(self.device)):
                 for k in range(K):
                     rc = self.lib.pds_history_advance(N, half, H, obs[k].data_ptr(), b["terminated"][k].data_ptr(),
@@ -406,7 +418,7 @@ class DroneVecEnv:
                     if rc != 0:
                         native.check(self._handle, rc, "pds_history_advance")
                     hist = b["obs_hist"][k]
-            self._hist = hist.clone()  # (the cached set is rewritten by the next call)
+            own.copy_(hist)  # (the cached set is rewritten by the next call)
             obs = b["obs_hist"].reshape(K, N, H * half)
             final = b["final_hist"].reshape(K, N, H * half) if self._auto_reset else obs
         return (obs, b["reward"], b["terminated"].view(torch.bool), b["truncated"].view(torch.bool),

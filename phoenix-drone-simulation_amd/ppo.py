@@ -29,6 +29,15 @@ from . import native
 from .fused import counter_add, gaussian_sample, random_permutation, rollout_record
 
 
+# Collectives are skipped when the job has one rank -- unless this is set (tests: the RCCL calls of the multi-GPU path executed
+# on a 1-GPU box under torch.distributed.run --nproc-per-node 1; an all-reduce over one rank leaves its operand as it is).
+FORCE_COLLECTIVES = False
+
+
+def _collectives():
+    return dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
+
+
 class OnlineMeanStd(nn.Module):
     """utils/online_mean_std.py:6-95 with identical parameter names (mean, std, count)."""
 
@@ -55,13 +64,13 @@ class OnlineMeanStd(nn.Module):
         n_A = self.count.clone()
         n_AB = self.count + n_B
         batch_mean = torch.mean(x, dim=0)
-        if world > 1:
+        if _collectives():
             dist.all_reduce(batch_mean)
             batch_mean /= world
         delta = batch_mean - self.mean
         mean_new = self.mean + delta * n_B / n_AB
         batch_var = torch.mean((x - mean_new) ** 2, dim=0)
-        if world > 1:
+        if _collectives():
             dist.all_reduce(batch_var)
             batch_var /= world
         M2_AB = n_A * torch.square(self.std) + n_B * batch_var + delta ** 2 * (n_A * n_B / n_AB)
@@ -197,7 +206,7 @@ def gae(rew, val, terminated, truncated, final_val, last_val, gamma, lam, rew_sc
 
 def avg_grads(module):
     """mpi_avg_grads (utils/mpi_tools.py:30-36) as ONE flattened RCCL all-reduce."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _collectives():
         return
     grads = [p.grad for p in module.parameters() if p.grad is not None]
     flat = torch.cat([g.reshape(-1) for g in grads])
@@ -232,7 +241,7 @@ class PPOTrainer:
         torch.manual_seed(seed + 10000 * rank)  # algs/iwpg/iwpg.py:124-127
         dev = env.device
         self.ac = ActorCritic(env.obs_dim, env.act_dim, ac_kwargs, use_standardized_obs, use_reward_scaling).to(dev)
-        if dist.is_initialized() and dist.get_world_size() > 1:  # sync_params, utils/mpi_tools.py:39-44
+        if _collectives():  # sync_params, utils/mpi_tools.py:39-44
             for p in self.ac.parameters():
                 dist.broadcast(p.data, 0)
         self.pi_opt = torch.optim.Adam(self.ac.pi.net.parameters(), lr=pi_lr)
@@ -267,14 +276,18 @@ class PPOTrainer:
             try:
                 self.fm_pi = FusedMLP(self.ac.pi.net, kw["pi"]["activation"])
                 self.fm_v = FusedMLP(self.ac.v.net, kw["val"]["activation"])
-            except (ValueError, NotImplementedError):
-                # outside the fused kernels' range -- more than 64 inputs (observation_history_size >= 4 on Hover,
-                # experiments/04_*: 4 x 17 = 68), other depths / activations: the networks run as PyTorch ops on the HIP
-                # envs (same update, the path the fused kernels are tested against); asked for explicitly, it is an error
+            except (ValueError, NotImplementedError) as e:
+                # outside the fused kernels' range (layer sizes, depths, activations: fused.FusedMLP says which): the networks
+                # run as PyTorch ops on the HIP envs (same update, the path the fused kernels are tested against) -- an order
+                # of magnitude slower, so never silently; asked for explicitly, it is an error
                 if fused:
                     raise
+                import warnings
+                warnings.warn(f"PPOTrainer: the fused MFMA kernels do not cover these networks ({e}); using PyTorch ops",
+                              RuntimeWarning, stacklevel=2)
                 self.fused = False
                 self.graph_rollout = False
+                self.fm_pi = self.fm_v = None
         if self.fused:
             # Adam runs in pds_adam_step; the torch optimisers only carry the learning rate (LambdaLR)
             self.pi_opt._opt_called = True
@@ -294,8 +307,10 @@ class PPOTrainer:
         # reset_each_rollout: IWPGAlgorithm.roll_out starts every epoch with `o, _ = self.env.reset()` and drops the
         # episode that the previous epoch cut (algs/iwpg/iwpg.py:352-353, 382-385).  With thousands of lockstep envs
         # that would throw away the unfinished episode of every env each epoch, so the default is to carry on
-        # (the cut path is bootstrapped with V either way); True mirrors the reference, e.g. for the learning-curve
-        # comparison against its own trainer (tests/test_trainer.py, tests/golden/learning_curve.json).
+        # (the cut path is bootstrapped with V either way); True mirrors the reference -- including its bootstrap of a path
+        # that terminated on the epoch's last step, see roll_out -- e.g. for the learning-curve comparison against its own
+        # trainer (tests/test_trainer.py, tests/golden/learning_curve.json) and the element-for-element replay of its
+        # rollouts (tests/golden/rollout.npz, oracle/refgen/check_rollout_logic.py).
         self.reset_each_rollout = bool(reset_each_rollout)
         if self.reset_each_rollout:
             graph_rollout = False  # (a captured rollout holds the address of the previous observation)
@@ -310,6 +325,15 @@ class PPOTrainer:
             self.obs, _ = self.env.reset()
             self.ep_ret.zero_()
             self.ep_len.zero_()
+        stats = self._roll_out_dispatch()
+        if self.reset_each_rollout:
+            # the reference's epoch-end cut: `if truncated or epoch_ended: v = V(o)` (algs/iwpg/iwpg.py:374-379) also for a path
+            # that TERMINATED on the epoch's last step -- it bootstraps with V(its last observation), not with 0.  pds_gae
+            # lets the cut win over the termination; V(final_obs) of the last step is in fval_buf[T - 1] on every path.
+            self.trunc_buf[self.T - 1] |= self.term_buf[self.T - 1]
+        return stats
+
+    def _roll_out_dispatch(self):
         if self.fused and self.fused_rollout is not False and getattr(self.env, "observation_history_size", 2) == 2:
             try:
                 return self._roll_out_fused()
@@ -463,7 +487,7 @@ class PPOTrainer:
             if self.use_kl_early_stopping:
                 with torch.no_grad():
                     kl = torch.distributions.kl.kl_divergence(p_dist, ac.pi.dist(data["obs"])).mean()
-                    if dist.is_initialized() and dist.get_world_size() > 1:
+                    if _collectives():
                         dist.all_reduce(kl); kl /= dist.get_world_size()
                 if kl.item() > self.target_kl:
                     stop_iter = i + 1
@@ -483,8 +507,10 @@ class PPOTrainer:
         ac = self.ac
         world = dist.get_world_size() if dist.is_initialized() else 1
 
+        multi = _collectives()  # several ranks (or FORCE_COLLECTIVES): gradients are averaged between the gradient and Adam
+
         def average(fm):
-            if world > 1:
+            if multi:
                 dist.all_reduce(fm.flat_grad)
                 fm.flat_grad /= world
 
@@ -500,7 +526,7 @@ class PPOTrainer:
                 perm = (self.perm_fn(B) if self.perm_fn is not None else
                         random_permutation(B, self._sample_seed ^ 0x5045524D, self._perm_calls, obs.device))
                 for s in range(0, mbs * self.num_mini_batches, mbs):
-                    if world == 1:  # the Adam step rides on the gradient's partial-sum kernel (same bits, one launch less)
+                    if not multi:  # the Adam step rides on the gradient's partial-sum kernel (same bits, one launch less)
                         self.fm_v.value_grad(obs, target_v, index=perm[s:s + mbs], adam_lr=self.vf_opt.param_groups[0]["lr"])
                     else:
                         self.fm_v.value_grad(obs, target_v, index=perm[s:s + mbs])
@@ -516,7 +542,7 @@ class PPOTrainer:
         # on every rank: kept sequential.)
         side = None
         vgen = value_steps()
-        if world == 1 and self.overlap_value_update and obs.is_cuda:
+        if not multi and self.overlap_value_update and obs.is_cuda:
             main = torch.cuda.current_stream(obs.device)
             if self._side_stream is None:
                 self._side_stream = torch.cuda.Stream(device=obs.device)  # (a high-priority stream: no gain, profiles/r04_ppo_overlap.txt)
@@ -547,7 +573,7 @@ class PPOTrainer:
             for i in range(self.train_pi_iterations):
                 # the value steps due by now: spread evenly over the policy iterations
                 feed_value_stream((i + 1) * v_total // self.train_pi_iterations - i * v_total // self.train_pi_iterations)
-                ride = world == 1 and not self.use_max_grad_norm  # Adam inside the gradient call (same bits)
+                ride = not multi and not self.use_max_grad_norm  # Adam inside the gradient call (same bits)
                 stats = self.fm_pi.ppo_grad(obs, act, adv, logp_old, log_std, self.clip_ratio,
                                             adam_lr=self.pi_opt.param_groups[0]["lr"] if ride else None)
                 if first is None:
@@ -560,17 +586,18 @@ class PPOTrainer:
                 if self.use_kl_early_stopping:
                     with torch.no_grad():  # KL(N(mu_old, s) || N(mu_new, s)) = sum (mu_old - mu_new)^2 / (2 s^2)
                         kl = (((mu_old - self.fm_pi.forward(obs)) ** 2) / (2 * torch.exp(2 * log_std))).sum(-1).mean()
-                        if world > 1:
+                        if multi:
                             dist.all_reduce(kl); kl /= world
                     if kl.item() > self.target_kl:
                         stop_iter = i + 1
                         break
+            feed_value_stream(v_total)  # (whatever an early stop of the policy loop has left; not on an exception)
         finally:
             # whatever happens in the policy loop (a non-finite KL, KeyboardInterrupt): the value steps already enqueued on the
             # side stream read `obs`, `target_v` and the value net's tensors, which were allocated on the main stream -- the
-            # main stream waits for them before anything can be freed or reused (no value step is left half-fed either)
+            # main stream waits for them before anything can be freed or reused.  Nothing more is enqueued here: after an
+            # exception the value net keeps the steps it had got, and a second error cannot hide the first.
             if side is not None:
-                feed_value_stream(v_total)  # (whatever an early stop of the policy loop has left)
                 torch.cuda.current_stream(obs.device).wait_stream(side)
         if self.use_standardized_obs:
             ac.obs_oms.update(raw_obs)
@@ -599,7 +626,7 @@ class PPOTrainer:
         stats = self.roll_out()
         info = self.update()
         bad_here = not (math.isfinite(info["loss_pi"]) and math.isfinite(info["loss_v"]))
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if _collectives():
             # the losses are rank-local (the shard that holds a NaN env sees it first): decide TOGETHER, or the
             # other ranks would walk into the next all-reduce and hang until the RCCL timeout
             flag = torch.tensor([1.0 if bad_here else 0.0], device=self.env.device)
@@ -615,7 +642,7 @@ class PPOTrainer:
                                      "explicit Euler step overflows on an env that never terminates)")
         if self.scheduler is not None:
             self.scheduler.step()
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if _collectives():
             dist.all_reduce(stats)
         s = stats.tolist()
         world = dist.get_world_size() if dist.is_initialized() else 1
@@ -654,13 +681,17 @@ def train_runs_side_by_side(env_id, seeds, num_envs, rollout_len, epochs, thread
     A run at the reference's layout (one env, 32 000 steps per epoch) keeps one of the 256 CUs busy, so runs overlap almost for
     free: 12.4 s -> 1.9 s per 40-epoch run with 8 threads -- PROVIDED the HIP runtime has enough hardware queues: export
     GPU_MAX_HW_QUEUES=16 before the process first touches the GPU (the default of 4 serialises streams that share a queue:
-    5.2 s per run).  Results are bit-identical to running the seeds one after the other (every random draw is keyed by the run's
-    seed; only the construction of a trainer is serialised, because torch.manual_seed and the networks' initialisation use
-    torch's global generator).  -> {seed: PPOTrainer.log (list of per-epoch dicts)}"""
+    5.2 s per run).  On the FUSED path results are bit-identical to running the seeds one after the other (every random draw is
+    keyed by the run's seed; only the construction of a trainer is serialised, because torch.manual_seed and the networks'
+    initialisation use torch's global generator).  Where the networks fall back to PyTorch ops the update draws from torch's
+    global generator (randperm, Normal.sample), so runs would depend on the threads' interleaving: that case runs the seeds one
+    after the other.  Rollouts are never captured into a hipGraph here (a capture in one thread is invalidated by allocations
+    and launches of the others).  -> {seed: PPOTrainer.log (list of per-epoch dicts)}"""
     import threading
     from .envs import make
     env_kwargs, trainer_kwargs = dict(env_kwargs or {}), dict(trainer_kwargs or {})
-    build, pick = threading.Lock(), threading.Lock()
+    trainer_kwargs["graph_rollout"] = False
+    build, pick, serial = threading.Lock(), threading.Lock(), threading.Lock()
     pending, logs, errors = list(seeds), {}, []
 
     def worker():
@@ -671,14 +702,23 @@ def train_runs_side_by_side(env_id, seeds, num_envs, rollout_len, epochs, thread
                         if not pending or errors:
                             return
                         seed = pending.pop(0)
-                    with build:
-                        env = make(env_id, num_envs=num_envs, seed=seed, **env_kwargs)
-                        tr = PPOTrainer(env, rollout_len=rollout_len, epochs=epochs, seed=seed, **trainer_kwargs)
+                    env = None
+                    try:
+                        with build:
+                            env = make(env_id, num_envs=num_envs, seed=seed, **env_kwargs)
+                            tr = PPOTrainer(env, rollout_len=rollout_len, epochs=epochs, seed=seed, **trainer_kwargs)
+                            torch.cuda.current_stream().synchronize()
+                        if tr.fused:
+                            tr.learn()
+                        else:  # torch's global generator is in play: one run at a time, re-seeded as a lone run would be
+                            with serial:
+                                torch.manual_seed(seed)
+                                tr.learn()
                         torch.cuda.current_stream().synchronize()
-                    tr.learn()
-                    torch.cuda.current_stream().synchronize()
-                    logs[seed] = tr.log
-                    env.close()
+                        logs[seed] = tr.log
+                    finally:
+                        if env is not None:
+                            env.close()
         except BaseException as e:  # noqa: BLE001  (re-raised in the caller's thread)
             errors.append(e)
 

@@ -310,7 +310,7 @@ def gae_torch(rew, val, terminated, truncated, final_val, last_val, gamma, lam, 
     for t in range(T - 1, -1, -1):
         te, tr = terminated[t].bool(), truncated[t].bool()
         end = te | tr
-        b = torch.where(te, zero, final_val[t] if final_val is not None else zero)
+        b = torch.where(tr, final_val[t] if final_val is not None else zero, zero)  # (cut wins: iwpg.py:374-379)
         next_val, next_ret, next_adv = torch.where(end, b, next_val), torch.where(end, b, next_ret), torch.where(end, zero, next_adv)
         rs = torch.clamp(rew[t] * rew_scale, -rew_clip, rew_clip) if rew_scale > 0 else rew[t]
         a = (rs + gamma * next_val - val[t]) + gl * next_adv
@@ -338,8 +338,8 @@ def load_update_epoch(g, e, device):
             last_val = float(lv)          # epoch end: PPOTrainer's last_val (no flag on the last step)
         elif term[t] and lv == 0.0:
             pass                           # terminated: bootstrap 0
-        else:                              # the TimeLimit cut (or terminated AND cut: the reference takes V, iwpg.py:375-379)
-            term[t], trunc[t], fval[t] = 0, 1, lv
+        else:                              # the TimeLimit cut (also terminated AND cut: the reference takes V, iwpg.py:374-379)
+            trunc[t], fval[t] = 1, lv
     f = lambda x, dt=torch.float32: torch.as_tensor(np.asarray(x), dtype=dt, device=device)  # noqa: E731
     return dict(obs=f(g[f"e{e}_obs_buf"])[:, None], act=f(g[f"e{e}_act_buf"])[:, None], rew=f(g[f"e{e}_rew_buf"])[:, None],
                 val=f(g[f"e{e}_val_buf"])[:, None], logp=f(g[f"e{e}_logp_buf"])[:, None], term=f(term, torch.uint8)[:, None],

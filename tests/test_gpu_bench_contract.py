@@ -133,3 +133,84 @@ def test_bench_two_gpus_rccl_allgather_for_real():
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["collective_backend"] == "nccl" and d["visible_devices"] >= 2
     assert d["allgather_ms"] > 0 and d["scaling"] == "weak"
+
+
+def _clean_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    return env
+
+
+def test_bench_one_rank_on_rccl_force_dist():
+    """RCCL loaded and executed at last: `bench.py --force-dist --allgather-obs rccl` under
+    torch.distributed.run with ONE rank -- `init_process_group("nccl", device_id=...)`, the barriers and the all_gather of the
+    max-over-ranks timing, and `all_gather_into_tensor` of the observations after every step (checked against the owner's
+    block) run on this ROCm's librccl.  Says nothing about xGMI or N > 1."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29741", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "4",
+           "--envs-per-gpu", "65536", "--force-dist", "--allgather-obs", "rccl", "--no-traffic", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=_clean_env())
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["collective_backend"] == "nccl" and d["n_gpus"] == 1 and d["ranks"] == 1
+    assert d["allgather_ms"] > 0 and len(d["per_rank_ms_per_step"]) == 1 and "rccl" in d["config"]["parallelism"]
+
+
+_RCCL_TRAINER_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+import phoenix_drone_simulation_amd as pds
+import phoenix_drone_simulation_amd.ppo as ppo
+dev = torch.device("cuda", int(os.environ["LOCAL_RANK"]))
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", device_id=dev)
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+calls = dict(all_reduce=0, broadcast=0)
+for name in calls:
+    def wrap(fn, name=name):
+        def f(*a, **k):
+            calls[name] += 1
+            assert a[0].is_cuda
+            return fn(*a, **k)
+        return f
+    setattr(dist, name, wrap(getattr(dist, name)))
+ppo.FORCE_COLLECTIVES = True
+res = {{}}
+for fused in (True, False):
+    env = pds.make_sharded("DroneHoverSimpleEnv-v0", 2048, rank=0, world_size=1, device=dev, seed=7)
+    tr = ppo.PPOTrainer(env, rollout_len=16, epochs=4, train_pi_iterations=4, train_v_iterations=2, num_mini_batches=4, seed=7, fused=fused)
+    before = dict(calls)
+    info = tr.learn_one_epoch()
+    torch.cuda.synchronize()
+    n_ar = calls["all_reduce"] - before["all_reduce"]
+    # 4 policy + 8 value gradient averages, 4 running-statistics reductions (mean / var of obs and returns), the NaN flag, the stats
+    assert n_ar >= 4 + 8 + 4 + 2, (fused, n_ar)
+    res[fused] = (info["loss_pi"], info["loss_v"], info["ep_len"])
+    env.close()
+assert calls["broadcast"] > 0  # sync_params
+# the collectives over one rank change nothing: same epoch without them
+ppo.FORCE_COLLECTIVES = False
+env = pds.make_sharded("DroneHoverSimpleEnv-v0", 2048, rank=0, world_size=1, device=dev, seed=7)
+tr = ppo.PPOTrainer(env, rollout_len=16, epochs=4, train_pi_iterations=4, train_v_iterations=2, num_mini_batches=4, seed=7, fused=True,
+                    overlap_value_update=False)
+info = tr.learn_one_epoch()
+assert abs(info["loss_pi"] - res[True][0]) < 1e-6 and abs(info["loss_v"] - res[True][1]) < 1e-5 * abs(info["loss_v"]) and info["ep_len"] == res[True][2], (info, res)
+dist.barrier()
+dist.destroy_process_group()
+print("rccl trainer ok", calls)
+"""
+
+
+def test_trainer_epoch_with_the_collectives_on_rccl_one_rank(tmp_path):
+    """One `PPOTrainer.learn_one_epoch()` per path (fused kernels / PyTorch ops) with every collective of the multi-GPU trainer
+    executed on the `nccl` (= RCCL) backend over one rank: sync_params broadcasts, the flattened gradient all-reduce of both
+    networks, the running-statistics all-reduces, the NaN-flag and episode-statistics reductions (utils/mpi_tools.py:30-44,
+    utils/online_mean_std.py:54-95).  Over one rank they are identities: the epoch's losses equal a run without them."""
+    script = tmp_path / "rccl_trainer.py"
+    script.write_text(_RCCL_TRAINER_WORKER.format(root=ROOT))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29743", str(script)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=_clean_env())
+    assert out.returncode == 0 and "rccl trainer ok" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
