@@ -304,7 +304,8 @@ int pds_gae(const float *d_rew, const float *d_val, const uint8_t *d_terminated,
 
 /* ---- caller-side dense kernels on the f32 matrix cores ----------------------
  * A 3-layer MLP in torch's nn.Linear layout (weights [out][in] row-major, device pointers):
- * y = W3 act(W2 act(W1 x + b1) + b2) + b3; d_in, h1, h2 <= 64, d_out <= 8; activation 0 relu, 1 tanh.
+ * y = W3 act(W2 act(W1 x + b1) + b2) + b3; d_in <= 192 (more than 64 inputs -- observation_history_size >= 4,
+ * envs/base.py:303-319 -- run the K-tiled kernels of csrc/pds_mlp_wide.hip), h1, h2 <= 64, d_out <= 8; activation 0 relu, 1 tanh.
  * Mirrors build_mlp_network / MLPGaussianActor.net / MLPCritic.net (algs/core.py:65-103, 228-311). */
 typedef struct pds_mlp {
   int32_t d_in, h1, h2, d_out, activation;
@@ -329,6 +330,21 @@ int pds_rollout(pds_handle *h, int T, const pds_mlp *pi, const pds_mlp *vf, cons
                 float *d_obs_buf, float *d_act_buf, float *d_logp_buf, float *d_val_buf, float *d_rew_buf,
                 uint8_t *d_term_buf, uint8_t *d_trunc_buf, float *d_cost_buf, float *d_fval_buf, float *d_last_val,
                 float *d_ep_ret, float *d_ep_len, float *d_stats, void *stream);
+
+/* The same for observation histories other than 2 (observation_history_size = H, envs/base.py:44, 303-319, 417-431;
+ * csrc/pds_rollout_hist.h): the actor reads the last `history` [o, u] halves of every env, history x half <= 192 inputs.
+ * In the kernel: actor, sampling, env.step (bitwise pds_step), the history update of pds_history_advance, the episode
+ * bookkeeping.  NOT in the kernel: the critic -- the caller evaluates V over d_obs_buf afterwards (pds_mlp_forward), and
+ * over d_fin_rows: the final histories of the envs whose path bootstraps with V (the TimeLimit cut it, or it finished on
+ * step T - 1: algs/iwpg/iwpg.py:374-379), one slot list per env -- d_fin_rows [slots, N, history x half], d_fin_step
+ * [slots, N] = the step t whose d_fval_buf[t] entry the row's value is; the caller presets d_fin_step to -1 (unused);
+ * slots >= T / max_episode_steps + 2.  d_obs_buf [T + 1, N, history x half]: row 0 = the histories on entry, rows 1..T
+ * written.  Other buffers as pds_rollout.  PDS_EUNSUPPORTED where no kernel is built (the per-step path gives the same bits). */
+int pds_rollout_history(pds_handle *h, int T, int history, const pds_mlp *pi, const float *d_mean, const float *d_std, float eps,
+                        const float *d_log_std, uint64_t seed, const uint64_t *d_call_base, uint64_t call_offset,
+                        int deterministic, float *d_obs_buf, float *d_act_buf, float *d_logp_buf, float *d_rew_buf,
+                        uint8_t *d_term_buf, uint8_t *d_trunc_buf, float *d_cost_buf, float *d_fin_rows, int32_t *d_fin_step,
+                        int slots, float *d_ep_ret, float *d_ep_len, float *d_stats, void *stream);
 
 /* number of parameters; flat gradient layout = [W1, b1, W2, b2, W3, b3] (torch parameter order) */
 int pds_mlp_param_count(const pds_mlp *m);

@@ -14,11 +14,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 _UNITS = ["pds_task_hover.hip", "pds_task_circle.hip", "pds_task_takeoff.hip", "pds_task_hover_lat.hip",
           "pds_task_circle_lat.hip", "pds_task_hover_pid.hip", "pds_task_circle_pid.hip", "pds_task_takeoff_lat.hip",
-          "pds_mlp.hip", "pds_task_hover_hold.hip", "pds_task_circle_hold.hip", "pds_task_takeoff_hold.hip",
+          "pds_mlp.hip", "pds_mlp_wide.hip", "pds_task_hover_hold.hip", "pds_task_circle_hold.hip", "pds_task_takeoff_hold.hip",
           "pds_task_hover_pid_ge.hip", "pds_task_circle_pid_ge.hip", "pds_rollout_hover_pwm.hip", "pds_rollout_circle_pwm.hip", "pds_rollout_hover_lat.hip", "pds_rollout_circle_lat.hip",
           "pds_api.hip", "pds_rollout_hover.hip", "pds_rollout_circle.hip", "pds_rollout_takeoff.hip",
+          "pds_rollout_hist_hover.hip", "pds_rollout_hist_circle.hip", "pds_rollout_hist_takeoff.hip",
           "pds_gae.hip", "pds_train.hip", "pds_history.hip"]  # longest first
-_HEADERS = ["pds_device.h", "pds_types.h", "pds_reset.h", "pds_step.h", "pds_mlp_fwd.h", "pds_rollout.h"]
+_HEADERS = ["pds_device.h", "pds_types.h", "pds_reset.h", "pds_step.h", "pds_mlp_fwd.h", "pds_rollout.h", "pds_rollout_hist.h", "pds_mlp_common.h"]
 _DEPS = [os.path.join(_CSRC, f) for f in _UNITS + _HEADERS] + [os.path.join(_HERE, "..", "include", "pds.h")]
 _LIB = os.path.join(_HERE, "libpds_hip.so")
 _OBJ = os.path.join(_HERE, "build")

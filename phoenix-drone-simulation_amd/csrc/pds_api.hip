@@ -719,6 +719,10 @@ extern "C" int pds_bytes_per_env_step_k(const pds_handle *h, int k_steps) {
   if (!h || k_steps < 1) return PDS_EINVAL;
   const LaunchFlags &f = h->flags;
   const int full = pds_bytes_per_env_step(h);
+  // the PID control modes have no K-step kernel: pds_step_k loops over pds_step for them (below), every step moves the
+  // single-step kernel's bytes (rounds 2-5 priced those rows with the K-step formula: 0.26-0.36 "of their own roofline"
+  // for what is pds_step at 0.57-0.86)
+  if (f.ctrl != 0) return full;
   const int stream = 16 + 4 * h->obs_dim + 10 + (f.lat ? 32 * h->cfg.aggregate_phy_steps : 0);
   // once per launch: the state read + written, both ring slots and the randomised parameters written back
   // (+ the kept noisy observation, which the K-step kernel reads from and leaves in oh0-2: materialize_oh_kernel)
@@ -952,6 +956,66 @@ extern "C" int pds_rollout(pds_handle *h, int T, const pds_mlp *pi, const pds_ml
   else if (h->cfg.task == PDS_TASK_CIRCLE) ok = launch_rollout_circle(h->flags, grid, (hipStream_t)stream, ra);
   else ok = launch_rollout_takeoff(h->flags, grid, (hipStream_t)stream, ra);
   if (!ok) return fail(h, PDS_EHIP, "pds_rollout: rollout_supported() and the launchers disagree");
+  PDS_HIP(h, hipGetLastError());
+  h->tick += (uint64_t)T;
+  return PDS_OK;
+}
+
+// One launch per rollout for observation histories other than 2: csrc/pds_rollout_hist.h.
+extern "C" int pds_rollout_history(pds_handle *h, int T, int history, const pds_mlp *pi, const float *d_mean, const float *d_std,
+                                   float eps, const float *d_log_std, uint64_t seed, const uint64_t *d_call_base,
+                                   uint64_t call_offset, int deterministic, float *d_obs_buf, float *d_act_buf,
+                                   float *d_logp_buf, float *d_rew_buf, uint8_t *d_term_buf, uint8_t *d_trunc_buf,
+                                   float *d_cost_buf, float *d_fin_rows, int32_t *d_fin_step, int slots, float *d_ep_ret,
+                                   float *d_ep_len, float *d_stats, void *stream) {
+  if (!h) return PDS_EINVAL;
+  if (T < 1 || history < 1 || slots < 1) return fail(h, PDS_EINVAL, "pds_rollout_history: T %d, history %d, slots %d", T, history, slots);
+  if (!pi || !d_log_std || !d_obs_buf || !d_act_buf || !d_logp_buf || !d_rew_buf || !d_term_buf || !d_trunc_buf || !d_cost_buf ||
+      !d_fin_rows || !d_fin_step || !d_ep_ret || !d_ep_len || !d_stats)
+    return fail(h, PDS_EINVAL, "pds_rollout_history: NULL pointer");
+  if ((d_mean == nullptr) != (d_std == nullptr)) return fail(h, PDS_EINVAL, "pds_rollout_history: mean and std come together");
+  if (!h->was_reset) return fail(h, PDS_EINVAL, "pds_rollout_history before pds_reset");
+  if (!h->cfg.auto_reset) return fail(h, PDS_EUNSUPPORTED, "pds_rollout_history needs a handle created with auto_reset = 1");
+  const int half = h->obs_dim / 2, HS = history * half;
+  if (HS > 192) return fail(h, PDS_EUNSUPPORTED, "pds_rollout_history: %d x %d = %d network inputs (<= 192)", history, half, HS);
+  if (pi->d_in != HS || pi->h1 < 1 || pi->h1 > 64 || pi->h2 < 1 || pi->h2 > 64 || (pi->activation != 0 && pi->activation != 1) ||
+      !pi->w1 || !pi->b1 || !pi->w2 || !pi->b2 || !pi->w3 || !pi->b3 || pi->d_out != 4)
+    return fail(h, PDS_EINVAL, "pds_rollout_history: actor shape (d_in must be history x half = %d, hidden <= 64, d_out 4)", HS);
+  // max_episode_steps bounds how often the TimeLimit can cut one env within T steps; + the rollout's last step
+  if (slots < T / h->cfg.max_episode_steps + 2)
+    return fail(h, PDS_EINVAL, "pds_rollout_history: slots %d < T / max_episode_steps + 2 = %d", slots, T / h->cfg.max_episode_steps + 2);
+  if ((((uintptr_t)d_act_buf) & 15u) || (((uintptr_t)d_obs_buf) & 3u)) return fail(h, PDS_EINVAL, "pds_rollout_history: alignment");
+  // support is decided BEFORE the handle is touched (a refused call leaves it as it was)
+  if (!rollout_hist_supported(h->cfg.task, h->flags))
+    return fail(h, PDS_EUNSUPPORTED, "pds_rollout_history: no kernel for this env configuration (built: control_mode PWM without latency ring, "
+                                     "Kalman hold or ground effect; noise off or the reference's default; TakeOff without motor dynamics) "
+                                     "-- the per-step kernels give the same bits");
+  DeviceGuard guard(h->cfg.device);
+  PDS_HIP(h, guard.err);
+  RolloutHistArgs ra;
+  memset(&ra, 0, sizeof(ra));
+  base_args(h, ra.s);
+  ra.s.actions = reinterpret_cast<const float4 *>(d_act_buf);  // (load_env's action slot: valid memory, value unused)
+  ra.s.obs = nullptr;                                           // (the kernel's own [o(k), o(k + 1)] row stays in LDS)
+  ra.s.reward = d_rew_buf; ra.s.term = d_term_buf; ra.s.trunc = d_trunc_buf; ra.s.cost = d_cost_buf;
+  ra.s.final_obs = nullptr;
+  ra.s.k_steps = T;
+  ra.pi = *pi;
+  ra.mean = d_mean; ra.stdv = d_std; ra.eps = eps; ra.log_std = d_log_std;
+  ra.seed = seed; ra.call_base = reinterpret_cast<const unsigned long long *>(d_call_base); ra.call_offset = call_offset;
+  ra.deterministic = deterministic; ra.T = T; ra.H = history; ra.half = half; ra.slots = slots;
+  ra.obs_buf = d_obs_buf; ra.act_buf = d_act_buf; ra.logp_buf = d_logp_buf;
+  ra.fin_rows = d_fin_rows; ra.fin_step = d_fin_step;
+  ra.ep_ret = d_ep_ret; ra.ep_len = d_ep_len; ra.stats = d_stats;
+  const long long n = h->cfg.num_envs;
+  const dim3 grid((unsigned)((n + kWave - 1) / kWave));
+  if (const int rc = materialize_kept_obs(h, (hipStream_t)stream)) return rc;  // (StoredOh, like pds_rollout)
+  const int hn = rollout_hist_tiles(HS);
+  bool ok;
+  if (h->cfg.task == PDS_TASK_HOVER) ok = launch_rollout_hist_hover(h->flags, hn, grid, (hipStream_t)stream, ra);
+  else if (h->cfg.task == PDS_TASK_CIRCLE) ok = launch_rollout_hist_circle(h->flags, hn, grid, (hipStream_t)stream, ra);
+  else ok = launch_rollout_hist_takeoff(h->flags, hn, grid, (hipStream_t)stream, ra);
+  if (!ok) return fail(h, PDS_EHIP, "pds_rollout_history: rollout_hist_supported() and the launchers disagree");
   PDS_HIP(h, hipGetLastError());
   h->tick += (uint64_t)T;
   return PDS_OK;

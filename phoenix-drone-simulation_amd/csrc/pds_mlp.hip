@@ -28,76 +28,9 @@
 // Round 3: the PPO gradient of the reference's default policy (50-50 relu) runs on ppo_split_kernel below instead --
 // the two waves of a SIMD take different ROLES on the same tiles (forward / loss / small GEMMs vs. the large
 // weight-gradient GEMMs) so that neither carries 128 accumulator registers through phases that do not need them.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
+#include "pds_mlp_common.h"
 
-#include "../../include/pds.h"
-
-namespace pds_mlp_detail {  // named (not anonymous) so that profiler kernel names are readable
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int kTS = 16;            // samples per wave tile (= N of every activation GEMM)
-constexpr int kTW = 16;            // feature tile width
-constexpr int kNT = 4;             // 16-wide tiles per 64-wide dimension
-constexpr int kS = 68;             // image row stride: 16-B aligned rows (b128 access) and 4 * kS == 16 (mod 32),
-                                   // so the sample-slot walk of the dword reads below is bank-conflict free
-constexpr int kSY = 20;            // row stride of the [16 samples][16 outputs] output-gradient image (same rule)
-constexpr int kMaxDim = 64;        // d_in, h1, h2 <= 64
-constexpr int kMaxOut = 8;         // d_out <= 8
-constexpr int kWaves = 8;          // waves per block, two per SIMD; 1 block per CU (LDS-bound)
-constexpr int kStats = 4;          // loss sum, ratio sum, kl sum, sample count
-constexpr int kWaveFloats = 3 * kTS * kS + kTS * kSY;
-
-enum { LOSS_NONE = 0, LOSS_PPO = 1, LOSS_MSE = 2 };
-
-struct Args {
-  pds_mlp m;
-  const float *x;            // [rows, d_in]
-  const int64_t *index;      // optional gather: sample g reads row index[g]
-  long long B;               // samples
-  const float *mean, *stdv;  // optional input standardisation (x - mean) / (std + eps)
-  float eps;
-  float *y;                  // forward output [B, d_out]
-  const float *act, *adv, *logp_old, *log_std;  // PPO
-  const float *target;                          // MSE
-  float clip;
-  float *partials;           // [waves of the grid][pstride]
-  int pstride;
-};
-
-// ACT 0 relu, 1 tanh (branch-free: 1 - 2 / (e^{2v} + 1) on v_exp_f32 / v_rcp_f32, abs error < 3e-7)
-template <int ACT>
-__device__ __forceinline__ float act_fn(float v) {
-  if (ACT == 0) return fmaxf(v, 0.f);
-  return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * v) + 1.f);
-}
-// derivative expressed through the activation's OUTPUT h (relu: h > 0; tanh: 1 - h^2)
-template <int ACT>
-__device__ __forceinline__ float act_grad(float h) { return ACT == 0 ? (h > 0.f ? 1.f : 0.f) : 1.f - h * h; }
-
-// flat parameter layout == torch's nn.Sequential order: W1 [h1][d_in], b1, W2 [h2][h1], b2, W3 [d_out][h2], b3
-struct Offsets {
-  int w1, b1, w2, b2, w3, b3, total;
-};
-__host__ __device__ inline Offsets offsets(const pds_mlp &m) {
-  Offsets o;
-  o.w1 = 0;
-  o.b1 = o.w1 + m.h1 * m.d_in;
-  o.w2 = o.b1 + m.h1;
-  o.b2 = o.w2 + m.h2 * m.h1;
-  o.w3 = o.b2 + m.h2;
-  o.b3 = o.w3 + m.d_out * m.h2;
-  o.total = o.b3 + m.d_out;
-  return o;
-}
-
-#define PDS_WAVE_SYNC()                                          \
-  do {                                                           \
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       \
-    __builtin_amdgcn_wave_barrier();                             \
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       \
-  } while (0)
+namespace pds_mlp_detail {
 
 #ifndef PDS_SPLIT_WRES
 #define PDS_SPLIT_WRES 1
@@ -134,7 +67,6 @@ __host__ __device__ inline Offsets offsets(const pds_mlp &m) {
 #ifndef PDS_MLP_EDGE
 #define PDS_MLP_EDGE 1  // A/B: 0 = the fourth output tile of the 50-wide layers on the matrix cores as well
 #endif
-#define PDS_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 // v_mfma_f32_4x4x1_16b_f32: 16 independent 4 x 4 outer products per instruction (block b = lane / 4: D_b[i][j] += A_b[i] B_b[j],
 // lane 4 b + i supplies A_b[i], lane 4 b + j supplies B_b[j] and holds D_b[0..3][j] in its four registers), 8 cycles
 // against 32 for a 16x16x4 tile at the same flop rate: the right shape for a 4-row or 4-column STRIP of a weight
@@ -154,9 +86,6 @@ __device__ __forceinline__ pds_f32x4_ pds_no_mfma(float a, float b, pds_f32x4_ c
 #else
 #define PDS_MFMA_F(a, b, c) PDS_MFMA(a, b, c)
 #endif
-
-__device__ __forceinline__ f32x4 lds4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
-__device__ __forceinline__ void sts4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
 
 // Z^T tile `it` (16 output features x 16 samples) = W[16 it .. +16][:] * In^T, with In^T given as NK
 // register tiles in the C/D layout: the k-slot (step j, lane group h) of feature tile kt carries
@@ -1373,7 +1302,7 @@ inline bool two_hidden_steps(const pds_mlp &m) { return m.h1 == m.h2 && m.h1 > 4
 inline bool two_input_steps(const pds_mlp &m) { return m.d_in > 32 && m.d_in <= 48 && last_steps(m.d_in) == 2; }
 
 int check(const pds_mlp *m) {
-  if (!m || m->d_in < 1 || m->d_in > kMaxDim || m->h1 < 1 || m->h1 > kMaxDim || m->h2 < 1 || m->h2 > kMaxDim ||
+  if (!m || m->d_in < 1 || m->d_in > kMaxDimIn || m->h1 < 1 || m->h1 > kMaxDim || m->h2 < 1 || m->h2 > kMaxDim ||
       m->d_out < 1 || m->d_out > kMaxOut || (m->activation != 0 && m->activation != 1) || !m->w1 || !m->b1 ||
       !m->w2 || !m->b2 || !m->w3 || !m->b3)
     return PDS_EINVAL;
@@ -1404,7 +1333,9 @@ extern "C" int pds_mlp_param_count(const pds_mlp *m) {
 
 extern "C" int64_t pds_mlp_workspace_floats(const pds_mlp *m) {
   if (check(m) != PDS_OK) return PDS_EINVAL;
-  return (int64_t)kMaxGridBlocks * (offsets(*m).total + kStats);
+  // (more than 64 inputs: one partial per WAVE of csrc/pds_mlp_wide.hip's grid)
+  const int64_t parts = m->d_in > kMaxDim ? (int64_t)kWideMaxBlocks * kWideWaves : kMaxGridBlocks;
+  return parts * (offsets(*m).total + kStats);
 }
 
 extern "C" int pds_mlp_forward(const pds_mlp *m, const float *d_x, const int64_t *d_index, int64_t B,
@@ -1414,6 +1345,10 @@ extern "C" int pds_mlp_forward(const pds_mlp *m, const float *d_x, const int64_t
   a.m = *m; a.x = d_x; a.index = d_index; a.B = B; a.mean = d_mean; a.stdv = d_std; a.eps = eps; a.y = d_y;
   const dim3 g(grid_blocks(B)), b(kWaves * 64);
   hipStream_t s = (hipStream_t)stream;
+  if (m->d_in > kMaxDim) {  // the K-tiled first layer (csrc/pds_mlp_wide.hip)
+    launch_wide(LOSS_NONE, a, s);
+    return hipGetLastError() == hipSuccess ? PDS_OK : PDS_EHIP;
+  }
   const bool wide = m->d_in > 3 * kTW;
   const bool ki2 = two_input_steps(*m), kh2 = two_hidden_steps(*m);
   if (m->activation == 0) {
@@ -1441,6 +1376,7 @@ static int launch_grad(int loss, Args &a, float *d_grads, float *d_stats, float 
   // takes the 4-tile input variant); per-lane partial sums otherwise (e.g. the 64-64 critic)
   const bool gb = a.m.h1 == kMaxDim || a.m.h2 == kMaxDim || a.m.d_in == kMaxDim;
   const bool wide = gb ? a.m.d_in > 3 * kTW : a.m.d_in >= 3 * kTW;
+  const bool ktiled = a.m.d_in > kMaxDim;  // csrc/pds_mlp_wide.hip: one partial per wave of its grid
 #define PDS_MLP_LAUNCH(L, A)                                                             \
   do {                                                                                   \
     if (gb) {                                                                            \
@@ -1453,7 +1389,9 @@ static int launch_grad(int loss, Args &a, float *d_grads, float *d_stats, float 
   } while (0)
   // the reference's default policy (algs/ppo/defaults.py: 50-50 relu) on 34 (Hover, noisy) / 40 / 42 / 48
   // inputs: hidden k-tile 3 holds features 48, 49 only, input k-tile 2 of the 34-input net 32, 33 only
-  if (PDS_MLP_SPLIT && loss == LOSS_PPO && a.m.activation == 0 && !gb && !wide && two_hidden_steps(a.m) &&
+  if (ktiled) {
+    blocks = launch_wide(loss, a, s);
+  } else if (PDS_MLP_SPLIT && loss == LOSS_PPO && a.m.activation == 0 && !gb && !wide && two_hidden_steps(a.m) &&
       a.index == nullptr && a.mean == nullptr) {
     // wave roles (ppo_split_kernel): a block takes 4 tiles at a time, not 8
     const long long tiles = (a.B + kTS - 1) / kTS;

@@ -128,6 +128,80 @@ __device__ __forceinline__ f32x4 forward16(const NetLds &w, const f32x4 (&xin)[N
   return c + b;
 }
 
+// The same pass for a first layer that is K-tiled over NIN input tiles with an LDS image of row stride S1 = 16 NIN + 4
+// (csrc/pds_mlp_wide.hip mlp_wide_kernel<LOSS_NONE>, pds_mlp_forward with more than 64 inputs): same k-order, same bits.
+template <int NK, int S>
+__device__ __forceinline__ void gemm_wt2s(const float *Ws, int it, const f32x4 (&in)[NK], int n, int g, f32x4 &c0, f32x4 &c1) {
+  c0 = (f32x4)(0.f);
+  c1 = (f32x4)(0.f);
+  const float *wp = Ws + (it * kTW + n) * S + 4 * g;
+#pragma unroll
+  for (int kt = 0; kt < NK; ++kt) {
+    const f32x4 a0 = lds4(wp + kt * kTW), a1 = lds4(wp + kTW * S + kt * kTW);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      c0 = PDS_MLPF_MFMA(a0[j], in[kt][j], c0);
+      c1 = PDS_MLPF_MFMA(a1[j], in[kt][j], c1);
+    }
+  }
+}
+// w.W1: [64][S1] image; w.W2 / w.W3 / biases as in NetLds.  KJH as in forward16.
+template <int ACT, int NIN, int S1, int KJH = 4>
+__device__ __forceinline__ f32x4 forward16_wide(const NetLds &w, const f32x4 (&xin)[NIN], int n, int g) {
+  f32x4 h1r[kNT], h2r[kNT], cc[kNT];
+#pragma unroll
+  for (int it = 0; it < kNT; it += 2) gemm_wt2s<NIN, S1>(w.W1, it, xin, n, g, cc[it], cc[it + 1]);
+#pragma unroll
+  for (int it = 0; it < kNT; ++it) {
+    const f32x4 b = lds4(w.b1 + it * kTW + 4 * g);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) h1r[it][q] = act_fn<ACT>(cc[it][q] + b[q]);
+  }
+#pragma unroll
+  for (int it = 0; it < kNT; it += 2) gemm_wt2<kNT, KJH>(w.W2, it, h1r, n, g, cc[it], cc[it + 1]);
+#pragma unroll
+  for (int it = 0; it < kNT; ++it) {
+    const f32x4 b = lds4(w.b2 + it * kTW + 4 * g);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) h2r[it][q] = act_fn<ACT>(cc[it][q] + b[q]);
+  }
+  const f32x4 c = gemm_wt<kNT, KJH>(w.W3, 0, h2r, n, g);
+  const f32x4 b = lds4(w.b3 + 4 * g);
+  return c + b;
+}
+// LDS image of a network whose first layer has NIN input tiles (W1 row stride S1 = 16 NIN + 4)
+template <int NIN>
+constexpr int net_floats_wide() { return kMaxDim * (kTW * NIN + 4) + kMaxDim * kS + kTW * kS + 2 * kMaxDim + kTW; }
+template <int NIN>
+__device__ __forceinline__ NetLds net_lds_wide(float *base) {
+  NetLds n;
+  n.W1 = base;
+  n.W2 = n.W1 + kMaxDim * (kTW * NIN + 4);
+  n.W3 = n.W2 + kMaxDim * kS;
+  n.b1 = n.W3 + kTW * kS;
+  n.b2 = n.b1 + kMaxDim;
+  n.b3 = n.b2 + kMaxDim;
+  return n;
+}
+template <int NIN>
+__device__ __forceinline__ void stage_net_wide(const pds_mlp &m, const NetLds &n, int tid, int nthreads) {
+  constexpr int S1 = kTW * NIN + 4;
+  for (int i = tid; i < kMaxDim * S1; i += nthreads) {
+    const int r = i / S1, k = i - r * S1;
+    n.W1[i] = (r < m.h1 && k < m.d_in) ? m.w1[r * m.d_in + k] : 0.f;
+  }
+  for (int i = tid; i < kMaxDim * kS; i += nthreads) {
+    const int r = i / kS, k = i - r * kS;
+    n.W2[i] = (r < m.h2 && k < m.h1) ? m.w2[r * m.h1 + k] : 0.f;
+    if (i < kTW * kS) n.W3[i] = (r < m.d_out && k < m.h2) ? m.w3[r * m.h2 + k] : 0.f;
+  }
+  for (int i = tid; i < kMaxDim; i += nthreads) {
+    n.b1[i] = i < m.h1 ? m.b1[i] : 0.f;
+    n.b2[i] = i < m.h2 ? m.b2[i] : 0.f;
+    if (i < kTW) n.b3[i] = i < m.d_out ? m.b3[i] : 0.f;
+  }
+}
+
 // run-time shape -> the instantiation with the fewest k-steps (data steps of the last k-tile of a dimension `dim`
 // that spans `tiles` 16-wide tiles; 4 when the tile is full or the dimension ends in an earlier tile)
 __device__ __forceinline__ int last_tile_steps(int dim, int tiles) {

@@ -506,6 +506,9 @@ constexpr bool four_block_variant() {
   return regen_obs_variant<V>() && V::TASK == PDS_TASK_HOVER && !(V::MOTOR && V::DR) && V::CTRL == 0 && !V::LAT;
 }
 
+#ifndef PDS_SPLIT_RESET_EXP
+#define PDS_SPLIT_RESET_EXP 0
+#endif
 // What a caller that goes on with the step's results in registers gets back (csrc/pds_rollout.h).
 struct StepOut {
   float reward;
@@ -761,7 +764,9 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
   // ---- auto-reset.  ~2 % of the envs finish per step under random actions, i.e. 3 of 4 waves
   // hold one or two finished envs.  Their last observation goes to final_obs (below, out of the
   // LDS tile); the reset itself: see RM_* above.
-  const bool need_reset = a.auto_reset && (done || trunc) && active;
+  // PDS_SPLIT_RESET_EXP (profiling builds): the single-step kernels that reset in place are compiled WITHOUT their reset --
+  // what the step alone needs in registers / LDS (the reset as a follow-up launch: DESIGN section 9, round 6)
+  const bool need_reset = (PDS_SPLIT_RESET_EXP && STORE && RM == RM_INLINE) ? false : (a.auto_reset && (done || trunc) && active);
   const unsigned long long reset_mask = __ballot(need_reset);  // wave-uniform
   const unsigned long long done_mask = (a.final_obs != nullptr || fin_lds != nullptr) ? reset_mask : 0ull;  // -> final_obs
   if (so != nullptr) { so->reward = reward; so->done = done; so->trunc = trunc; }
@@ -981,7 +986,8 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
     }
     if constexpr (!STORE) { PDS_STAMP(7); }
     const long long left = rem - pass * TR;
-    if (left > 0)
+    // (the history rollout, csrc/pds_rollout_hist.h, keeps the row in LDS only: obs == nullptr; compile-time true for pds_step)
+    if (left > 0 && (STORE || a.obs != nullptr))
       flush_tile<D, TR, saddr_variant<V>()>(tile, a.obs + (o1 + wave_base + pass * TR) * D, left >= TR ? TR : (int)left, lane);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();  // the tile is rewritten by the next pass / the reset drain / the next step
@@ -1078,7 +1084,7 @@ PDS_DEV void prefetch_kernargs() {
   __shared__ __attribute__((aligned(16))) float park_all[kParkFloats_ > 0 ? (kBlock / kWave) * kParkFloats_ : 4]; \
   const float2 *ref_lds = nullptr; /* (the Circle table of rounds 1-2: the reference point is evaluated now) */ \
   __shared__ uint32_t queue_all[(kBlock / kWave) * kQueueCap];                                        \
-  constexpr int kScratchU4_ = (RM == RM_MERGED) ? kMergedScratchU4 : ((RM == RM_INLINE && inline_coop_variant<V>()) ? inline_envs<V, ST>() * scratch_stride<V>() : 0); \
+  constexpr int kScratchU4_ = (RM == RM_MERGED) ? kMergedScratchU4 : ((RM == RM_INLINE && inline_coop_variant<V>() && !(PDS_SPLIT_RESET_EXP && ST)) ? inline_envs<V, ST>() * scratch_stride<V>() : 0); \
   __shared__ U4 scratch_all[kScratchU4_ > 0 ? (kBlock / kWave) * kScratchU4_ : 1];                     \
   const int tid = threadIdx.x;                                                                         \
   const int lane = tid & (kWave - 1);                                                                  \

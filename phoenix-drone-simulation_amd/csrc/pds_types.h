@@ -389,6 +389,39 @@ inline bool rollout_supported(int task, const LaunchFlags &f) {
   if (f.ctrl != 0) return (lean || full) && task != PDS_TASK_TAKEOFF;
   return !(task == PDS_TASK_TAKEOFF && f.motor);  // control_mode PWM: every noise setting
 }
+// ---- the one-launch rollout for observation histories other than 2 (csrc/pds_rollout_hist.h) ----
+struct RolloutHistArgs {
+  StepArgs s;  // FIRST member (reload_args); reward / term / trunc / cost point at the [T, N] rollout buffers; obs unused
+  pds_mlp pi;
+  const float *mean, *stdv;
+  float eps;
+  const float *log_std;
+  unsigned long long seed;
+  const unsigned long long *call_base;
+  unsigned long long call_offset;
+  int deterministic, T, H, half, slots;
+  float *obs_buf;            // [T + 1, N, H half]
+  float *act_buf, *logp_buf;
+  float *fin_rows;           // [slots, N, H half]
+  int *fin_step;             // [slots, N]: step whose fval entry the row's value is, -1 = unused (set by the caller)
+  float *ep_ret, *ep_len, *stats;
+};
+static_assert(offsetof(RolloutHistArgs, s) == 0, "reload_args() reads the head of the kernarg segment as a StepArgs");
+
+// The env configurations the history rollout is built for: control_mode PWM, no latency ring, no Kalman hold, no ground effect;
+// noise {none, reference default (DR + thrust noise + observation noise)} x {with, without motor dynamics; TakeOff: without}.
+inline bool rollout_hist_supported(int task, const LaunchFlags &f) {
+  if (f.ge || f.hold || f.lat || f.ctrl != 0) return false;
+  const bool lean = !f.dr && !f.tn && !f.on, full = f.dr && f.tn && f.on;
+  if (!lean && !full) return false;
+  return !(task == PDS_TASK_TAKEOFF && f.motor);
+}
+// input tiles the kernels are instantiated for (d_in <= 64 / 96 / 128 / 192)
+inline int rollout_hist_tiles(int d_in) { return d_in <= 64 ? 4 : (d_in <= 96 ? 6 : (d_in <= 128 ? 8 : 12)); }
+
+bool launch_rollout_hist_hover(const LaunchFlags &f, int hn, dim3 grid, hipStream_t s, const RolloutHistArgs &ra);
+bool launch_rollout_hist_circle(const LaunchFlags &f, int hn, dim3 grid, hipStream_t s, const RolloutHistArgs &ra);
+bool launch_rollout_hist_takeoff(const LaunchFlags &f, int hn, dim3 grid, hipStream_t s, const RolloutHistArgs &ra);
 bool launch_rollout_hover(const LaunchFlags &f, dim3 grid, hipStream_t s, const RolloutArgs &ra);
 bool launch_rollout_circle(const LaunchFlags &f, dim3 grid, hipStream_t s, const RolloutArgs &ra);
 bool launch_rollout_takeoff(const LaunchFlags &f, dim3 grid, hipStream_t s, const RolloutArgs &ra);

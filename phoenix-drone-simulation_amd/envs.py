@@ -284,6 +284,18 @@ class DroneVecEnv:
         self._hist = fresh if mask is None else torch.where(mask.bool()[:, None, None], fresh, self._hist)
         return self._hist.reshape(self.num_envs, -1)
 
+    def adopt_history(self, flat):
+        """Take `flat` [N, H * half] as the current observation histories (the one-launch rollout, pds_rollout_history, advanced
+        them in the kernel)."""
+        if self._hist is None:
+            raise ValueError("observation_history_size == 2: the handle keeps the observation itself")
+        own = getattr(self, "_hist_own", None)
+        if own is None:
+            own = self._hist_own = torch.empty(self.num_envs, self.observation_history_size, self._half,
+                                               dtype=torch.float32, device=self.device)
+        own.copy_(flat.view_as(own))
+        self._hist = own
+
     def _advance_history(self, ret):
         """One launch of pds_history_advance (csrc/pds_history.hip): shift the [N, H, half] history by the
         step's newest half, write the final history of the envs that finished and restart theirs from the reset

@@ -59,7 +59,7 @@ class FusedMLP:
         self._bind()
         n = self.lib.pds_mlp_param_count(C.byref(m))
         if n < 0:
-            raise ValueError("layer sizes outside the fused kernels' range (d_in, h1, h2 <= 64, d_out <= 8)")
+            raise ValueError("layer sizes outside the fused kernels' range (d_in <= 192, h1, h2 <= 64, d_out <= 8)")
         dev = self.params[0].device
         self.flat_grad = torch.zeros(n, device=dev)
         off = 0
@@ -180,6 +180,24 @@ def fused_rollout(env, fm_pi, fm_v, T, mean, std, eps, log_std, seed, call_offse
                                  _ptr(stats), FusedMLP._stream(obs_buf))
     if rc != native.OK:
         native.check(env._handle, rc, "pds_rollout")
+
+
+def fused_rollout_history(env, fm_pi, T, H, mean, std, eps, log_std, seed, call_offset, deterministic, obs_buf, act_buf, logp_buf,
+                          rew_buf, term_buf, trunc_buf, cost_buf, fin_rows, fin_step, ep_ret, ep_len, stats, call_base=None):
+    """ONE launch for the T closed-loop steps of a rollout with observation_history_size = H != 2 (include/pds.h
+    pds_rollout_history, csrc/pds_rollout_hist.h): obs_buf is [T + 1, N, H * half] with the current histories in row 0; the critic
+    is NOT in the kernel (the caller evaluates V over obs_buf and over the final histories in fin_rows [slots, N, H * half],
+    whose fin_step [slots, N] (int32, preset to -1) names the step each belongs to).  Raises NotImplementedError for env
+    configurations the kernel is not built for (the per-step path gives the same bits)."""
+    fm_pi._bind()
+    with _on(obs_buf):
+        rc = env.lib.pds_rollout_history(env._handle, int(T), int(H), C.byref(fm_pi.m), _ptr(mean), _ptr(std), float(eps),
+                                         _ptr(log_std), int(seed), _ptr(call_base), int(call_offset), int(bool(deterministic)),
+                                         _ptr(obs_buf), _ptr(act_buf), _ptr(logp_buf), _ptr(rew_buf), _ptr(term_buf),
+                                         _ptr(trunc_buf), _ptr(cost_buf), _ptr(fin_rows), _ptr(fin_step), int(fin_rows.shape[0]),
+                                         _ptr(ep_ret), _ptr(ep_len), _ptr(stats), FusedMLP._stream(obs_buf))
+    if rc != native.OK:
+        native.check(env._handle, rc, "pds_rollout_history")
 
 
 def gaussian_sample(mu, log_std, act_out, logp_out, seed, call, id_base=0, deterministic=False, call_base=None):

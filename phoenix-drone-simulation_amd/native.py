@@ -37,7 +37,7 @@ EXPORTS = ["pds_version", "pds_default_config", "pds_create", "pds_destroy", "pd
            "pds_latency_steps", "pds_philox4x32", "pds_noise_normals", "pds_gae", "pds_history_advance",
            "pds_mlp_param_count", "pds_mlp_workspace_floats", "pds_mlp_forward", "pds_ppo_policy_grad",
            "pds_value_grad", "pds_ppo_policy_grad_step", "pds_value_grad_step", "pds_gaussian_sample", "pds_gaussian_sample_dev", "pds_counter_add", "pds_permutation", "pds_rollout_record",
-           "pds_adam_step", "pds_rollout"]
+           "pds_adam_step", "pds_rollout", "pds_rollout_history"]
 
 
 class Mlp(C.Structure):
@@ -148,6 +148,7 @@ def load():
     later("pds_noise_normals", [u64, u64, C.c_uint32, u64, i64, vp, vp])
     later("pds_permutation", [vp, i64, u64, u64, vp])
     later("pds_rollout", [vp, i32, mp, mp, vp, vp, C.c_float, vp, u64, vp, u64, i32] + [vp] * 14)
+    later("pds_rollout_history", [vp, i32, i32, mp, vp, vp, C.c_float, vp, u64, vp, u64, i32] + [vp] * 9 + [i32] + [vp] * 4)
     _lib = lib
     return lib
 

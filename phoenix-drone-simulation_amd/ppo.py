@@ -296,9 +296,11 @@ class PPOTrainer:
         self._obs_buf = torch.zeros(T + 1, N, D, **f)  # row T: o(T), written by the fused rollout
         self.obs_buf = self._obs_buf[:T]
         self.cost_buf = torch.zeros(T, N, **f)
-        self._last_val_buf = torch.zeros(N, **f)
+        self._val_store = torch.zeros(T + 1, N, **f)   # V(o(0 .. T)): rows 0 .. T - 1 = val_buf, row T = V(o(T))
+        self.val_buf, self._last_val_buf = self._val_store[:T], self._val_store[T]
         self.act_buf = torch.zeros(T, N, 4, **f)
-        self.rew_buf, self.val_buf, self.logp_buf, self.fval_buf = (torch.zeros(T, N, **f) for _ in range(4))
+        self.rew_buf, self.logp_buf, self.fval_buf = (torch.zeros(T, N, **f) for _ in range(3))
+        self._fin_rows = self._fin_step = None         # pds_rollout_history's slot list (allocated at its first call)
         self.term_buf = torch.zeros(T, N, device=dev, dtype=torch.uint8)
         self.trunc_buf = torch.zeros(T, N, device=dev, dtype=torch.uint8)
         self.ep_ret = torch.zeros(N, **f)
@@ -334,8 +336,10 @@ class PPOTrainer:
         return stats
 
     def _roll_out_dispatch(self):
-        if self.fused and self.fused_rollout is not False and getattr(self.env, "observation_history_size", 2) == 2:
+        if self.fused and self.fused_rollout is not False:
             try:
+                if getattr(self.env, "observation_history_size", 2) != 2:
+                    return self._roll_out_fused_history()
                 return self._roll_out_fused()
             except NotImplementedError:
                 if self.fused_rollout:  # asked for explicitly
@@ -360,6 +364,42 @@ class PPOTrainer:
         self._sample_calls += self.T
         self.fused_rollout = True
         self.obs = self._obs_buf[self.T]  # (a view: copied into row 0 before the next launch overwrites it)
+        self.last_val = self._last_val_buf
+        return stats
+
+    @torch.no_grad()
+    def _roll_out_fused_history(self):
+        """observation_history_size != 2: actor, sampling, env step and history update in one launch (pds_rollout_history), then
+        the critic over the whole rollout in one pds_mlp_forward (V(o(0..T)): val_buf and last_val) and one over the final
+        histories of the paths that bootstrap with V.  Same draws and same bits as the per-step path."""
+        from .fused import fused_rollout_history
+        env, T, N = self.env, self.T, self.N
+        H, D = env.observation_history_size, env.obs_dim
+        mean, std, eps = self._oms()
+        stats = torch.zeros(3, device=self.obs.device)
+        if self._fin_rows is None:
+            slots = T // int(env.cfg.max_episode_steps) + 2
+            self._fin_rows = torch.zeros(slots, N, D, device=self.obs.device)
+            self._fin_step = torch.empty(slots, N, dtype=torch.int32, device=self.obs.device)
+            self._fval_store = torch.zeros(T * N + 1, device=self.obs.device)  # (+ 1: where the unused slots' values go)
+            self.fval_buf = self._fval_store[:T * N].view(T, N)
+            self._env_ids = torch.arange(N, device=self.obs.device, dtype=torch.int64)
+        self._obs_buf[0].copy_(self.obs)
+        self._fin_step.fill_(-1)
+        fused_rollout_history(env, self.fm_pi, T, H, mean, std, eps, self.ac.pi.log_std, self._sample_seed, self._sample_calls,
+                              not self.ac.training, self._obs_buf, self.act_buf, self.logp_buf, self.rew_buf, self.term_buf,
+                              self.trunc_buf, self.cost_buf, self._fin_rows, self._fin_step, self.ep_ret, self.ep_len, stats)
+        self._sample_calls += T
+        self.fused_rollout = True
+        # the critic, off the kernel: V(o(t)) for t = 0 .. T in one pass over obs_buf ...
+        self.fm_v.forward(self._obs_buf.view((T + 1) * N, D), mean=mean, std=std, eps=eps, out=self._val_store.view(-1, 1))
+        # ... and V(final history) of the paths that bootstrap with it -> fval_buf[fin_step, env]
+        vfin = self.fm_v.forward(self._fin_rows.view(-1, D), mean=mean, std=std, eps=eps).view(-1, N)
+        step = self._fin_step.to(torch.int64)
+        target = torch.where(step >= 0, step * N + self._env_ids, torch.full_like(step, T * N))
+        self._fval_store.scatter_(0, target.view(-1), vfin.reshape(-1))
+        self.obs = self._obs_buf[T]
+        env.adopt_history(self.obs)
         self.last_val = self._last_val_buf
         return stats
 

@@ -14,7 +14,7 @@ IDS = {"hover": "DroneHoverSimpleEnv-v0", "circle": "DroneCircleSimpleEnv-v0", "
 task, kw, N, steps = json.loads(sys.argv[1])
 g = torch.Generator(device="cuda").manual_seed(0)
 acts = [(-0.1 + 0.25 * torch.randn(N, 4, device="cuda", generator=g)).contiguous() for _ in range(8)]
-env = pds.make(IDS[task], num_envs=N, seed=0, **kw)
+env = pds.make(IDS[task], num_envs=N, seed=0, auto_reset=os.environ.get("AB_AUTO_RESET", "1") != "0", **kw)
 env.reset()
 for s in range(60):
     env.step(acts[s %% 8])

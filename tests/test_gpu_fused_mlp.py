@@ -16,6 +16,10 @@ def _net(d_in, h1, h2, d_out, act, seed):
 @pytest.mark.parametrize("d_in,h1,h2,d_out,act,B", [
     (34, 50, 50, 4, "relu", 1000), (40, 50, 50, 4, "relu", 32), (42, 64, 64, 1, "tanh", 4097),
     (48, 50, 50, 4, "tanh", 77), (17, 33, 7, 8, "relu", 1), (64, 64, 64, 1, "tanh", 300),
+    # round 6: more than 64 inputs (observation_history_size >= 4): the K-tiled first layer of csrc/pds_mlp_wide.hip, one
+    # shape per input-tile count it is built for (<= 96 / 128 / 160 / 192) and the widths the three tasks produce
+    (68, 50, 50, 4, "relu", 1000), (80, 32, 32, 4, "relu", 33), (96, 64, 64, 1, "tanh", 4097), (102, 48, 48, 4, "relu", 500),
+    (136, 64, 64, 1, "tanh", 777), (160, 64, 64, 4, "relu", 2049), (192, 64, 64, 1, "tanh", 300), (65, 50, 50, 4, "relu", 17),
 ])
 def test_forward_matches_torch(d_in, h1, h2, d_out, act, B):
     from phoenix_drone_simulation_amd.fused import FusedMLP
@@ -33,7 +37,10 @@ def test_forward_matches_torch(d_in, h1, h2, d_out, act, B):
 
 
 @pytest.mark.parametrize("d_in,h,act,B", [(34, 50, "relu", 5000), (40, 50, "relu", 31), (42, 64, "tanh", 2048 + 5),
-                                          (48, 50, "relu", 777), (64, 33, "tanh", 1500), (17, 16, "relu", 100)])
+                                          (48, 50, "relu", 777), (64, 33, "tanh", 1500), (17, 16, "relu", 100),
+                                          # round 6: the K-tiled kernels (64 < d_in <= 192)
+                                          (68, 50, "relu", 5000), (80, 32, "relu", 31), (136, 64, "relu", 2048 + 5),
+                                          (160, 48, "tanh", 777), (192, 64, "relu", 1500), (120, 64, "relu", 70001)])
 def test_ppo_policy_grad_matches_autograd(d_in, h, act, B):
     from phoenix_drone_simulation_amd.fused import FusedMLP
     A, clip = (6 if d_in == 17 else 4), 0.2  # 6 outputs: the log-prob sum spans two lane groups
@@ -148,7 +155,9 @@ def test_wave_role_policy_gradient_over_net_shapes(d_in, A):
     _ppo_grad_case(d_in, 50, A, "relu", 40000 + A, seed=7)
 
 
-@pytest.mark.parametrize("d_in,B,use_index", [(34, 3000, False), (42, 4096, True), (40, 17, True)])
+@pytest.mark.parametrize("d_in,B,use_index", [(34, 3000, False), (42, 4096, True), (40, 17, True),
+                                              (68, 3000, False), (80, 4096, True), (136, 17, True), (160, 40000, True),
+                                              (192, 5000, False)])
 def test_value_grad_matches_autograd(d_in, B, use_index):
     from phoenix_drone_simulation_amd.fused import FusedMLP
     net = _net(d_in, 64, 64, 1, "tanh", 3)

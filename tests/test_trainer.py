@@ -165,13 +165,25 @@ def test_ppo_learns_hover_end_to_end(fused):
 
 
 @pytest.mark.gpu
-def test_fused_update_matches_the_autograd_update():
+@pytest.mark.parametrize("task,H,ac_kwargs", [
+    ("DroneCircleSimpleEnv-v0", 2, None),
+    # round 6: more than 64 network inputs (csrc/pds_mlp_wide.hip) -- the widths and layer sizes of the reference's
+    # experiments/04_history_of_state_action_inputs/04_train_with_history.py:34-42 (H = 4 / 6 / 8; policy 32-32 / 48-48 / 64-64)
+    ("DroneHoverSimpleEnv-v0", 4, None),
+    ("DroneCircleSimpleEnv-v0", 4, {"pi": {"hidden_sizes": (32, 32), "activation": "relu"}, "val": {"hidden_sizes": (64, 64), "activation": "tanh"}}),
+    ("DroneCircleSimpleEnv-v0", 6, {"pi": {"hidden_sizes": (48, 48), "activation": "relu"}, "val": {"hidden_sizes": (64, 64), "activation": "tanh"}}),
+    ("DroneHoverSimpleEnv-v0", 8, None),
+    ("DroneCircleSimpleEnv-v0", 8, {"pi": {"hidden_sizes": (64, 64), "activation": "relu"}, "val": {"hidden_sizes": (64, 64), "activation": "tanh"}}),
+    ("DroneTakeOffSimpleEnv-v0", 8, None),
+])
+def test_fused_update_matches_the_autograd_update(task, H, ac_kwargs):
     """One policy iteration and one value mini-batch on real rollout data: the fused kernels write the
     same gradients into .grad as loss.backward() of the PyTorch path (ppo_loss / value_loss)."""
     import phoenix_drone_simulation_amd as pds
     from phoenix_drone_simulation_amd.ppo import PPOTrainer, gae, ppo_loss, value_loss
-    env = pds.make("DroneCircleSimpleEnv-v0", num_envs=1024, seed=2)
-    tr = PPOTrainer(env, rollout_len=16, epochs=4, seed=2, fused=True)
+    env = pds.make(task, num_envs=1024, seed=2, observation_history_size=H)
+    assert env.obs_dim == {"DroneHoverSimpleEnv-v0": 17, "DroneCircleSimpleEnv-v0": 20, "DroneTakeOffSimpleEnv-v0": 24}[task] * H
+    tr = PPOTrainer(env, rollout_len=16, epochs=4, seed=2, fused=True, ac_kwargs=ac_kwargs)
     tr.roll_out()
     ac, T, N = tr.ac, tr.T, tr.N
     adv, target_v, _ = gae(tr.rew_buf, tr.val_buf, tr.term_buf, tr.trunc_buf, tr.fval_buf, tr.last_val, 0.99, 0.95, 0.0, 10.0)
@@ -359,6 +371,19 @@ def test_value_update_on_a_second_stream_equals_the_sequential_update_bitwise():
     ("DroneCircleSimpleEnv-v0", dict(use_latency=True, latency=0.03, control_mode="Attitude", aggregate_phy_steps=2,
                                      use_motor_dynamics=True, observation_noise=-1, domain_randomization=-1,
                                      motor_thrust_noise=0), 130),
+    # round 6: observation histories other than 2 (pds_rollout_history, csrc/pds_rollout_hist.h: actor + env + history update in
+    # the kernel, the critic in one pass after it) -- every input-tile count the kernel is built for (<= 64 / 96 / 128 / 192
+    # inputs), H = 1 (no shift), 16-byte aligned halves (Circle 20, TakeOff 24) and unaligned ones (Hover 17)
+    ("DroneHoverSimpleEnv-v0", dict(observation_history_size=4), 200),                                              # 68 inputs
+    ("DroneCircleSimpleEnv-v0", dict(observation_history_size=8, use_motor_dynamics=True), 130),                    # 160
+    ("DroneTakeOffSimpleEnv-v0", dict(observation_history_size=8, observation_noise=-1, domain_randomization=-1,
+                                      motor_thrust_noise=0), 100),                                                  # 192
+    ("DroneHoverSimpleEnv-v0", dict(observation_history_size=1, observation_noise=-1, domain_randomization=-1,
+                                    motor_thrust_noise=0), 130),                                                    # 17
+    ("DroneCircleSimpleEnv-v0", dict(observation_history_size=3), 64 * 5 - 3),                                      # 60
+    ("DroneHoverSimpleEnv-v0", dict(observation_history_size=6, use_motor_dynamics=True, observation_noise=-1,
+                                    domain_randomization=-1, motor_thrust_noise=0), 64 * 300),                      # 102, > 256 tiles
+    ("DroneCircleSimpleEnv-v0", dict(observation_history_size=6), 70),                                              # 120
 ])
 def test_fused_rollout_equals_per_step_rollout_bitwise(task, kw, n):
     """pds_rollout (ONE launch for the T closed-loop steps: both networks on the matrix cores, Gaussian sampling, env
@@ -381,6 +406,8 @@ def test_fused_rollout_equals_per_step_rollout_bitwise(task, kw, n):
             x, y = getattr(a, name), getattr(b, name)
             assert torch.equal(x, y), (rnd, name, (x != y).nonzero()[:4])
         assert torch.equal(a.obs, b.obs)
+        if kw.get("observation_history_size", 2) != 2:  # the env's own history is what the next step() would start from
+            assert torch.equal(a.env._hist.reshape(n, -1), b.env._hist.reshape(n, -1))
         done = (a.term_buf | a.trunc_buf).bool()
         assert int(done.sum()) >= n  # max_episode_steps = 9 < T
         # V(final_obs) where pds_gae reads it: episodes the TimeLimit cut, terminated on that step or not (one that only
@@ -587,27 +614,40 @@ def test_ppo_learning_curve_with_eight_envs_keeps_the_late_level():
 
 
 @pytest.mark.gpu
-def test_trainer_falls_back_to_torch_networks_beyond_the_fused_kernels_range():
-    """observation_history_size = 4 (experiments/04_*: the reference trains H = 1 .. 8, envs/base.py:303-319) gives Hover 4 x 17 =
-    68 network inputs, more than the fused MFMA kernels' 64: PPOTrainer keeps the HIP envs (with pds_history_advance) and runs
-    the two networks as PyTorch ops; asked for explicitly (fused=True) it refuses."""
+def test_trainer_stays_fused_up_to_192_inputs():
+    """observation_history_size = 4 .. 8 (experiments/04_*: the reference trains H = 1 .. 8, envs/base.py:303-319) gives 68 .. 192
+    network inputs: since round 6 both networks stay on the fused MFMA kernels (csrc/pds_mlp_wide.hip: the first layer K-tiled;
+    rounds 1-5 fell back to PyTorch ops above 64 inputs), on the HIP envs with pds_history_advance; the one-launch rollout is
+    for H = 2 only, so the per-step kernels run.  Beyond 192 inputs the trainer says so and uses PyTorch ops; asked for
+    explicitly (fused=True) it refuses."""
+    import warnings
     import phoenix_drone_simulation_amd as pds
     from phoenix_drone_simulation_amd.ppo import PPOTrainer
-    env = pds.make("DroneHoverSimpleEnv-v0", num_envs=256, seed=3, observation_history_size=4)
-    assert env.obs_dim == 68
-    tr = PPOTrainer(env, rollout_len=16, epochs=3, train_pi_iterations=4, train_v_iterations=1, seed=5)
-    assert tr.fused is False and tr.graph_rollout is False
-    info = tr.learn_one_epoch()
-    assert np.isfinite(info["loss_pi"]) and np.isfinite(info["loss_v"]) and info["episodes"] > 0
+    for task, H, D in (("DroneHoverSimpleEnv-v0", 4, 68), ("DroneCircleSimpleEnv-v0", 8, 160), ("DroneTakeOffSimpleEnv-v0", 8, 192)):
+        env = pds.make(task, num_envs=256, seed=3, observation_history_size=H)
+        assert env.obs_dim == D
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")  # (no fallback warning)
+            tr = PPOTrainer(env, rollout_len=16, epochs=3, train_pi_iterations=4, train_v_iterations=1, seed=5)
+        assert tr.fused is True and tr.graph_rollout is False
+        ref = PPOTrainer(pds.make(task, num_envs=256, seed=3, observation_history_size=H), rollout_len=16, epochs=3,
+                         train_pi_iterations=4, train_v_iterations=1, seed=5, fused=False)
+        info, info_ref = tr.learn_one_epoch(), ref.learn_one_epoch()
+        assert tr.fused_rollout is not True  # (no one-launch rollout for H != 2)
+        assert np.isfinite(info["loss_pi"]) and np.isfinite(info["loss_v"]) and info["episodes"] > 0
+        # same seeds, same initial networks: the first epoch's value loss (before the update) agrees with the PyTorch-op
+        # trainer up to the two samplers' different action draws
+        assert abs(info["loss_v"] - info_ref["loss_v"]) < 0.2 * abs(info_ref["loss_v"]) + 1e-3, (info, info_ref)
+        env.close(); ref.env.close()
+    env = pds.make("DroneTakeOffSimpleEnv-v0", num_envs=64, seed=3, observation_history_size=10)
+    assert env.obs_dim == 240
+    with pytest.warns(RuntimeWarning, match="fused MFMA kernels do not cover"):
+        tr = PPOTrainer(env, rollout_len=8, epochs=3, train_pi_iterations=2, train_v_iterations=1, seed=5)
+    assert tr.fused is False and tr.graph_rollout is False and tr.fm_pi is None
+    assert np.isfinite(tr.learn_one_epoch()["loss_pi"])
     with pytest.raises(ValueError):
-        PPOTrainer(env, rollout_len=16, epochs=3, seed=5, fused=True)
+        PPOTrainer(env, rollout_len=8, epochs=3, seed=5, fused=True)
     env.close()
-    small = pds.make("DroneHoverSimpleEnv-v0", num_envs=256, seed=3, observation_history_size=3)  # 51 inputs: fused
-    tr = PPOTrainer(small, rollout_len=16, epochs=3, train_pi_iterations=4, train_v_iterations=1, seed=5)
-    assert tr.fused is True
-    info = tr.learn_one_epoch()
-    assert np.isfinite(info["loss_pi"]) and tr.fused_rollout is not True  # (no one-launch rollout for H != 2)
-    small.close()
 
 
 # ---- one full update() of the reference's trainer, replayed (tests/golden/update.npz) ------------------------------------------
