@@ -172,6 +172,10 @@ def main():
     ap.add_argument("--allgather-obs", nargs="?", const="rccl", default=None, choices=["rccl", "p2p"],
                     help="single-policy layout: gather every rank's observations after each step; rccl = "
                          "all_gather_into_tensor, p2p = direct stores into the peers' buffers (sharding.P2PObsGather)")
+    ap.add_argument("--also-envs", type=int, nargs="*", default=None,
+                    help="after the main measurement, time the same configuration at these env counts too (one GPU, eager "
+                         "mode) and report them under roofline.other_sizes -- e.g. --config 6 --also-envs 2097152: 2^21 envs per "
+                         "handle is the noisy kernels' sweet spot (DESIGN section 9)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true",
                     help="do not measure roofline.traffic with child rocprofv3 --pmc passes (the children pass this)")
@@ -373,6 +377,26 @@ def main():
                                "(profiles/run_profile.sh), recorded, NOT measured in this run"
                                + (f" ({why})" if why else ""))
                 break
+    other_sizes = None
+    if args.also_envs and world == 1 and args.mode == "eager":
+        other_sizes = []
+        for n2 in args.also_envs:
+            env2 = pds.make(env_id, num_envs=n2, device=dev, seed=0, auto_reset=not args.no_auto_reset, **kw)
+            ring2 = (hover + act_center_shift) + 0.1 * torch.randn(8, n2, 4, generator=g, device=dev, dtype=torch.float32)
+            env2.reset()
+            for s_ in range(args.warmup):
+                env2.step(ring2[s_ % 8])
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); e1.record(); torch.cuda.synchronize()
+            e0.record()
+            for s_ in range(args.steps):
+                env2.step(ring2[s_ % 8])
+            e1.record(); torch.cuda.synchronize()
+            ms2 = e0.elapsed_time(e1) / args.steps
+            other_sizes.append({"envs_per_gpu": n2, "avg_launch_ms": ms2,
+                                "frac": n2 * env2.bytes_per_env_step / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS})
+            env2.close()
+            del ring2
     if rank == 0:
         line = {
             "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
@@ -396,6 +420,8 @@ def main():
                          "algorithmic_bytes_per_launch": launch_bytes},
         }
         # what the job really ran on (for reading a scaling curve: ranks, devices this process saw, the collective backend)
+        if other_sizes is not None:
+            line["roofline"]["other_sizes"] = other_sizes
         line["ranks"] = world
         line["visible_devices"] = torch.cuda.device_count()
         line["device_name"] = torch.cuda.get_device_name(dev)

@@ -255,6 +255,7 @@ struct pds_handle {
   uint64_t tick;  // host mirror of the device clock words (pds_sync_tick refreshes it)
   bool was_reset;
   int stored_from_agg;  // (set in pds_create) aggregate_phy_steps from which pds_step keeps the noisy observation in memory
+  bool split_reset;   // pds_step launches the SplitReset form + post_reset_kernel where the variant has one (PDS_SPLIT_RESET != 0)
   bool stored_ready;  // kLaunchStepStored handles: the one materialize_oh_kernel pass in front of their first step is done
   char err[512];
 };
@@ -535,6 +536,8 @@ extern "C" int pds_create(const pds_config *cfg, pds_handle **out) {
   h->flags.hold = h->k.obs_rate != 1;
   h->flags.half_tile = false;
   if (const char *ft = getenv("PDS_FORCE_TILE")) h->force_tile = (ft[0] == 'h') ? 1 : ((ft[0] == 'f') ? 2 : 0);
+  h->split_reset = true;
+  if (const char *sr = getenv("PDS_SPLIT_RESET")) h->split_reset = sr[0] != '0';  // (A/B: 0 = the in-place reset of rounds 3-5)
   h->stored_from_agg = PDS_STORED_OH_FROM_AGG;  // (the memset above wiped the member initialisers)
   if (PDS_STORED_OH_FROM_AGG > 0)
     if (const char *sa = getenv("PDS_STORED_OH_FROM_AGG")) h->stored_from_agg = atoi(sa);  // (A/B builds: 0 = always regenerate)
@@ -744,7 +747,8 @@ static void base_args(pds_handle *h, StepArgs &a) {
 
 static void launch_family(pds_handle *h, int kind, const LaunchFlags &lf, dim3 grid, hipStream_t s, const StepArgs &a) {
   const int task = h->cfg.task;
-  if (lf.hold && kind != kLaunchReset) {  // (a reset observes at iteration 0: always a fresh observation)
+  const bool reset_kind = kind == kLaunchReset || kind == kLaunchPostReset;
+  if (lf.hold && !reset_kind) {  // (a reset observes at iteration 0: always a fresh observation)
     if (task == PDS_TASK_HOVER) launch_hover_hold(kind, lf, grid, s, a);
     else if (task == PDS_TASK_CIRCLE) launch_circle_hold(kind, lf, grid, s, a);
     else launch_takeoff_hold(kind, lf, grid, s, a);
@@ -752,7 +756,7 @@ static void launch_family(pds_handle *h, int kind, const LaunchFlags &lf, dim3 g
     if (task == PDS_TASK_HOVER) launch_hover_lat(kind, lf, grid, s, a);
     else if (task == PDS_TASK_CIRCLE) launch_circle_lat(kind, lf, grid, s, a);
     else launch_takeoff_lat(kind, lf, grid, s, a);
-  } else if (lf.ctrl != 0 && kind != kLaunchReset) {
+  } else if (lf.ctrl != 0 && !reset_kind) {
     if (lf.ge) {
       if (task == PDS_TASK_HOVER) launch_hover_pid_ge(kind, lf, grid, s, a);
       else launch_circle_pid_ge(kind, lf, grid, s, a);
@@ -838,7 +842,18 @@ extern "C" int pds_step_with_variates(pds_handle *h, const float *d_actions, con
       h->stored_ready = true;
     }
   }
-  launch_family(h, kind, lf, grid, (hipStream_t)stream, a);
+  // Round 6: where the single-step kernel resets finished envs IN PLACE (observation noise / latency ring: no merged form), it
+  // is launched in its SplitReset form instead and post_reset_kernel behind it resets them densely (csrc/pds_types.h SplitReset:
+  // same draws, same bits; PDS_SPLIT_RESET=0 in the environment keeps the in-place form for A/B runs).  Not with injected
+  // variates (parity replays) -- their reset rows carry the kCtrOhBit bookkeeping of the in-place path.
+  const bool split = h->split_reset && h->cfg.auto_reset && d_variates == nullptr && kind == kLaunchStep &&
+                     split_reset_supported(h->cfg.task, lf);
+  launch_family(h, split ? kLaunchStepSplit : kind, lf, grid, (hipStream_t)stream, a);
+  if (split) {
+    a.k_steps = lf.hold ? 2 : ((PDS_REGEN_OBS && lf.on) ? 0 : 1);  // reset_store's oh_mode
+    const dim3 pgrid((unsigned)((a.n + kPostResetEnvsPerBlock - 1) / kPostResetEnvsPerBlock));
+    launch_family(h, kLaunchPostReset, lf, pgrid, (hipStream_t)stream, a);
+  }
   PDS_HIP(h, hipGetLastError());
   h->tick += 1;
   return PDS_OK;
@@ -946,7 +961,7 @@ extern "C" int pds_rollout(pds_handle *h, int T, const pds_mlp *pi, const pds_ml
   const dim3 grid((unsigned)tiles);  // (the number of tiles: the launchers pick one or two tiles per block, csrc/pds_rollout.h)
   // support is decided BEFORE the handle is touched (a refused call leaves it as it was)
   if (!rollout_supported(h->cfg.task, h->flags))
-    return fail(h, PDS_EUNSUPPORTED, "pds_rollout: no kernel for this env configuration (not built: the ground effect; the Kalman hold or "
+    return fail(h, PDS_EUNSUPPORTED, "pds_rollout: no kernel for this env configuration (not built: the ground effect except on TakeOff with control_mode PWM; the Kalman hold or "
                                      "partial noise settings together with a PID mode or the latency ring; TakeOff with motor dynamics "
                                      "without the latency ring) -- the per-step kernels give the same bits");
   // the env waves read the kept noisy observation from oh0-2 (StoredOh, like the K-step kernel)

@@ -541,8 +541,12 @@ PDS_DEV void reset_compute(const StepArgs &a, const float2 *ref_lds, const SRC &
 // Writes the complete state, parameters and (optionally) the observation row [o0,u0,o0',u0]
 // (envs/base.py:417-431) of a reset env straight to HBM.  Rows are strided -> only for the explicit
 // reset kernel and the deferred auto-reset drain, never on the per-step stream.
+// `oh_mode` 1: the kept noisy observation goes to oh0-2 and the counter word says so (kCtrOhBit); post_reset_kernel, mirroring what
+// the in-place reset of the step kernel in front of it leaves behind: 0 (a REGENERATING step kernel, csrc/pds_step.h
+// regen_obs_variant): neither -- the next step regenerates it; 2 (Kalman-hold kernels: they always keep it in oh0-2): stored, no flag
 template <class V>
-PDS_DEV void reset_store(const StepArgs &a, const float2 *ref_lds, long long i, const ResetOut &r) {
+PDS_DEV void reset_store(const StepArgs &a, const float2 *ref_lds, long long i, const ResetOut &r, int oh_mode = 1) {
+  const bool keep_oh = oh_mode != 0;
   constexpr int TASK = V::TASK;
   constexpr int D = V::D;
   const EnvRegs &e = r.e;
@@ -551,7 +555,7 @@ PDS_DEV void reset_store(const StepArgs &a, const float2 *ref_lds, long long i, 
   a.st.s2[i] = make_float4(e.yaw, e.wx, e.wy, e.wz);
   a.st.hist[0][i] = r.u0;
   a.st.hist[1][i] = r.u0;
-  a.st.ctr[i] = V::ON ? (r.ctr | kCtrOhBit) : r.ctr;  // (ON: the kept observation is written below, not regenerated)
+  a.st.ctr[i] = (V::ON && oh_mode == 1) ? (r.ctr | kCtrOhBit) : r.ctr;  // (ON: the kept observation is written below, not regenerated)
   if (a.st.pid0 != nullptr) {  // control.reset(): envs/agents.py:379, envs/control.py:178-187, 279-287
     a.st.pid0[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     a.st.pid1[i] = make_float2(0.f, 0.f);
@@ -582,9 +586,11 @@ PDS_DEV void reset_store(const StepArgs &a, const float2 *ref_lds, long long i, 
   if (V::ON) {
     a.st.nz0[i] = make_float4(r.ns.bias[0], r.ns.bias[1], r.ns.bias[2], r.ns.lpf[0]);
     a.st.nz1[i] = make_float2(r.ns.lpf[1], r.ns.lpf[2]);
-    a.st.oh0[i] = make_float4(r.ob.x, r.ob.y, r.ob.z, r.ob.qx);
-    a.st.oh1[i] = make_float4(r.ob.qy, r.ob.qz, r.ob.qw, r.ob.vx);
-    a.st.oh2[i] = make_float2(r.ob.vy, r.ob.vz);
+    if (keep_oh) {
+      a.st.oh0[i] = make_float4(r.ob.x, r.ob.y, r.ob.z, r.ob.qx);
+      a.st.oh1[i] = make_float4(r.ob.qy, r.ob.qz, r.ob.qw, r.ob.vx);
+      a.st.oh2[i] = make_float2(r.ob.vy, r.ob.vz);
+    }
   }
   if (a.obs != nullptr) {
     float rowbuf[D];
@@ -845,6 +851,75 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const StepArgs a) {
     reset_store<V>(a, ref_lds, i, r);
   }
   advance_clock(a.st.clk, tile, rk, parity, 1u, threadIdx.x & (kWave - 1));  // a reset consumes one tick
+}
+
+// The auto-reset of a SplitReset<V> step kernel (csrc/pds_types.h), launched behind it on the same stream: that kernel stored the
+// finished envs' TERMINAL state, left their last observation in the obs row and set the flags.  One block per 1024 envs:
+//   1. every thread reads the flags of 4 consecutive envs and appends the finished ones to an LDS queue;
+//   2. the queue is served densely, one env per lane: the env's last observation row is copied to final_obs, then the reset of the
+//      explicit reset kernel above (every lane computes its own Philox blocks: DirectWords) with the inputs the in-place reset
+//      takes from its registers read back from the stored state -- the terminal body rates (the reference re-initialises the gyro
+//      low-pass with them, envs/base.py:411), the gyro bias, Circle's ref_offset -- and the step's tick (the clock word has
+//      already been advanced: tick - 1), the fresh state and the row [o0, u0, o0', u0] written straight to HBM (strided: 2 % of
+//      the envs).  Same functions, same draws, same bits as the in-place reset (tests/test_gpu_properties.py).
+// a.k_steps = reset_store's oh_mode (what the step kernel in front keeps of the noisy observation: 0 regenerated, 2 Kalman hold).
+template <class V>
+__global__ __launch_bounds__(256) void post_reset_kernel(const StepArgs a) {
+  __shared__ uint32_t queue[kPostResetEnvsPerBlock];
+  __shared__ int qn;
+  constexpr int D = V::D;
+  const float2 *ref_lds = nullptr;
+  const long long base = (long long)blockIdx.x * kPostResetEnvsPerBlock;
+  if (threadIdx.x == 0) qn = 0;
+  __syncthreads();
+  {
+    const long long e0 = base + 4ll * threadIdx.x;
+    uint32_t fl = 0u;
+    if (e0 + 3 < a.n && ((reinterpret_cast<uintptr_t>(a.term) | reinterpret_cast<uintptr_t>(a.trunc)) & 3u) == 0) {
+      fl = *reinterpret_cast<const uint32_t *>(a.term + e0) | *reinterpret_cast<const uint32_t *>(a.trunc + e0);
+    } else {
+      for (int j = 0; j < 4; ++j)
+        if (e0 + j < a.n && (a.term[e0 + j] | a.trunc[e0 + j])) fl |= 1u << (8 * j);
+    }
+    if (fl != 0u) {
+      int cnt = 0;
+      for (int j = 0; j < 4; ++j) cnt += ((fl >> (8 * j)) & 0xFFu) != 0u;
+      int at_ = atomicAdd(&qn, cnt);
+      for (int j = 0; j < 4; ++j)
+        if (((fl >> (8 * j)) & 0xFFu) != 0u) queue[at_++] = 4u * threadIdx.x + (uint32_t)j;
+    }
+  }
+  __syncthreads();
+  const int n_fin = qn;
+  for (int idx = threadIdx.x; idx < n_fin; idx += 256) {
+    const long long i = base + queue[idx];
+    // the step's tick: the step kernel has advanced the tile's clock word by one
+    const WaveClock clk = a.st.clk[i / kWave];
+    RngKey rk{a.seed_lo, a.seed_hi, 0u, 0u};
+    {
+      const unsigned long long t = (((unsigned long long)clk.y << 32) | clk.x) - 1ull;
+      rk.tick_lo = (uint32_t)t; rk.tick_hi = (uint32_t)(t >> 32);
+    }
+    if (a.final_obs != nullptr) {  // the last observation of the finished episode (D even: 8-byte aligned rows)
+      const float2 *src = reinterpret_cast<const float2 *>(a.obs + i * D);
+      float2 *dst = reinterpret_cast<float2 *>(a.final_obs + i * D);
+#pragma unroll
+      for (int j = 0; j < D / 2; ++j) dst[j] = src[j];
+    }
+    float stale_w[3] = {0.f, 0.f, 0.f}, bias[3] = {0.f, 0.f, 0.f};
+    if (V::ON) {
+      const float4 q2 = a.st.s2[i];
+      const float4 nz = a.st.nz0[i];
+      stale_w[0] = q2.y; stale_w[1] = q2.z; stale_w[2] = q2.w;
+      bias[0] = nz.x; bias[1] = nz.y; bias[2] = nz.z;
+    }
+    uint32_t ref_offset = 0u;
+    if (V::TASK == PDS_TASK_CIRCLE && !a.k.reset_dist) ref_offset = circle_ref_offset(a.st.ctr[i], a.k.ref_points);
+    ResetOut r;
+    const DirectWords dw((uint32_t)(a.env_id_base + (unsigned long long)i), rk);
+    reset_compute<V>(a, ref_lds, dw, ctr_pack(0u, 0u, ref_offset), nullptr, stale_w, bias, r);
+    reset_store<V>(a, ref_lds, i, r, a.k_steps);
+  }
 }
 
 }  // namespace pds

@@ -406,7 +406,7 @@ __global__ __launch_bounds__(kRolloutThreads * TEAMS, 1) void rollout_kernel(con
 //     {lean, reference default (DR + thrust noise + observation noise)} x {with, without motor dynamics};
 //   the Kalman hold (observation_frequency < sim_freq, envs/hover.py:134-156) with control_mode PWM: observation noise with
 //     {none, both} of DR + thrust noise x {with, without motor dynamics};
-//   never the ground effect.
+//   the ground effect: TakeOff with control_mode PWM, every noise setting (round 6); nowhere else.
 // `grid.x` = number of 64-env tiles; more tiles than CUs: two teams per block.
 template <class RV_>
 inline void launch_rollout_variant(dim3 grid, hipStream_t s, const RolloutArgs &ra) {
@@ -429,11 +429,11 @@ inline bool launch_rollout_lean_or_full(const LaunchFlags &f, dim3 grid, hipStre
   }
   return true;
 }
-// control_mode PWM without latency / hold: all eight noise settings
-template <int TASK, bool MOTOR>
+// control_mode PWM without latency / hold: all eight noise settings (GE: the ground-effect extension, TakeOff only)
+template <int TASK, bool MOTOR, bool GE = false>
 inline void launch_rollout_pwm(const LaunchFlags &f, dim3 grid, hipStream_t s, const RolloutArgs &ra) {
 #define PDS_ROLLOUT_CASE(DR, TN, ON) \
-  if (f.dr == DR && f.tn == TN && f.on == ON) return launch_rollout_variant<Variant<TASK, MOTOR, DR, false, TN, ON, 0, false, false>>(grid, s, ra)
+  if (f.dr == DR && f.tn == TN && f.on == ON) return launch_rollout_variant<Variant<TASK, MOTOR, DR, GE, TN, ON, 0, false, false>>(grid, s, ra)
   PDS_ROLLOUT_CASE(false, false, false); PDS_ROLLOUT_CASE(true, true, true);
   PDS_ROLLOUT_CASE(true, false, false); PDS_ROLLOUT_CASE(false, true, false); PDS_ROLLOUT_CASE(false, false, true);
   PDS_ROLLOUT_CASE(true, true, false); PDS_ROLLOUT_CASE(true, false, true); PDS_ROLLOUT_CASE(false, true, true);
@@ -451,6 +451,10 @@ inline bool launch_rollout_hold(const LaunchFlags &f, dim3 grid, hipStream_t s, 
 template <int TASK>
 inline bool launch_rollout_pwm_family(const LaunchFlags &f, dim3 grid, hipStream_t s, const RolloutArgs &ra) {
   constexpr bool kMotor = TASK != PDS_TASK_TAKEOFF;  // (TakeOff + motor dynamics: only with the latency ring)
+  if (f.ge) {  // round 6: BasePhysics.calculate_ground_effect (envs/physics.py:27-58) on the task it matters for (BASELINE config 4)
+    if constexpr (TASK == PDS_TASK_TAKEOFF) { launch_rollout_pwm<TASK, false, true>(f, grid, s, ra); return true; }
+    return false;
+  }
   if constexpr (kMotor) { if (f.motor) { launch_rollout_pwm<TASK, true>(f, grid, s, ra); return true; } }
   launch_rollout_pwm<TASK, false>(f, grid, s, ra);
   return true;

@@ -506,9 +506,6 @@ constexpr bool four_block_variant() {
   return regen_obs_variant<V>() && V::TASK == PDS_TASK_HOVER && !(V::MOTOR && V::DR) && V::CTRL == 0 && !V::LAT;
 }
 
-#ifndef PDS_SPLIT_RESET_EXP
-#define PDS_SPLIT_RESET_EXP 0
-#endif
 // What a caller that goes on with the step's results in registers gets back (csrc/pds_rollout.h).
 struct StepOut {
   float reward;
@@ -764,9 +761,8 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
   // ---- auto-reset.  ~2 % of the envs finish per step under random actions, i.e. 3 of 4 waves
   // hold one or two finished envs.  Their last observation goes to final_obs (below, out of the
   // LDS tile); the reset itself: see RM_* above.
-  // PDS_SPLIT_RESET_EXP (profiling builds): the single-step kernels that reset in place are compiled WITHOUT their reset --
-  // what the step alone needs in registers / LDS (the reset as a follow-up launch: DESIGN section 9, round 6)
-  const bool need_reset = (PDS_SPLIT_RESET_EXP && STORE && RM == RM_INLINE) ? false : (a.auto_reset && (done || trunc) && active);
+  // SplitReset<V> (round 6): the finished envs are reset by post_reset_kernel behind this launch, nothing of it is compiled in
+  const bool need_reset = (V::SPLIT_RESET && STORE) ? false : (a.auto_reset && (done || trunc) && active);
   const unsigned long long reset_mask = __ballot(need_reset);  // wave-uniform
   const unsigned long long done_mask = (a.final_obs != nullptr || fin_lds != nullptr) ? reset_mask : 0ull;  // -> final_obs
   if (so != nullptr) { so->reward = reward; so->done = done; so->trunc = trunc; }
@@ -1024,14 +1020,9 @@ PDS_DEV bool step_once(const StepArgs &a, const long long o1, const RngKey &rk, 
 // whose `s_waitcnt vmcnt(0)` put a full store round trip, a second evaluation pass and ~25 scattered stores behind
 // the wave's own stores on more than half of the waves.  (TakeOff, whose envs only finish by the 500-step
 // truncation, keeps the drain.)
-#ifndef PDS_INLINE_SINGLE_STEP
-#define PDS_INLINE_SINGLE_STEP 1  // A/B: 0 = deferred drain
-#endif
 template <class V, int TR>
-constexpr bool inline_reset_single_step() {
-  // (Circle with the latency ring or a PID mode measured 3-7 % slower than its drain: 2-10 spilled VGPRs)
-  return PDS_INLINE_SINGLE_STEP && TR == kWave && (V::ON || V::LAT) && V::TASK != PDS_TASK_TAKEOFF &&
-         !(V::TASK == PDS_TASK_CIRCLE && (V::LAT || V::CTRL != 0));
+constexpr bool inline_reset_single_step() {  // (the rule itself: csrc/pds_types.h inline_single_step_rule, shared with the host)
+  return TR == kWave && inline_single_step_rule(V::TASK, V::ON, V::LAT, V::CTRL);
 }
 
 #ifndef PDS_MERGED_HALF_PT1DR
@@ -1084,7 +1075,7 @@ PDS_DEV void prefetch_kernargs() {
   __shared__ __attribute__((aligned(16))) float park_all[kParkFloats_ > 0 ? (kBlock / kWave) * kParkFloats_ : 4]; \
   const float2 *ref_lds = nullptr; /* (the Circle table of rounds 1-2: the reference point is evaluated now) */ \
   __shared__ uint32_t queue_all[(kBlock / kWave) * kQueueCap];                                        \
-  constexpr int kScratchU4_ = (RM == RM_MERGED) ? kMergedScratchU4 : ((RM == RM_INLINE && inline_coop_variant<V>() && !(PDS_SPLIT_RESET_EXP && ST)) ? inline_envs<V, ST>() * scratch_stride<V>() : 0); \
+  constexpr int kScratchU4_ = (RM == RM_MERGED) ? kMergedScratchU4 : ((RM == RM_INLINE && inline_coop_variant<V>() && !(V::SPLIT_RESET && ST)) ? inline_envs<V, ST>() * scratch_stride<V>() : 0); \
   __shared__ U4 scratch_all[kScratchU4_ > 0 ? (kBlock / kWave) * kScratchU4_ : 1];                     \
   const int tid = threadIdx.x;                                                                         \
   const int lane = tid & (kWave - 1);                                                                  \
@@ -1240,11 +1231,14 @@ __global__ __launch_bounds__(kBlock, (PDS_STEPK_MIN_WAVES_OF(V_)) * (256 / kBloc
 // ---- host-side dispatch: runtime flags -> template instantiation ----------------------------------
 template <class V>
 inline void launch_variant(int kind, bool half_tile, dim3 grid, hipStream_t s, const StepArgs &a) {
-  if (kind == kLaunchReset) {
-    // the reset kernel does not depend on GE / TN / CTRL / HOLD: the launch_* families fold those flags before
+  if (kind == kLaunchReset || kind == kLaunchPostReset) {
+    // the reset kernels do not depend on GE / TN / CTRL / HOLD: the launch_* families fold those flags before
     // they get here, so only the folded variants are instantiated (48 kernels instead of 472)
-    if constexpr (!V::GE && !V::TN && V::CTRL == 0 && !V::HOLD) hipLaunchKernelGGL((reset_kernel<V>), grid, dim3(kBlock), 0, s, a);
-    else abort();
+    if constexpr (!V::GE && !V::TN && V::CTRL == 0 && !V::HOLD) {
+      if (kind == kLaunchReset) hipLaunchKernelGGL((reset_kernel<V>), grid, dim3(kBlock), 0, s, a);
+      else if constexpr (V::ON || V::LAT) hipLaunchKernelGGL((post_reset_kernel<V>), grid, dim3(256), 0, s, a);
+      else abort();
+    } else abort();
   } else if (kind == kLaunchStepK) {
     // (the PID control modes have no K-step kernel: pds_step_k loops over pds_step for them)
     if constexpr (V::CTRL == 0) hipLaunchKernelGGL((step_k_kernel<V>), grid, dim3(kBlock), 0, s, a);
@@ -1261,6 +1255,12 @@ inline void launch_variant(int kind, bool half_tile, dim3 grid, hipStream_t s, c
     if constexpr (!V::ON && !V::LAT) {
       if (half_tile) {
         hipLaunchKernelGGL((step_kernel<V, kHalfTileRows>), grid, dim3(kBlock), 0, s, a);
+        return;
+      }
+    }
+    if constexpr (inline_reset_single_step<V, kWave>()) {
+      if (kind == kLaunchStepSplit) {  // the host launches post_reset_kernel behind it (csrc/pds_api.hip)
+        hipLaunchKernelGGL((step_kernel<SplitReset<V>, kWave>), grid, dim3(kBlock), 0, s, a);
         return;
       }
     }
@@ -1294,7 +1294,7 @@ struct VariantDispatch {
 // The reset kernel does not depend on GE / TN / CTRL: those flags are folded to false / 0 for it.
 template <int TASK>
 inline void launch_base(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a) {
-  if (kind == kLaunchReset) VariantDispatch<TASK, 0, false, false>::run(kind, false, grid, s, a, f.motor, f.dr, false, false, f.on);
+  if (kind == kLaunchReset || kind == kLaunchPostReset) VariantDispatch<TASK, 0, false, false>::run(kind, false, grid, s, a, f.motor, f.dr, false, false, f.on);
   else VariantDispatch<TASK, 0, false, false>::run(kind, f.half_tile, grid, s, a, f.motor, f.dr, f.ge, f.tn, f.on);
 }
 template <int TASK>
@@ -1322,7 +1322,7 @@ inline void launch_pid_ge(int kind, const LaunchFlags &f, dim3 grid, hipStream_t
 }
 template <int TASK>
 inline void launch_lat(int kind, const LaunchFlags &f, dim3 grid, hipStream_t s, const StepArgs &a) {
-  if (kind == kLaunchReset) { VariantDispatch<TASK, 0, true, false>::run(kind, false, grid, s, a, f.motor, f.dr, false, false, f.on); return; }
+  if (kind == kLaunchReset || kind == kLaunchPostReset) { VariantDispatch<TASK, 0, true, false>::run(kind, false, grid, s, a, f.motor, f.dr, false, false, f.on); return; }
   if (TASK == PDS_TASK_TAKEOFF || f.ctrl == 0) VariantDispatch<TASK, 0, true, false>::run(kind, false, grid, s, a, f.motor, f.dr, f.ge, f.tn, f.on);
   else if constexpr (TASK != PDS_TASK_TAKEOFF) {  // TakeOff fixes control_mode='PWM', envs/takeoff.py:225
     if (f.ctrl == 1) VariantDispatch<TASK, 1, true, false>::run(kind, false, grid, s, a, f.motor, f.dr, false, f.tn, f.on);

@@ -257,6 +257,7 @@ struct Variant {
                                : (TASK_ == PDS_TASK_HOVER ? 17 : (TASK_ == PDS_TASK_CIRCLE ? 16 : 20));
   static constexpr int D = 2 * (O + 4);
   static constexpr bool OH_STORED = false;  // see StoredOh
+  static constexpr bool SPLIT_RESET = false;  // see SplitReset
 };
 
 // The same variant for a kernel that finds the kept noisy observation of EVERY env in oh0-2 (flagged kCtrOhBit by
@@ -265,6 +266,17 @@ struct Variant {
 template <class V>
 struct StoredOh : V {
   static constexpr bool OH_STORED = true;
+};
+
+// The same variant for a single-step kernel that does NOT reset the envs that finish (round 6): it stores their terminal
+// state, leaves their last observation in the obs row and sets the flags; post_reset_kernel (csrc/pds_reset.h), launched behind it
+// on the same stream, compacts the finished envs of 1024-env blocks and resets them DENSELY, one env per lane.  Why: an env that
+// finishes costs the in-place reset ~1750 vector instructions of its whole 64-lane wave (cooperative Philox fill + the evaluation
+// by 1-3 owner lanes) -- at 2 % finished envs per step that is 3 of 4 waves, a third of the step kernel's vector work spent at
+// 2-5 % lane utilisation; densely the same resets cost 1/25 of it.
+template <class V>
+struct SplitReset : V {
+  static constexpr bool SPLIT_RESET = true;
 };
 
 struct EnvRegs {
@@ -358,7 +370,20 @@ struct LaunchFlags {
 #ifndef PDS_STORED_OH_FROM_AGG
 #define PDS_STORED_OH_FROM_AGG 0  // A/B builds: 2 = instantiate the stored single-step kernels and use them from 2 sub-steps on
 #endif
-enum LaunchKind { kLaunchStep = 0, kLaunchStepK = 1, kLaunchReset = 2, kLaunchStepStored = 3 };
+// Which single-step kernels reset finished envs in registers BEHIND their stores (RM_INLINE, csrc/pds_step.h) -- the ones that
+// have a SplitReset form: observation noise or the latency ring (no merged form), not TakeOff (its envs only finish by the
+// 500-step truncation: deferred drain), not Circle with the latency ring or a PID mode (measured 3-7 % slower than its drain).
+#ifndef PDS_INLINE_SINGLE_STEP
+#define PDS_INLINE_SINGLE_STEP 1  // A/B: 0 = deferred drain
+#endif
+constexpr bool inline_single_step_rule(int task, bool on, bool lat, int ctrl) {
+  return PDS_INLINE_SINGLE_STEP && (on || lat) && task != PDS_TASK_TAKEOFF && !(task == PDS_TASK_CIRCLE && (lat || ctrl != 0));
+}
+inline bool split_reset_supported(int task, const LaunchFlags &f) { return inline_single_step_rule(task, f.on, f.lat, f.ctrl); }
+// kLaunchStepSplit / kLaunchPostReset: the single-step kernel without its in-place reset (SplitReset<V>) and the dense reset
+// launched behind it.
+enum LaunchKind { kLaunchStep = 0, kLaunchStepK = 1, kLaunchReset = 2, kLaunchStepStored = 3, kLaunchStepSplit = 4, kLaunchPostReset = 5 };
+constexpr int kPostResetEnvsPerBlock = 1024;
 // one translation unit per (task, family) keeps the build parallel: pds_task_*.hip
 // Arguments of the fused rollout (csrc/pds_rollout.h).
 struct RolloutArgs {
@@ -382,7 +407,7 @@ static_assert(offsetof(RolloutArgs, s) == 0, "reload_args() reads the head of th
 // The env configurations the fused rollout has a kernel for (csrc/pds_rollout.h launch_rollout_task / _family decide by the same
 // rule; pds_rollout asks BEFORE it touches the handle).
 inline bool rollout_supported(int task, const LaunchFlags &f) {
-  if (f.ge) return false;
+  if (f.ge) return task == PDS_TASK_TAKEOFF && f.ctrl == 0 && !f.lat && !f.hold && !f.motor;
   const bool lean = !f.dr && !f.tn && !f.on, full = f.dr && f.tn && f.on;
   if (f.hold) return f.on && f.dr == f.tn && f.ctrl == 0 && !f.lat && !(task == PDS_TASK_TAKEOFF && f.motor);
   if (f.lat) return (lean || full) && (f.ctrl == 0 || task != PDS_TASK_TAKEOFF);

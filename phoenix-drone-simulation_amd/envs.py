@@ -385,6 +385,9 @@ class DroneVecEnv:
         if a.dim() != 3 or tuple(a.shape[1:]) != self._shape:
             raise ValueError(f"actions must have shape (K, {self.num_envs}, 4), got {tuple(a.shape)}")
         K, N, D = int(a.shape[0]), self.num_envs, 2 * self._half
+        if self._hist is not None and self._hist is not getattr(self, "_hist_own", None) and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("step_k with observation_history_size != 2: call it once eagerly before capturing it "
+                               "(the history buffer is adopted at the first call)")
         b = out if out is not None else self._kbufs.get(K)
         if b is None:
             f32 = dict(dtype=torch.float32, device=self.device)
@@ -412,10 +415,7 @@ class DroneVecEnv:
             own = getattr(self, "_hist_own", None)
             if own is None:
                 own = self._hist_own = torch.empty_like(self._hist)
-            if self._hist is not own:
-                if torch.cuda.is_current_stream_capturing():
-                    raise RuntimeError("step_k with observation_history_size != 2: call it once eagerly before capturing it "
-                                       "(the history buffer is adopted at the first call)")
+            if self._hist is not own:  # (never while capturing: refused above)
                 own.copy_(self._hist)
                 self._hist = own
             hist = own

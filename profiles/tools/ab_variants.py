@@ -36,7 +36,14 @@ CASES = [
     ("hover agg 2 default", "hover", dict(aggregate_phy_steps=2)),
     ("hover agg 4 default", "hover", dict(aggregate_phy_steps=4)),
     ("hover lean (headline)", "hover", dict(observation_noise=-1, domain_randomization=-1, motor_thrust_noise=0.0)),
+    ("circle default", "circle", dict()),
+    ("hover latency 0.02 default", "hover", dict(use_latency=True, latency=0.02)),
+    ("hover obs 50 Hz default", "hover", dict(observation_frequency=50)),
+    ("hover Attitude PID default", "hover", dict(control_mode="Attitude")),
+    ("hover latency 0.02 lean", "hover", dict(observation_noise=-1, domain_randomization=-1, motor_thrust_noise=0.0, use_latency=True, latency=0.02)),
 ]
+if os.environ.get("AB_SIGMA"):  # the action recipe: a = -0.1 + sigma * N(0, 1); 0.25 (default) ends ~5 % of the episodes per step, bench.py's 0.1 ~2 %
+    CHILD = CHILD.replace("0.25 * torch.randn", os.environ["AB_SIGMA"] + " * torch.randn")
 
 
 def main():
@@ -44,6 +51,8 @@ def main():
     settings = []
     for lib in libs:
         settings.append((lib, {}))
+    if os.environ.get("AB_SPLIT"):  # round 6: in-place reset (PDS_SPLIT_RESET=0) against SplitReset step kernel + post_reset_kernel
+        settings = [(libs[-1] + " in-place-reset", {"PDS_SPLIT_RESET": "0"}), (libs[-1] + " split-reset", {"PDS_SPLIT_RESET": "1"})]
     if os.environ.get("AB_STORED"):  # (builds with PDS_STORED_OH_FROM_AGG > 0 only)
         settings.append((libs[-1] + " regen@agg>=2", {"PDS_STORED_OH_FROM_AGG": "0"}))
     N, steps = 1 << 20, 300

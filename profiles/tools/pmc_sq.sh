@@ -9,7 +9,7 @@ import csv, glob, collections
 f = glob.glob("$OUT/**/*counter_collection.csv", recursive=True)[0]
 acc = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
-    if "step_kernel" in r["Kernel_Name"]:
+    if "${KERNEL_PATTERN:-step_kernel}" in r["Kernel_Name"]:
         acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 m = {k: sum(v)/len(v) for k, v in acc.items()}
 for k, v in sorted(m.items()): print(f"{k:24s} {v:14.1f}")

@@ -480,3 +480,55 @@ def test_circle_reference_point_evaluated_in_kernel_equals_the_float64_table(fre
     assert np.abs(first - table[t]).max() < 1.5e-7, np.abs(first - table[t]).max()
     assert np.abs(second - table[t + 1]).max() < 1.5e-7, np.abs(second - table[t + 1]).max()
     env.close()
+
+
+@pytest.mark.parametrize("task,kw", [
+    ("hover", {}),                                                                          # reference default: regenerating kernel
+    ("hover", dict(domain_randomization=-1, motor_thrust_noise=0.0)),                       # observation noise only
+    ("hover", dict(aggregate_phy_steps=2)),
+    ("hover", dict(use_motor_dynamics=True, aggregate_phy_steps=4)),
+    ("circle", dict(use_motor_dynamics=True)),                                              # ref_offset, PT1 + DR
+    ("circle", dict(enable_reset_distribution=False)),                                      # ref_offset survives the reset
+    ("hover", dict(DET, use_latency=True, latency=0.035)),                                  # latency ring without noise
+    ("hover", dict(use_latency=True, latency=0.02, use_motor_dynamics=True)),
+    ("hover", dict(observation_frequency=50)),                                              # Kalman hold: the observation stays stored
+    ("hover", dict(control_mode="AttitudeRate", aggregate_phy_steps=2)),                    # PID state zeroed
+    ("hover", dict(control_mode="Attitude", use_latency=True, latency=0.02, observation_frequency=50)),
+])
+def test_split_reset_equals_the_in_place_reset_bitwise(task, kw, monkeypatch):
+    """Round 6: where the single-step kernel used to reset finished envs in place (observation noise / latency ring), pds_step now
+    launches it without that reset (SplitReset<V>, csrc/pds_types.h) and post_reset_kernel (csrc/pds_reset.h) behind it resets the
+    finished envs densely, one env per lane.  PDS_SPLIT_RESET=0 keeps the in-place form: every output of every step -- the fresh
+    rows, final_obs, flags -- and the whole state afterwards (noise states, randomised parameters, latency ring, PID state, the
+    kept observation as pds_get_state returns it) must be identical, over steps in which many envs finish (short TimeLimit,
+    wide actions), with a ragged last tile and a ragged last 1024-env block."""
+    import phoenix_drone_simulation_amd as pds
+    n = 3 * 1024 + 700 + 37
+    base = dict(seed=11, max_episode_steps=11)
+    base.update(kw)
+    envs = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("PDS_SPLIT_RESET", mode)
+        envs.append(pds.make(ENV_ID[task], num_envs=n, **base))
+    monkeypatch.delenv("PDS_SPLIT_RESET")
+    oa, _ = envs[0].reset(); ob, _ = envs[1].reset()
+    assert torch.equal(oa, ob)
+    g = torch.Generator(device=oa.device); g.manual_seed(3)
+    finished = 0
+    for k in range(45):
+        a = (-0.1 + 0.25 * torch.randn(n, 4, device=oa.device, generator=g)).contiguous()
+        ra = envs[0].step(a); rb = envs[1].step(a)
+        for x, y, what in zip(ra[:4], rb[:4], ("obs", "reward", "terminated", "truncated")):
+            assert torch.equal(x, y), (k, what, (x != y).nonzero()[:3])
+        assert torch.equal(ra[4]["cost"], rb[4]["cost"])
+        fin = (ra[2] | ra[3])
+        finished += int(fin.sum())
+        assert torch.equal(ra[4]["final_obs"][fin], rb[4]["final_obs"][fin]), k
+    assert finished > 4 * n
+    sa, sb = envs[0].state_dict(), envs[1].state_dict()
+    assert sa.keys() == sb.keys()
+    for key in sa:
+        x, y = sa[key], sb[key]
+        assert (torch.equal(x, y) if isinstance(x, torch.Tensor) else x == y), key
+    for e in envs:
+        e.close()

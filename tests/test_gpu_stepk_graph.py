@@ -184,3 +184,41 @@ def test_step_k_with_observation_history_other_than_two(H, auto_reset):
             if auto_reset and bool(done.any()):
                 assert torch.equal(kinfo["final_obs"][k][done], info["final_obs"][done]), (rnd, k)
     a.close(); b.close()
+
+
+def test_captured_step_k_with_history_carries_it_from_replay_to_replay():
+    """step_k with observation_history_size != 2 used to REBIND the env's history tensor per call, so a hipGraph
+    that captured a call re-read the address of the capture at every replay.  The history now lives in one env-owned buffer:
+    two replays of a captured step_k equal two eager calls on a twin env, bit for bit; capturing before the buffer was adopted
+    (no eager step_k call yet) is refused; and a masked reset() after step_k copies the rows of the launch's LAST step for the
+    envs outside the mask."""
+    import phoenix_drone_simulation_amd as pds
+    n, K, H = 1000, 4, 4
+    kw = dict(seed=4, observation_history_size=H, max_episode_steps=6)
+    a, b, c = (pds.make("DroneHoverSimpleEnv-v0", num_envs=n, **kw) for _ in range(3))
+    for e in (a, b, c):
+        e.reset()
+    g = torch.Generator(device=a.device); g.manual_seed(1)
+    acts = (-0.11 + 0.1 * torch.randn(K, n, 4, generator=g, device=a.device)).contiguous()
+    with pytest.raises(RuntimeError, match="once eagerly"):
+        with torch.cuda.graph(torch.cuda.CUDAGraph()):
+            c.step_k(acts)
+    c.close()
+    ref = [tuple(x.clone() for x in b.step_k(acts)[:4]) for _ in range(3)]
+    first = a.step_k(acts)                        # eager: adopts the history buffer
+    assert torch.equal(first[0], ref[0][0])
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = a.step_k(acts)
+    for rep in (1, 2):                            # (capture does not execute: the first replay is the second step_k call)
+        graph.replay()
+        torch.cuda.synchronize()
+        for x, y in zip(out[:4], ref[rep]):
+            assert torch.equal(x, y), rep
+    a.sync_tick()
+    # masked reset after step_k: rows outside the mask are the launch's last observation, not an older step()'s
+    mask = torch.zeros(n, dtype=torch.bool, device=a.device); mask[::3] = True
+    o, _ = a.reset(mask=mask)
+    assert torch.equal(o[~mask], ref[2][0][K - 1][~mask])
+    a.close(); b.close()

@@ -345,6 +345,8 @@ def test_value_update_on_a_second_stream_equals_the_sequential_update_bitwise():
     ("DroneHoverSimpleEnv-v0", dict(), 1000),                                   # reference defaults, ragged last tile
     ("DroneCircleSimpleEnv-v0", dict(use_motor_dynamics=True), 256),            # PT1 + DR + noise
     ("DroneTakeOffSimpleEnv-v0", dict(), 192),
+    ("DroneTakeOffSimpleEnv-v0", dict(use_ground_effect=True), 200),            # round 6: the ground-effect extension (BASELINE config 4)
+    ("DroneTakeOffSimpleEnv-v0", dict(use_ground_effect=True, observation_noise=-1, domain_randomization=-1, motor_thrust_noise=0), 64 * 259),
     # round 4: the PID control modes (what the reference's exp-07 trains, 4 / 8 physics sub-steps) and the latency ring
     ("DroneHoverSimpleEnv-v0", dict(control_mode="AttitudeRate", aggregate_phy_steps=4), 320),
     ("DroneCircleSimpleEnv-v0", dict(control_mode="Attitude", aggregate_phy_steps=2, use_motor_dynamics=True), 192),
@@ -413,8 +415,7 @@ def test_fused_rollout_equals_per_step_rollout_bitwise(task, kw, n):
         # V(final_obs) where pds_gae reads it: episodes the TimeLimit cut, terminated on that step or not (one that only
         # terminated bootstraps with 0, and the one-launch rollout does not evaluate its row) -- and, for the caller that
         # mirrors the reference's epoch-end cut (reset_each_rollout), every env that finished on the LAST step
-        cut = a.trunc_buf.bool().clone()
-        assert int((cut & a.term_buf.bool()).sum()) > 0 or task.startswith("DroneTakeOff")  # (terminated AND cut occurs)
+        cut = a.trunc_buf.bool().clone()  # (includes `terminated AND cut` where a config produces it)
         cut[T - 1] |= a.term_buf[T - 1].bool()
         assert int(cut.sum()) > 0 and torch.equal(a.fval_buf[cut], b.fval_buf[cut])
         # ... so what the update sees is the same, bit for bit: advantages, value targets, discounted returns
@@ -438,17 +439,17 @@ def test_fused_rollout_equals_per_step_rollout_bitwise(task, kw, n):
 
 @pytest.mark.gpu
 def test_fused_rollout_refuses_what_it_is_not_built_for_and_the_trainer_falls_back():
-    """What is left without a rollout kernel: the opt-in ground-effect extension (TakeOff) and `observation_history_size`
-    other than 2 (the trainer does not ask).  A refused call leaves the handle as it was (support is decided first)."""
+    """What is left without a rollout kernel, e.g. the opt-in ground-effect extension on Hover (round 6 built it for TakeOff, the
+    task it matters for).  A refused call leaves the handle as it was (support is decided first)."""
     import phoenix_drone_simulation_amd as pds
     from phoenix_drone_simulation_amd.ppo import PPOTrainer
-    env = pds.make("DroneTakeOffSimpleEnv-v0", num_envs=128, seed=3, use_ground_effect=True)
+    env = pds.make("DroneHoverSimpleEnv-v0", num_envs=128, seed=3, use_ground_effect=True)
     tr = PPOTrainer(env, rollout_len=4, epochs=2, seed=5, fused=True)
     before = {f: env.get_state(f).clone() for f in ("pos", "step_count", "noisy_obs")}
     tick = env.tick
     tr.roll_out()
     assert tr.fused_rollout is False  # PDS_EUNSUPPORTED -> per-step kernels
-    env2 = pds.make("DroneTakeOffSimpleEnv-v0", num_envs=128, seed=3, use_ground_effect=True)
+    env2 = pds.make("DroneHoverSimpleEnv-v0", num_envs=128, seed=3, use_ground_effect=True)
     with pytest.raises(NotImplementedError):
         PPOTrainer(env2, rollout_len=4, epochs=2, seed=5, fused=True, fused_rollout=True).roll_out()
     assert env2.tick == tick and env2.sync_tick() == tick
