@@ -536,8 +536,11 @@ extern "C" int pds_create(const pds_config *cfg, pds_handle **out) {
   h->flags.hold = h->k.obs_rate != 1;
   h->flags.half_tile = false;
   if (const char *ft = getenv("PDS_FORCE_TILE")) h->force_tile = (ft[0] == 'h') ? 1 : ((ft[0] == 'f') ? 2 : 0);
-  h->split_reset = true;
-  if (const char *sr = getenv("PDS_SPLIT_RESET")) h->split_reset = sr[0] != '0';  // (A/B: 0 = the in-place reset of rounds 3-5)
+  // Round 6 built the reset OUT of the single-step kernel (SplitReset<V> + post_reset_kernel, csrc/pds_types.h) and measured it
+  // SLOWER than the in-place reset on every configuration (profiles/r06_ab_split_reset.txt: config 6 85 -> 108-117 us), so it is
+  // off unless PDS_SPLIT_RESET=1 asks for it (same bits either way: tests/test_gpu_properties.py)
+  h->split_reset = false;
+  if (const char *sr = getenv("PDS_SPLIT_RESET")) h->split_reset = sr[0] == '1';
   h->stored_from_agg = PDS_STORED_OH_FROM_AGG;  // (the memset above wiped the member initialisers)
   if (PDS_STORED_OH_FROM_AGG > 0)
     if (const char *sa = getenv("PDS_STORED_OH_FROM_AGG")) h->stored_from_agg = atoi(sa);  // (A/B builds: 0 = always regenerate)
@@ -842,10 +845,10 @@ extern "C" int pds_step_with_variates(pds_handle *h, const float *d_actions, con
       h->stored_ready = true;
     }
   }
-  // Round 6: where the single-step kernel resets finished envs IN PLACE (observation noise / latency ring: no merged form), it
-  // is launched in its SplitReset form instead and post_reset_kernel behind it resets them densely (csrc/pds_types.h SplitReset:
-  // same draws, same bits; PDS_SPLIT_RESET=0 in the environment keeps the in-place form for A/B runs).  Not with injected
-  // variates (parity replays) -- their reset rows carry the kCtrOhBit bookkeeping of the in-place path.
+  // Round 6 (opt-in, PDS_SPLIT_RESET=1: measured slower, see pds_create): where the single-step kernel resets finished envs IN
+  // PLACE (observation noise / latency ring: no merged form), it is launched in its SplitReset form instead and post_reset_kernel
+  // behind it resets them densely (csrc/pds_types.h SplitReset: same draws, same bits).  Not with injected variates (parity
+  // replays) -- their reset rows carry the kCtrOhBit bookkeeping of the in-place path.
   const bool split = h->split_reset && h->cfg.auto_reset && d_variates == nullptr && kind == kLaunchStep &&
                      split_reset_supported(h->cfg.task, lf);
   launch_family(h, split ? kLaunchStepSplit : kind, lf, grid, (hipStream_t)stream, a);

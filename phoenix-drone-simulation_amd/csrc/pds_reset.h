@@ -652,6 +652,33 @@ constexpr int variates_floats() {
   return V::LAT ? kVarResetFloats + kVarNoiseFloats + 4 * kLatRowBlocks : (V::ON ? kVarResetFloats + kVarNoiseFloats : kVarResetFloats);
 }
 
+// Philox block j of a reset (DirectWords::scratch_block order) -> the standard variates of the block's role, at their place in an
+// env's LdsVariates image `dst`
+PDS_DEV void store_block_variates(const U4 &w, int j, float *dst) {
+  if (j < kResetBlocks) {
+    float f[4];
+    if (j == 3 || j == 4) {
+      words_to_normals4(w, f);
+    } else if (j == kRawWordsBlock) {
+      f[0] = __uint_as_float(w.x); f[1] = __uint_as_float(w.y); f[2] = __uint_as_float(w.z); f[3] = __uint_as_float(w.w);
+    } else {
+      words_to_uniforms4(w, f);
+    }
+    *reinterpret_cast<float4 *>(dst + 4 * j) = make_float4(f[0], f[1], f[2], f[3]);
+  } else if (j < kResetBlocks + kResetNoiseBlocks) {
+    const int nb = j - kResetBlocks;
+    float f[8];
+    words_to_noise8(w, nb % kObsCallBlocks, f);
+    *reinterpret_cast<float4 *>(dst + kVarResetFloats + 8 * nb) = make_float4(f[0], f[1], f[2], f[3]);
+    *reinterpret_cast<float4 *>(dst + kVarResetFloats + 8 * nb + 4) = make_float4(f[4], f[5], f[6], f[7]);
+  } else {
+    float f[4];
+    words_to_normals4(w, f);
+    *reinterpret_cast<float4 *>(dst + kVarResetFloats + kVarNoiseFloats + 4 * (j - kResetBlocks - kResetNoiseBlocks)) =
+        make_float4(f[0], f[1], f[2], f[3]);
+  }
+}
+
 // fill_reset_scratch + conversion: lane j of an env's group computes Philox block j AND turns its four words into the
 // standard variates of the block's role (words_to_*), so that the one or two lanes that evaluate the reset read floats
 // instead of running ~20 Box-Muller pairs and ~30 uniform conversions in a row (~260 of the ~1100 vector instructions
@@ -674,32 +701,7 @@ PDS_DEV void fill_reset_variates(const StepArgs &a, const RngKey &rk, const uint
     bool need = false;
 #pragma unroll
     for (int c = 0; c < NB; ++c) need = need || (c == j && block_needed<V>(c));
-    if (on && need) {
-      const U4 w = dw.scratch_block(j);
-      float *dst = var + slot * VF;
-      if (j < kResetBlocks) {
-        float f[4];
-        if (j == 3 || j == 4) {
-          words_to_normals4(w, f);
-        } else if (j == kRawWordsBlock) {
-          f[0] = __uint_as_float(w.x); f[1] = __uint_as_float(w.y); f[2] = __uint_as_float(w.z); f[3] = __uint_as_float(w.w);
-        } else {
-          words_to_uniforms4(w, f);
-        }
-        *reinterpret_cast<float4 *>(dst + 4 * j) = make_float4(f[0], f[1], f[2], f[3]);
-      } else if (j < kResetBlocks + kResetNoiseBlocks) {
-        const int nb = j - kResetBlocks;
-        float f[8];
-        words_to_noise8(w, nb % kObsCallBlocks, f);
-        *reinterpret_cast<float4 *>(dst + kVarResetFloats + 8 * nb) = make_float4(f[0], f[1], f[2], f[3]);
-        *reinterpret_cast<float4 *>(dst + kVarResetFloats + 8 * nb + 4) = make_float4(f[4], f[5], f[6], f[7]);
-      } else {
-        float f[4];
-        words_to_normals4(w, f);
-        *reinterpret_cast<float4 *>(dst + kVarResetFloats + kVarNoiseFloats + 4 * (j - kResetBlocks - kResetNoiseBlocks)) =
-            make_float4(f[0], f[1], f[2], f[3]);
-      }
-    }
+    if (on && need) store_block_variates(dw.scratch_block(j), j, var + slot * VF);
   }
 }
 
@@ -854,9 +856,12 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const StepArgs a) {
 }
 
 // The auto-reset of a SplitReset<V> step kernel (csrc/pds_types.h), launched behind it on the same stream: that kernel stored the
-// finished envs' TERMINAL state, left their last observation in the obs row and set the flags.  One block per 1024 envs:
-//   1. every thread reads the flags of 4 consecutive envs and appends the finished ones to an LDS queue;
-//   2. the queue is served densely, one env per lane: the env's last observation row is copied to final_obs, then the reset of the
+// finished envs' TERMINAL state, left their last observation in the obs row and set the flags.  One WAVE (= block) per 1024 envs
+// -- a reset is a ~3 500-instruction dependent chain for the lane that evaluates it, whatever else its block does, so what
+// matters is that all 1024 waves of a 2^20-env launch are resident at once (a 256-thread block with one working wave held
+// four waves' registers: 20.7 us; the Philox blocks computed side by side by four waves through LDS + block barriers: 30.2):
+//   1. every lane reads the flags of 16 consecutive envs and appends the finished ones to an LDS queue;
+//   2. the queue is served one env per lane: the env's last observation row is copied to final_obs, then the reset of the
 //      explicit reset kernel above (every lane computes its own Philox blocks: DirectWords) with the inputs the in-place reset
 //      takes from its registers read back from the stored state -- the terminal body rates (the reference re-initialises the gyro
 //      low-pass with them, envs/base.py:411), the gyro bias, Circle's ref_offset -- and the step's tick (the clock word has
@@ -864,34 +869,48 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const StepArgs a) {
 //      the envs).  Same functions, same draws, same bits as the in-place reset (tests/test_gpu_properties.py).
 // a.k_steps = reset_store's oh_mode (what the step kernel in front keeps of the noisy observation: 0 regenerated, 2 Kalman hold).
 template <class V>
-__global__ __launch_bounds__(256) void post_reset_kernel(const StepArgs a) {
+__global__ __launch_bounds__(kWave) void post_reset_kernel(const StepArgs a) {
+  constexpr int D = V::D;
+  constexpr int kPer = kPostResetEnvsPerBlock / kWave;  // flags per lane
+  static_assert(kPer == 16 || kPer == 8 || kPer == 4, "one 16- / 8- / 4-byte load of each flag array per lane");
   __shared__ uint32_t queue[kPostResetEnvsPerBlock];
   __shared__ int qn;
-  constexpr int D = V::D;
   const float2 *ref_lds = nullptr;
+  const int lane = threadIdx.x;
   const long long base = (long long)blockIdx.x * kPostResetEnvsPerBlock;
-  if (threadIdx.x == 0) qn = 0;
-  __syncthreads();
+  if (lane == 0) qn = 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
   {
-    const long long e0 = base + 4ll * threadIdx.x;
-    uint32_t fl = 0u;
-    if (e0 + 3 < a.n && ((reinterpret_cast<uintptr_t>(a.term) | reinterpret_cast<uintptr_t>(a.trunc)) & 3u) == 0) {
-      fl = *reinterpret_cast<const uint32_t *>(a.term + e0) | *reinterpret_cast<const uint32_t *>(a.trunc + e0);
+    const long long e0 = base + (long long)kPer * lane;
+    uint32_t fl[4] = {0u, 0u, 0u, 0u};
+    if (e0 + kPer <= a.n && ((reinterpret_cast<uintptr_t>(a.term) | reinterpret_cast<uintptr_t>(a.trunc)) & (uintptr_t)(kPer - 1)) == 0) {
+      if constexpr (kPer == 16) {
+        const uint4 t4 = *reinterpret_cast<const uint4 *>(a.term + e0), u4 = *reinterpret_cast<const uint4 *>(a.trunc + e0);
+        fl[0] = t4.x | u4.x; fl[1] = t4.y | u4.y; fl[2] = t4.z | u4.z; fl[3] = t4.w | u4.w;
+      } else if constexpr (kPer == 8) {
+        const uint2 t2 = *reinterpret_cast<const uint2 *>(a.term + e0), u2 = *reinterpret_cast<const uint2 *>(a.trunc + e0);
+        fl[0] = t2.x | u2.x; fl[1] = t2.y | u2.y;
+      } else {
+        fl[0] = *reinterpret_cast<const uint32_t *>(a.term + e0) | *reinterpret_cast<const uint32_t *>(a.trunc + e0);
+      }
     } else {
-      for (int j = 0; j < 4; ++j)
-        if (e0 + j < a.n && (a.term[e0 + j] | a.trunc[e0 + j])) fl |= 1u << (8 * j);
+      for (int j = 0; j < kPer; ++j)
+        if (e0 + j < a.n && (a.term[e0 + j] | a.trunc[e0 + j])) fl[j >> 2] |= 1u << (8 * (j & 3));
     }
-    if (fl != 0u) {
+    if ((fl[0] | fl[1] | fl[2] | fl[3]) != 0u) {
       int cnt = 0;
-      for (int j = 0; j < 4; ++j) cnt += ((fl >> (8 * j)) & 0xFFu) != 0u;
+      for (int j = 0; j < kPer; ++j) cnt += ((fl[j >> 2] >> (8 * (j & 3))) & 0xFFu) != 0u;
       int at_ = atomicAdd(&qn, cnt);
-      for (int j = 0; j < 4; ++j)
-        if (((fl >> (8 * j)) & 0xFFu) != 0u) queue[at_++] = 4u * threadIdx.x + (uint32_t)j;
+      for (int j = 0; j < kPer; ++j)
+        if (((fl[j >> 2] >> (8 * (j & 3))) & 0xFFu) != 0u) queue[at_++] = (uint32_t)(kPer * lane + j);
     }
   }
-  __syncthreads();
-  const int n_fin = qn;
-  for (int idx = threadIdx.x; idx < n_fin; idx += 256) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  const int n_fin = __builtin_amdgcn_readfirstlane(qn);
+  for (int idx = lane; idx < n_fin; idx += kWave) {
     const long long i = base + queue[idx];
     // the step's tick: the step kernel has advanced the tile's clock word by one
     const WaveClock clk = a.st.clk[i / kWave];

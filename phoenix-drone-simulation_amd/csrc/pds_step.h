@@ -1236,7 +1236,7 @@ inline void launch_variant(int kind, bool half_tile, dim3 grid, hipStream_t s, c
     // they get here, so only the folded variants are instantiated (48 kernels instead of 472)
     if constexpr (!V::GE && !V::TN && V::CTRL == 0 && !V::HOLD) {
       if (kind == kLaunchReset) hipLaunchKernelGGL((reset_kernel<V>), grid, dim3(kBlock), 0, s, a);
-      else if constexpr (V::ON || V::LAT) hipLaunchKernelGGL((post_reset_kernel<V>), grid, dim3(256), 0, s, a);
+      else if constexpr (V::ON || V::LAT) hipLaunchKernelGGL((post_reset_kernel<V>), grid, dim3(kWave), 0, s, a);
       else abort();
     } else abort();
   } else if (kind == kLaunchStepK) {

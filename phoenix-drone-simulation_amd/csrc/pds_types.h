@@ -383,7 +383,10 @@ inline bool split_reset_supported(int task, const LaunchFlags &f) { return inlin
 // kLaunchStepSplit / kLaunchPostReset: the single-step kernel without its in-place reset (SplitReset<V>) and the dense reset
 // launched behind it.
 enum LaunchKind { kLaunchStep = 0, kLaunchStepK = 1, kLaunchReset = 2, kLaunchStepStored = 3, kLaunchStepSplit = 4, kLaunchPostReset = 5 };
-constexpr int kPostResetEnvsPerBlock = 1024;
+#ifndef PDS_POST_RESET_ENVS
+#define PDS_POST_RESET_ENVS 1024  // envs per wave of post_reset_kernel (A/B: 512, 256)
+#endif
+constexpr int kPostResetEnvsPerBlock = PDS_POST_RESET_ENVS;
 // one translation unit per (task, family) keeps the build parallel: pds_task_*.hip
 // Arguments of the fused rollout (csrc/pds_rollout.h).
 struct RolloutArgs {

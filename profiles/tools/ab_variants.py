@@ -52,7 +52,7 @@ def main():
     for lib in libs:
         settings.append((lib, {}))
     if os.environ.get("AB_SPLIT"):  # round 6: in-place reset (PDS_SPLIT_RESET=0) against SplitReset step kernel + post_reset_kernel
-        settings = [(libs[-1] + " in-place-reset", {"PDS_SPLIT_RESET": "0"}), (libs[-1] + " split-reset", {"PDS_SPLIT_RESET": "1"})]
+        settings = [(libs[0] + " in-place-reset", {"PDS_SPLIT_RESET": "0"})] + [(l + " split-reset", {"PDS_SPLIT_RESET": "1"}) for l in libs]
     if os.environ.get("AB_STORED"):  # (builds with PDS_STORED_OH_FROM_AGG > 0 only)
         settings.append((libs[-1] + " regen@agg>=2", {"PDS_STORED_OH_FROM_AGG": "0"}))
     N, steps = 1 << 20, 300

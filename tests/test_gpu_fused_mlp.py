@@ -188,8 +188,18 @@ def test_gradients_are_deterministic_and_size_limits_are_checked():
     fm.ppo_grad(x, a, adv, lp, ls, 0.2); g1 = fm.flat_grad.clone()
     fm.ppo_grad(x, a, adv, lp, ls, 0.2); g2 = fm.flat_grad.clone()
     assert torch.equal(g1, g2)
-    with pytest.raises((ValueError, NotImplementedError)):
-        FusedMLP(_net(70, 50, 50, 4, "relu", 0), "relu")
+    # size limits: d_in <= 192 (round 6: the K-tiled kernels; 64 before), hidden <= 64, d_out <= 8
+    FusedMLP(_net(192, 64, 64, 8, "relu", 0), "relu")
+    for shape in ((193, 50, 50, 4), (34, 65, 50, 4), (34, 50, 65, 4), (34, 50, 50, 9)):
+        with pytest.raises((ValueError, NotImplementedError)):
+            FusedMLP(_net(*shape, "relu", 0), "relu")
+    # the wide kernels are deterministic too (one partial per wave, summed in a fixed order)
+    netw = _net(136, 64, 64, 4, "relu", 4)
+    fw = FusedMLP(netw, "relu")
+    xw = torch.randn(B, 136, device="cuda")
+    fw.ppo_grad(xw, a, adv, lp, ls, 0.2); g1 = fw.flat_grad.clone()
+    fw.ppo_grad(xw, a, adv, lp, ls, 0.2); g2 = fw.flat_grad.clone()
+    assert torch.equal(g1, g2)
 
 
 def test_adam_step_matches_torch_adam():

@@ -524,7 +524,7 @@ def test_split_reset_equals_the_in_place_reset_bitwise(task, kw, monkeypatch):
         fin = (ra[2] | ra[3])
         finished += int(fin.sum())
         assert torch.equal(ra[4]["final_obs"][fin], rb[4]["final_obs"][fin]), k
-    assert finished > 4 * n
+    assert finished >= 4 * n  # (every env at least by the 11-step limit; most configurations also by termination)
     sa, sb = envs[0].state_dict(), envs[1].state_dict()
     assert sa.keys() == sb.keys()
     for key in sa:
