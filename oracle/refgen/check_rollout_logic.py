@@ -52,6 +52,7 @@ EPOCHS_TOTAL, EPOCHS_RUN, STEPS, MINI, V_ITERS, PI_ITERS = 8, 3, 1000, 4, 2, 10
 # name -> (TimeLimit override, seed); seed 8 is the first whose epoch 0 ends on a TERMINATED step (the reference bootstraps that
 # path with V(o) like any other epoch-end cut, iwpg.py:374-379)
 SCENARIOS = {"limit500": (None, 3), "limit12": (12, 3), "limit500_term_at_cut": (None, 8)}
+REPLAY_BUFFERS = False  # --full-size --replay-buffers
 
 
 def build_reference(limit, seed=3, np_seed=20261003):
@@ -257,9 +258,22 @@ def run_ours_live(limit, seed, g, states, ppo):
         row["ep_len_sum"] = (stats[1], int(g[f"e{e}_ep_len"].sum()))
         row["ep_ret_sum"] = (stats[0], float(g[f"e{e}_ep_ret"].sum()))
         report.append(row)
+        if REPLAY_BUFFERS:  # the update from the REFERENCE's buffers (isolates update() from the rollout's 1e-6 differences)
+            T = STEPS
+            f = lambda name: torch.as_tensor(g[f"e{e}_{name}"])  # noqa: E731
+            tr.obs_buf.copy_(f("obs_buf")[:, None]); tr.act_buf.copy_(f("act_buf")[:, None]); tr.rew_buf.copy_(f("rew_buf")[:, None])
+            tr.val_buf.copy_(f("val_buf")[:, None]); tr.logp_buf.copy_(f("logp_buf")[:, None])
+            got2 = buffers_of(tr, ppo)
+            row["gae_from_reference_buffers"] = tuple(float(np.max(np.abs(got2[k] - g[f"e{e}_{k}"]))) for k in ("adv_buf", "target_val_buf", "discounted_ret_buf"))
         tr.update()
-        worst = max(float(np.max(np.abs(p_.numpy() - g[f"e{e}_sd_after__" + k]))) for k, p_ in tr.ac.state_dict().items())
+        diffs = {k: float(np.max(np.abs(p_.numpy() - g[f"e{e}_sd_after__" + k]))) for k, p_ in tr.ac.state_dict().items()}
+        worst = max(diffs.values())
         row["state_dict_after_update"] = worst
+        row["state_dict_worst_keys"] = sorted(diffs.items(), key=lambda kv: -kv[1])[:3]
+        if REPLAY_BUFFERS:  # continue from the reference's parameters: every epoch is then an independent check
+            with torch.no_grad():
+                for k, p_ in tr.ac.state_dict().items():
+                    p_.copy_(torch.as_tensor(g[f"e{e}_sd_after__" + k]))
         tr.scheduler.step()
         tr.epoch += 1
     return report
@@ -278,7 +292,19 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "rollout.npz"))
     ap.add_argument("--no-write", action="store_true")
+    ap.add_argument("--full-size", action="store_true",
+                    help="the reference's own epoch (32 000 steps, 16 mini-batches x 5 value iterations, 80 policy iterations) instead of "
+                         "the fixture's small one; first scenario only, implies --no-write (a few minutes per epoch)")
+    ap.add_argument("--replay-buffers", action="store_true",
+                    help="with --full-size: run update() from the REFERENCE's rollout buffers and re-synchronise the parameters after each "
+                         "epoch (Adam amplifies the rollout's 1e-6 differences over 80 iterations otherwise)")
     a = ap.parse_args()
+    if a.full_size:
+        global STEPS, MINI, V_ITERS, PI_ITERS, EPOCHS_TOTAL, SCENARIOS, REPLAY_BUFFERS
+        REPLAY_BUFFERS = a.replay_buffers
+        STEPS, MINI, V_ITERS, PI_ITERS, EPOCHS_TOTAL = 32000, 16, 5, 80, 40
+        SCENARIOS = {"limit500_full_size": (None, 3)}
+        a.no_write = True
     torch.set_num_threads(1)
     ppo = load_ppo()
     out, failed = {}, []

@@ -112,7 +112,9 @@ PDS_DEV uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
 #endif
 }
 
-template <int ROUNDS>
+// X3: see philox4x32_10_or_7 below (default: the 7-round per-step noise blocks use v_bitop3_b32, the 10-round reset / sampling
+// blocks plain xors)
+template <int ROUNDS, bool X3 = (ROUNDS == 7)>
 PDS_DEV U4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {
@@ -120,8 +122,8 @@ PDS_DEV U4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32
     // (noisy Hover step 138 us vs 170 us)
     const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
     const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-    const uint32_t n0 = xor3(hi1, c1, k0);
-    const uint32_t n2 = xor3(hi0, c3, k1);
+    const uint32_t n0 = X3 ? xor3(hi1, c1, k0) : (hi1 ^ c1 ^ k0);
+    const uint32_t n2 = X3 ? xor3(hi0, c3, k1) : (hi0 ^ c3 ^ k1);
     c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
@@ -133,6 +135,11 @@ PDS_DEV U4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32
 // 10-round and the 7-round code one after the other: a round is ~14 vector instructions, ~60 cycles of the
 // wave's VALU time whatever the number of active lanes; v_mul_lo/hi_u32 issue at the v_fma_f32 rate on gfx950,
 // profiles/r02_valu_issue.txt.)
+// X3: the three-input xors as v_bitop3_b32 (xor3 above) -- what the observation-noise / latency variants gained 1.5 % from in round 5.
+// false (plain `^`, two v_xor_b32) for the merged in-register reset of the variants WITHOUT noise or latency: there v_bitop3's
+// register operands cost the half-tile PT1 + DR kernel (BASELINE config 3, 128-VGPR cap) 4 spilled VGPRs and 1.7 % (same box,
+// round-4 library 19.74 us, round 5 / 6 with xor3 20.1; profiles/r06_ab_vs_round4.txt).  Same bits either way.
+template <bool X3 = true>
 PDS_DEV U4 philox4x32_10_or_7(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, bool seven) {
   U4 at7{0u, 0u, 0u, 0u};
 #pragma unroll
@@ -140,8 +147,8 @@ PDS_DEV U4 philox4x32_10_or_7(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3
     if (r == 7) at7 = U4{c0, c1, c2, c3};
     const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
     const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-    const uint32_t n0 = xor3(hi1, c1, k0);
-    const uint32_t n2 = xor3(hi0, c3, k1);
+    const uint32_t n0 = X3 ? xor3(hi1, c1, k0) : (hi1 ^ c1 ^ k0);
+    const uint32_t n2 = X3 ? xor3(hi0, c3, k1) : (hi0 ^ c3 ^ k1);
     c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }

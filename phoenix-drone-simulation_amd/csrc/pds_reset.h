@@ -60,12 +60,13 @@ struct DirectWords {
   PDS_DEV U4 lat_block(uint32_t r) const { return philox4x32_10(env_id, tick_lo, tick_hi, kBlkLatRows + r, seed_lo, seed_hi); }
   // scratch slot j of the cooperative fill (LdsWords layout): reset / latency-row blocks take 10 rounds, the
   // noise blocks 7 -- evaluated in one instruction stream for all lanes of the wave
+  template <bool X3 = true>
   PDS_DEV U4 scratch_block(int j) const {
     const bool noise = j >= kResetBlocks && j < kResetBlocks + kResetNoiseBlocks;
     const uint32_t blk = j < kResetBlocks ? kBlkReset + (uint32_t)j
                          : (noise ? kBlkResetNoise + (uint32_t)(j - kResetBlocks)
                                   : kBlkLatRows + (uint32_t)(j - kResetBlocks - kResetNoiseBlocks));
-    return philox4x32_10_or_7(env_id, tick_lo, tick_hi, blk, seed_lo, seed_hi, noise);
+    return philox4x32_10_or_7<X3>(env_id, tick_lo, tick_hi, blk, seed_lo, seed_hi, noise);
   }
   PDS_DEV void uniforms4(uint32_t b, float (&u)[4]) const { words_to_uniforms4(reset_block(b), u); }
   PDS_DEV U4 raw4(uint32_t b) const { return reset_block(b); }
@@ -642,7 +643,7 @@ PDS_DEV void fill_reset_scratch(const StepArgs &a, const RngKey &rk, const uint3
     bool need = false;
 #pragma unroll
     for (int c = 0; c < NB; ++c) need = need || (c == j && block_needed<V>(c));
-    if (on && need) scratch[slot * STRIDE + j] = dw.scratch_block(j);
+    if (on && need) scratch[slot * STRIDE + j] = dw.template scratch_block<V::ON || V::LAT>(j);  // (see philox4x32_10_or_7)
   }
 }
 
