@@ -135,14 +135,34 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void rollout_hist_kernel(const 
       const float *krow = tile + lane * TS;
       const float *newest = dn ? fin + lane * D + HALF : krow + HALF;
       const int keep = HS - HALF;
+      // (blocks of reads, then the block's writes: a read-then-write loop over one array serialises on the LDS latency of every
+      //  element -- the compiler must assume the two alias --, ~130 cycles x 51 moves for Hover H = 4: 18.7 -> 13 us per step)
       if constexpr (HALF % 4 == 0) {  // 16-byte aligned halves: b128 moves (8 consecutive lanes cover all banks)
-        for (int j = 0; j < keep; j += 4) *reinterpret_cast<float4 *>(hrow + j) = *reinterpret_cast<const float4 *>(hrow + j + HALF);
+        for (int j0 = 0; j0 < keep; j0 += 32) {
+          float4 buf[8];
 #pragma unroll
-        for (int c = 0; c < HALF; c += 4) *reinterpret_cast<float4 *>(hrow + keep + c) = *reinterpret_cast<const float4 *>(newest + c);
+          for (int u = 0; u < 8; ++u) buf[u] = (j0 + 4 * u < keep) ? *reinterpret_cast<const float4 *>(hrow + j0 + 4 * u + HALF) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) if (j0 + 4 * u < keep) *reinterpret_cast<float4 *>(hrow + j0 + 4 * u) = buf[u];
+        }
+        float4 nb[HALF / 4];
+#pragma unroll
+        for (int c = 0; c < HALF / 4; ++c) nb[c] = *reinterpret_cast<const float4 *>(newest + 4 * c);
+#pragma unroll
+        for (int c = 0; c < HALF / 4; ++c) *reinterpret_cast<float4 *>(hrow + keep + 4 * c) = nb[c];
       } else {
-        for (int j = 0; j < keep; ++j) hrow[j] = hrow[j + HALF];
+        for (int j0 = 0; j0 < keep; j0 += 16) {
+          float buf[16];
 #pragma unroll
-        for (int c = 0; c < HALF; ++c) hrow[keep + c] = newest[c];
+          for (int u = 0; u < 16; ++u) buf[u] = (j0 + u < keep) ? hrow[j0 + u + HALF] : 0.f;
+#pragma unroll
+          for (int u = 0; u < 16; ++u) if (j0 + u < keep) hrow[j0 + u] = buf[u];
+        }
+        float nb[HALF];
+#pragma unroll
+        for (int c = 0; c < HALF; ++c) nb[c] = newest[c];
+#pragma unroll
+        for (int c = 0; c < HALF; ++c) hrow[keep + c] = nb[c];
       }
       // the final history of an env the TimeLimit cut bootstraps its path with V (also when it terminated on that step, and
       // for every env that finished on the rollout's last step: algs/iwpg/iwpg.py:374-379) -> the caller's slot list
@@ -167,11 +187,14 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void rollout_hist_kernel(const 
         __builtin_amdgcn_wave_barrier();  // (the rows are overwritten below)
       }
       if (dn) {  // restart: H - 1 copies of the reset row's first half, then its second half (envs/base.py:417-431)
+        float k0[HALF], k1[HALF];
+#pragma unroll
+        for (int c = 0; c < HALF; ++c) { k0[c] = krow[c]; k1[c] = krow[HALF + c]; }
         for (int j = 0; j < H - 1; ++j)
 #pragma unroll
-          for (int c = 0; c < HALF; ++c) hrow[j * HALF + c] = krow[c];
+          for (int c = 0; c < HALF; ++c) hrow[j * HALF + c] = k0[c];
 #pragma unroll
-        for (int c = 0; c < HALF; ++c) hrow[keep + c] = krow[HALF + c];
+        for (int c = 0; c < HALF; ++c) hrow[keep + c] = k1[c];
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -180,11 +203,38 @@ __global__ __launch_bounds__(kRolloutThreads, 1) void rollout_hist_kernel(const 
       {
         float *dst = rl.obs_buf + ((long long)(s + 1) * rl.s.n + wave_base) * HS;
         const int total = rows * HS;
-        int r = lane / HS, c = lane - r * HS;
-        for (int idx = lane; idx < total; idx += kWave) {
-          nt_store(dst + idx, hist[r * S1 + c]);
-          c += kWave;
-          while (c >= HS) { c -= HS; ++r; }
+        // 16-byte stores where the rows allow it (H half a multiple of 4: Circle, TakeOff, Hover at H = 4 / 8; the piece of obs_buf
+        // 16-byte aligned): the first form of this copy, 4 bytes per lane and store, was 68 store instructions per step at H = 4 --
+        // the release fence behind them waits for every one of them
+        if ((HS & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+          const int q4 = HS >> 2, total4 = total >> 2;  // float4 per row / in all
+          int r = lane / q4, c4 = lane - r * q4;
+          for (int idx0 = lane; idx0 < total4; idx0 += 4 * kWave) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              v[u] = (idx0 + u * kWave < total4) ? *reinterpret_cast<const float4 *>(hist + r * S1 + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+              c4 += kWave;
+              while (c4 >= q4) { c4 -= q4; ++r; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              if (idx0 + u * kWave < total4) nt_store4(reinterpret_cast<float4 *>(dst) + idx0 + u * kWave, v[u]);
+          }
+        } else {
+          int r = lane / HS, c = lane - r * HS;
+          for (int idx0 = lane; idx0 < total; idx0 += 8 * kWave) {  // eight LDS reads in flight, then their stores
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              v[u] = (idx0 + u * kWave < total) ? hist[r * S1 + c] : 0.f;
+              c += kWave;
+              while (c >= HS) { c -= HS; ++r; }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              if (idx0 + u * kWave < total) nt_store(dst + idx0 + u * kWave, v[u]);
+          }
         }
       }
       rollout_post(&obs_ready, lane);  // the histories of step s + 1 are in LDS
