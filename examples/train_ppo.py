@@ -29,7 +29,13 @@ def main():
     ap.add_argument("--epochs", type=int, default=300)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--log-dir", default=None)
+    ap.add_argument("--observation-history-size", type=int, default=2,
+                    help="the reference's history of [o, u] pairs fed to the networks (envs/base.py:44; experiments/04_*: 1, 2, 4, 6, 8); "
+                         "up to 192 network inputs stay on the fused kernels and the rollout is one launch (pds_rollout_history)")
+    ap.add_argument("--pi-hidden", type=int, nargs=2, default=(50, 50), help="policy hidden sizes (experiments/04_*: 32 32 / 48 48 / 64 64)")
     args = ap.parse_args()
+    env_kw = dict(observation_history_size=args.observation_history_size) if args.observation_history_size != 2 else {}
+    ac_kwargs = {"pi": {"hidden_sizes": tuple(args.pi_hidden), "activation": "relu"}, "val": {"hidden_sizes": (64, 64), "activation": "tanh"}}
     # one process per GPU (the reference: mpi_fork over CPU cores, examples/train_with_multi_cores.py):
     #   python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/train_ppo.py ...
     # every rank steps its shard of the envs; gradients and running statistics are averaged over RCCL
@@ -39,10 +45,10 @@ def main():
         from phoenix_drone_simulation_amd.sharding import make_sharded
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         dist.init_process_group("nccl")
-        env = make_sharded(args.env, args.num_envs * world, seed=args.seed)
+        env = make_sharded(args.env, args.num_envs * world, seed=args.seed, **env_kw)
     else:
-        env = pds.make(args.env, num_envs=args.num_envs, seed=args.seed)  # the reference's default config
-    trainer = PPOTrainer(env, rollout_len=args.rollout_len, epochs=args.epochs, seed=args.seed)
+        env = pds.make(args.env, num_envs=args.num_envs, seed=args.seed, **env_kw)  # the reference's default config
+    trainer = PPOTrainer(env, rollout_len=args.rollout_len, epochs=args.epochs, seed=args.seed, ac_kwargs=ac_kwargs)
     t0 = time.time()
     for e in range(args.epochs):
         i = trainer.learn_one_epoch()
