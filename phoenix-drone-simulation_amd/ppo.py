@@ -227,9 +227,12 @@ class PPOTrainer:
                  use_linear_lr_decay=True, use_exploration_noise_anneal=True, use_reward_scaling=True,
                  use_standardized_obs=True, use_max_grad_norm=False, max_grad_norm=0.5, ac_kwargs=None,
                  seed=0, fused=None, graph_rollout=None, fused_rollout=None, reset_each_rollout=False,
-                 overlap_value_update=True):
+                 overlap_value_update=True, log_reference_columns=False):
         self.env, self.T, self.N = env, int(rollout_len), env.num_envs
         self.overlap_value_update, self._side_stream = bool(overlap_value_update), None
+        # also log what the reference's progress.csv carries per epoch besides EpRet / EpLen (Values/V/Mean, Misc/RewScaleMean,
+        # Misc/RewScaleStddev: algs/iwpg/iwpg.py:524-563) -- three host syncs per epoch, for comparisons of whole runs
+        self.log_reference_columns = bool(log_reference_columns)
         self.epochs, self.gamma, self.lam, self.clip_ratio = epochs, gamma, lam, clip_ratio
         self.entropy_coef = entropy_coef if use_entropy else 0.0
         self.train_pi_iterations, self.train_v_iterations = train_pi_iterations, train_v_iterations
@@ -664,7 +667,14 @@ class PPOTrainer:
         if self.use_exploration_noise_anneal:
             self.ac.update(frac=self.epoch / self.epochs)
         stats = self.roll_out()
+        extra = {}
+        if self.log_reference_columns:
+            extra["values_v_mean"] = float(self.val_buf.mean())
         info = self.update()
+        if self.log_reference_columns and self.ac.ret_oms is not None:  # (the logger reads them after update_running_statistics)
+            extra["rew_scale_mean"] = float(self.ac.ret_oms.mean)
+            extra["rew_scale_std"] = float(self.ac.ret_oms.std)
+        info.update(extra)
         bad_here = not (math.isfinite(info["loss_pi"]) and math.isfinite(info["loss_v"]))
         if _collectives():
             # the losses are rank-local (the shard that holds a NaN env sees it first): decide TOGETHER, or the

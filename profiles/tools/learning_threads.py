@@ -23,6 +23,15 @@ def run_all(seeds, num_envs, threads, env_id, epochs=40, spe=32000):
     return {s: (np.array([r["ep_len"] for r in logs[s]]), np.array([r["ep_ret"] for r in logs[s]])) for s in seeds}
 
 
+def run_all_columns(seeds, num_envs, threads, env_id, epochs=40, spe=32000):
+    """-> {seed: {column: [epochs]}} with the reference's other progress.csv columns (PPOTrainer(log_reference_columns=True))"""
+    from phoenix_drone_simulation_amd.ppo import train_runs_side_by_side
+    logs = train_runs_side_by_side(env_id, seeds, num_envs, spe // num_envs, epochs, threads=threads,
+                                   trainer_kwargs=dict(reset_each_rollout=True, log_reference_columns=True))
+    cols = ("ep_len", "ep_ret", "loss_pi", "loss_v", "values_v_mean", "rew_scale_mean", "rew_scale_std", "ratio")
+    return {s: {c: [float(r.get(c, float("nan"))) for r in logs[s]] for c in cols} for s in seeds}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=8)
@@ -32,12 +41,20 @@ def main():
     ap.add_argument("--first-seed", type=int, default=100)
     ap.add_argument("--out", default=None)
     ap.add_argument("--no-check", action="store_true", help="skip the two sequential runs that check determinism")
+    ap.add_argument("--columns", action="store_true", help="record the reference's other progress.csv columns too (implies --no-check)")
     a = ap.parse_args()
     import torch
     import phoenix_drone_simulation_amd as pds  # noqa: F401  (imported once, before the threads)
     from phoenix_drone_simulation_amd.ppo import PPOTrainer  # noqa: F401
     torch.cuda.init()
     seeds = list(range(a.first_seed, a.first_seed + a.seeds))
+    if a.columns:
+        import json
+        t0 = time.time()
+        out = run_all_columns(seeds, a.envs, a.threads, a.env_id)
+        print(f"{a.seeds} seeds x {a.envs} envs in {a.threads} threads: {time.time() - t0:.1f} s")
+        json.dump({str(s): out[s] for s in seeds}, open(a.out, "w"))
+        return
     t0 = time.time()
     out = run_all(seeds, a.envs, a.threads, a.env_id)
     dt = time.time() - t0
