@@ -298,10 +298,14 @@ def main():
     ap.add_argument("--replay-buffers", action="store_true",
                     help="with --full-size: run update() from the REFERENCE's rollout buffers and re-synchronise the parameters after each "
                          "epoch (Adam amplifies the rollout's 1e-6 differences over 80 iterations otherwise)")
+    ap.add_argument("--epochs-run", type=int, default=0, help="with --full-size: epochs to compare (default 3)")
     a = ap.parse_args()
     if a.full_size:
         global STEPS, MINI, V_ITERS, PI_ITERS, EPOCHS_TOTAL, SCENARIOS, REPLAY_BUFFERS
         REPLAY_BUFFERS = a.replay_buffers
+        if a.epochs_run:
+            global EPOCHS_RUN
+            EPOCHS_RUN = a.epochs_run
         STEPS, MINI, V_ITERS, PI_ITERS, EPOCHS_TOTAL = 32000, 16, 5, 80, 40
         SCENARIOS = {"limit500_full_size": (None, 3)}
         a.no_write = True

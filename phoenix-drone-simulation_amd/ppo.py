@@ -670,7 +670,14 @@ class PPOTrainer:
         extra = {}
         if self.log_reference_columns:
             extra["values_v_mean"] = float(self.val_buf.mean())
+            with torch.no_grad():  # the policy's means over the epoch's batch before the update (for the reference's `KL` column)
+                obs_std = self.ac.obs_oms(self.obs_buf.reshape(self.T * self.N, -1)) if self.use_standardized_obs else self.obs_buf.reshape(self.T * self.N, -1)
+                mu_old = self.ac.pi.net(obs_std)
         info = self.update()
+        if self.log_reference_columns:
+            with torch.no_grad():  # torch_kl of update_policy_net (algs/iwpg/iwpg.py:437-439): KL(p_old || p_new), mean over batch and action dims
+                mu_new = self.ac.pi.net(obs_std)
+                extra["kl"] = float((((mu_old - mu_new) ** 2) / (2 * torch.exp(2 * self.ac.pi.log_std))).mean())
         if self.log_reference_columns and self.ac.ret_oms is not None:  # (the logger reads them after update_running_statistics)
             extra["rew_scale_mean"] = float(self.ac.ret_oms.mean)
             extra["rew_scale_std"] = float(self.ac.ret_oms.std)

@@ -28,7 +28,7 @@ def run_all_columns(seeds, num_envs, threads, env_id, epochs=40, spe=32000):
     from phoenix_drone_simulation_amd.ppo import train_runs_side_by_side
     logs = train_runs_side_by_side(env_id, seeds, num_envs, spe // num_envs, epochs, threads=threads,
                                    trainer_kwargs=dict(reset_each_rollout=True, log_reference_columns=True))
-    cols = ("ep_len", "ep_ret", "loss_pi", "loss_v", "values_v_mean", "rew_scale_mean", "rew_scale_std", "ratio")
+    cols = ("ep_len", "ep_ret", "loss_pi", "loss_v", "values_v_mean", "rew_scale_mean", "rew_scale_std", "kl")
     return {s: {c: [float(r.get(c, float("nan"))) for r in logs[s]] for c in cols} for s in seeds}
 
 
