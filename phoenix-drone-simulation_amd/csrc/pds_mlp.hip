@@ -28,6 +28,8 @@
 // Round 3: the PPO gradient of the reference's default policy (50-50 relu) runs on ppo_split_kernel below instead --
 // the two waves of a SIMD take different ROLES on the same tiles (forward / loss / small GEMMs vs. the large
 // weight-gradient GEMMs) so that neither carries 128 accumulator registers through phases that do not need them.
+#include <stdlib.h>
+
 #include "pds_mlp_common.h"
 
 namespace pds_mlp_detail {
@@ -75,6 +77,46 @@ namespace pds_mlp_detail {
 #ifndef PDS_MLP_STRIPS
 #define PDS_MLP_STRIPS 1  // round 4, ppo_split_kernel: rows / columns 48..51 of dW2, rows 48..51 of dW1 and the whole dW3 as 4x4x1 strips; A/B: 0
 #endif
+#ifndef PDS_SPLIT_BF16
+#define PDS_SPLIT_BF16 1  // round 6, ppo_split_kernel: the weight-gradient role's three GEMMs (dZ1, dW2, dW1) as split-bf16 MFMAs; A/B: 0 = f32 MFMAs
+#endif
+// ---- split-bf16 operands (round 6) ------------------------------------------------------------------------------
+// x = hi + mid + lo, three bf16 pieces (round to nearest even; the residuals x - hi and (x - hi) - mid are exact in f32), and
+// the six products hi hi, hi mid, mid hi, hi lo, lo hi, mid mid on v_mfma_f32_16x16x32_bf16 (16 cycles per K = 32 against
+// 8 x 32 for v_mfma_f32_16x16x4_f32): products exact, one f32 rounding per 32 terms -- max error / sum |products| 2^-24.5 ..
+// 2^-23.1, below the f32 MFMA's own 2^-22.6 .. 2^-21.8 (profiles/r06_split_bf16.txt).  4.5 vector instructions per element.
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_ __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x2_ __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {  // v_cvt_pk_bf16_f32: low half a, high half b
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_){a, b}, bf16x2_));
+}
+struct Quad3 { u32x2_ hi, mid, lo; };  // four values in three pieces, two dwords per piece
+__device__ __forceinline__ Quad3 split4(const f32x4 x) {
+  Quad3 s;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const uint32_t h = pk_bf16(x[2 * p], x[2 * p + 1]);
+    const float r0 = x[2 * p] - __uint_as_float(h << 16), r1 = x[2 * p + 1] - __uint_as_float(h & 0xFFFF0000u);
+    const uint32_t m = pk_bf16(r0, r1);
+    s.hi[p] = h;
+    s.mid[p] = m;
+    s.lo[p] = pk_bf16(r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xFFFF0000u));
+  }
+  return s;
+}
+// the 8 k-slots of a lane: slots 0..3 = `a`, slots 4..7 = `b`
+__device__ __forceinline__ bf16x8_ cat8(const u32x2_ a, const u32x2_ b) {
+  const u32x4_ v = {a[0], a[1], b[0], b[1]};
+  return __builtin_bit_cast(bf16x8_, v);
+}
+#define PDS_MFMA_BF(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+// C += A B over the 8 k-slots of every lane group, A = (a0 | a1), B = (b0 | b1) in three pieces each: the six products, smallest first
+struct Oct3 { bf16x8_ hi, mid, lo; };
+__device__ __forceinline__ Oct3 oct3(const Quad3 &a, const Quad3 &b) { return Oct3{cat8(a.hi, b.hi), cat8(a.mid, b.mid), cat8(a.lo, b.lo)}; }
+
 #if PDS_SPLIT_DEBUG == 3  // profiling: the forward role WITHOUT its MFMAs -- operands stay alive, no instruction is
                            // issued: what the rest of its instruction stream costs the pair (results invalid)
 typedef float pds_f32x4_ __attribute__((ext_vector_type(4)));
@@ -658,7 +700,7 @@ __device__ __forceinline__ f32x4 edge_pair(const float *wp, const f32x4 (&in)[NK
 
 // NG = 2 (not the default: slower, see PDS_MLP_SPLIT): the weight-gradient role split once more -- G1 (waves 4-7: dZ1,
 // dW1), G2 (waves 8-11: dW2) -- three waves per SIMD (12 per block, <= 168 registers each).
-template <int KJI, int NG>
+template <int KJI, int NG, bool BFP = false>
 __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const Args a) {
   constexpr int NIN = 3, KJH = 2, ACT = 0;
   constexpr int kThreads = (1 + NG) * 256;
@@ -726,6 +768,7 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
   // per tile.  The full tiles cover rows / columns 0..47.  dW3 (4 x 50) is one such strip on F's side (gW3s).
   constexpr bool STRIP = PDS_MLP_STRIPS != 0 && NG == 1;
   constexpr int NTF = STRIP ? kNT - 1 : kNT;  // full 16-wide tiles per hidden dimension
+  constexpr bool BF = BFP && PDS_SPLIT_BF16 != 0 && STRIP;  // the weight-gradient role's full-tile GEMMs on v_mfma_f32_16x16x32_bf16 (three pieces per operand)
   f32x4 gW2r = (f32x4)(0.f), gW2c = (f32x4)(0.f), gW1r = (f32x4)(0.f), gW3s = (f32x4)(0.f), gW3s2 = (f32x4)(0.f);
   const int lc = lane < kSI ? lane : kSI - 1;  // column of a 52-wide image row (lanes 52..63: clamped, their results are dropped)
 
@@ -758,13 +801,34 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
     __builtin_amdgcn_s_setprio(PDS_SPLIT_GPRIO);
     float *dZ1img = privg + pair * kPrivGFloats;
     float wz1[kNT][4][kNT - 1];  // W2^T read column-wise: tile invariant, kept in registers
+    // BF (PDS_SPLIT_BF16): the same operand for the K = 32 instruction, in three bf16 pieces.  The k index of an MFMA is a dummy
+    // index, so its slots can be assigned freely as long as A and B agree: slot (lane group h, i) of step ks carries h2 feature
+    // 16 (2 ks) + 4 h + i for i < 4 and 16 (2 ks + 1) + 4 h + (i - 4) for i >= 4 -- the B operand is then the lane's own dZ2
+    // registers of two feature tiles (the C/D layout), exactly as in the f32 form; no cross-lane movement.
+    // Tile invariant, kept in registers like wz1 (72 instead of 48; an LDS image of it would be 18 KB the block does not have).
+    Oct3 wzb[2][kNT - 1];
+    if constexpr (BF) {
 #pragma unroll
-    for (int kt = 0; kt < kNT; ++kt)
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+        for (int jt = 0; jt < kNT - 1; ++jt) {
+          f32x4 w0, w1;
 #pragma unroll
-        for (int jt = 0; jt < kNT - 1; ++jt)
-          wz1[kt][j][jt] = (kt < kNT - 1 || j < KJH) ? W2s[(kt * kTW + 4 * h + j) * kS + jt * kTW + r] : 0.f;
+          for (int q = 0; q < 4; ++q) {
+            w0[q] = W2s[(32 * ks + 4 * h + q) * kS + jt * kTW + r];
+            w1[q] = W2s[(32 * ks + 16 + 4 * h + q) * kS + jt * kTW + r];
+          }
+          wzb[ks][jt] = oct3(split4(w0), split4(w1));
+        }
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < kNT; ++kt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int jt = 0; jt < kNT - 1; ++jt)
+            wz1[kt][j][jt] = (kt < kNT - 1 || j < KJH) ? W2s[(kt * kTW + 4 * h + j) * kS + jt * kTW + r] : 0.f;
+    }
     const int r3 = min(r, 3);
     int k = 0;
     for (long long t = pid; t < ntiles; t += np, ++k) {
@@ -786,18 +850,71 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
         for (int q = 0; q < 4; ++q) we[kt][q] = *reinterpret_cast<const float2 *>(W2s + (kt * kTW + 4 * g + q) * kS + 48);
       // ---- dZ1^T = (W2^T dZ2^T) * act'(H1^T): three chains ----
       f32x4 cc[kNT];
+      if constexpr (BF) {
+        Oct3 bz[2];
+        bz[0] = oct3(split4(dz2[0]), split4(dz2[1]));
+        bz[1] = oct3(split4(dz2[2]), split4(dz2[3]));
 #pragma unroll
-      for (int kt = 0; kt < kNT; ++kt)
+        for (int jt = 0; jt < kNT - 1; ++jt) cc[jt] = (f32x4)(0.f);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int ks = 0; ks < 2; ++ks) {  // six products per step, smallest first; the three chains alternate
 #pragma unroll
-          for (int jt = 0; jt < kNT - 1; ++jt)
-            if (kt < kNT - 1 || j < KJH)
-              cc[jt] = PDS_MFMA(wz1[kt][j][jt], dz2[kt][j], (kt == 0 && j == 0) ? (f32x4)(0.f) : cc[jt]);
+          for (int jt = 0; jt < kNT - 1; ++jt) cc[jt] = PDS_MFMA_BF(wzb[ks][jt].mid, bz[ks].mid, cc[jt]);
+#pragma unroll
+          for (int jt = 0; jt < kNT - 1; ++jt) cc[jt] = PDS_MFMA_BF(wzb[ks][jt].hi, bz[ks].lo, cc[jt]);
+#pragma unroll
+          for (int jt = 0; jt < kNT - 1; ++jt) cc[jt] = PDS_MFMA_BF(wzb[ks][jt].lo, bz[ks].hi, cc[jt]);
+#pragma unroll
+          for (int jt = 0; jt < kNT - 1; ++jt) cc[jt] = PDS_MFMA_BF(wzb[ks][jt].hi, bz[ks].mid, cc[jt]);
+#pragma unroll
+          for (int jt = 0; jt < kNT - 1; ++jt) cc[jt] = PDS_MFMA_BF(wzb[ks][jt].mid, bz[ks].hi, cc[jt]);
+#pragma unroll
+          for (int jt = 0; jt < kNT - 1; ++jt) cc[jt] = PDS_MFMA_BF(wzb[ks][jt].hi, bz[ks].hi, cc[jt]);
+        }
+      } else {
+#pragma unroll
+        for (int kt = 0; kt < kNT; ++kt)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int jt = 0; jt < kNT - 1; ++jt)
+              if (kt < kNT - 1 || j < KJH)
+                cc[jt] = PDS_MFMA(wz1[kt][j][jt], dz2[kt][j], (kt == 0 && j == 0) ? (f32x4)(0.f) : cc[jt]);
+      }
       PDS_SSTAMP(1, 2);
       // ---- dW2 += dZ2^T H1 (covers the result latency of dZ1; G2's job when there is one) ----
+      // BF: K = the tile's 16 samples x TWO piece combinations -- slot (h, i < 4) = sample 4 h + i with pieces (a, b), slot
+      // (h, i >= 4) = the same sample with pieces (a', b'): (hi hi | hi mid), (mid hi | hi lo), (lo hi | mid mid) are the six
+      // products in three instructions.  Operands: the same four dword reads per lane and 16 x 16 block as the f32 form
+      // (samples 4 h .. 4 h + 3 of one feature), split in registers.
+      if constexpr (BF) {
+        Quad3 qa[NTF], qb[NTF];
 #pragma unroll
-      for (int j = 0; j < (NG == 1 ? 4 : 0); ++j) {
+        for (int i = 0; i < NTF; ++i) {
+          f32x4 va, vb;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            va[j] = dZ2img[(4 * h + j) * kSI + i * kTW + r];
+            vb[j] = H1img[(4 * h + j) * kSI + i * kTW + n];
+          }
+          qa[i] = split4(va);
+          qb[i] = split4(vb);
+        }
+#pragma unroll
+        for (int it = 0; it < NTF; ++it)
+#pragma unroll
+          for (int jt = 0; jt < NTF; ++jt) gW2[it][jt] = PDS_MFMA_BF(cat8(qa[it].lo, qa[it].mid), cat8(qb[jt].hi, qb[jt].mid), gW2[it][jt]);
+#pragma unroll
+        for (int it = 0; it < NTF; ++it)
+#pragma unroll
+          for (int jt = 0; jt < NTF; ++jt) gW2[it][jt] = PDS_MFMA_BF(cat8(qa[it].mid, qa[it].hi), cat8(qb[jt].hi, qb[jt].lo), gW2[it][jt]);
+#pragma unroll
+        for (int it = 0; it < NTF; ++it)
+#pragma unroll
+          for (int jt = 0; jt < NTF; ++jt) gW2[it][jt] = PDS_MFMA_BF(cat8(qa[it].hi, qa[it].hi), cat8(qb[jt].hi, qb[jt].mid), gW2[it][jt]);
+      }
+#pragma unroll
+      for (int j = 0; j < ((NG == 1 && !BF) ? 4 : 0); ++j) {
         float av[kNT], bv[kNT];
         const int row = (4 * h + j) * kSI;
 #pragma unroll
@@ -842,8 +959,37 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
       }
       PDS_WAVE_SYNC();
       PDS_SSTAMP(1, 4);
+      if constexpr (BF) {  // dW1 += dZ1^T X, as dW2 above
+        Quad3 qa[NTF], qb[NIN];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {  // dW1 += dZ1^T X
+        for (int i = 0; i < NTF; ++i) {
+          f32x4 va;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) va[j] = dZ1img[(4 * h + j) * kSI + i * kTW + r];
+          qa[i] = split4(va);
+        }
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) {
+          f32x4 vb;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) vb[j] = Ximg[(4 * h + j) * kSI + i * kTW + n];
+          qb[i] = split4(vb);
+        }
+#pragma unroll
+        for (int it = 0; it < NTF; ++it)
+#pragma unroll
+          for (int kt = 0; kt < NIN; ++kt) gW1[it][kt] = PDS_MFMA_BF(cat8(qa[it].lo, qa[it].mid), cat8(qb[kt].hi, qb[kt].mid), gW1[it][kt]);
+#pragma unroll
+        for (int it = 0; it < NTF; ++it)
+#pragma unroll
+          for (int kt = 0; kt < NIN; ++kt) gW1[it][kt] = PDS_MFMA_BF(cat8(qa[it].mid, qa[it].hi), cat8(qb[kt].hi, qb[kt].lo), gW1[it][kt]);
+#pragma unroll
+        for (int it = 0; it < NTF; ++it)
+#pragma unroll
+          for (int kt = 0; kt < NIN; ++kt) gW1[it][kt] = PDS_MFMA_BF(cat8(qa[it].hi, qa[it].hi), cat8(qb[kt].hi, qb[kt].mid), gW1[it][kt]);
+      }
+#pragma unroll
+      for (int j = 0; j < (BF ? 0 : 4); ++j) {  // dW1 += dZ1^T X
         float av[kNT], bv[NIN];
         const int row = (4 * h + j) * kSI;
 #pragma unroll
@@ -1398,8 +1544,16 @@ static int launch_grad(int loss, Args &a, float *d_grads, float *d_stats, float 
     blocks = (int)((tiles + kPairs - 1) / kPairs < kMaxGridBlocks ? (tiles + kPairs - 1) / kPairs : kMaxGridBlocks);
     const dim3 gs(blocks);
     const dim3 bs((1 + PDS_MLP_SPLIT) * 256);  // PDS_MLP_SPLIT = number of weight-gradient roles
-    if (two_input_steps(a.m)) hipLaunchKernelGGL((ppo_split_kernel<2, PDS_MLP_SPLIT>), gs, bs, 0, s, a);
-    else hipLaunchKernelGGL((ppo_split_kernel<4, PDS_MLP_SPLIT>), gs, bs, 0, s, a);
+    // the split-bf16 form of the weight-gradient role wins where a wave pair streams many tiles (its per-tile LATENCY is longer:
+    // the splits sit in front of the MFMAs), the f32 form below ~10 tiles per pair (measured crossover: 131 072 .. 196 608 samples, profiles/r06_bf16_threshold.txt)
+    static const long long bf16_min = [] { const char *e = getenv("PDS_BF16_MIN_SAMPLES"); return e ? atoll(e) : 163840ll; }();
+    if (PDS_SPLIT_BF16 && a.B >= bf16_min) {
+      if (two_input_steps(a.m)) hipLaunchKernelGGL((ppo_split_kernel<2, PDS_MLP_SPLIT, true>), gs, bs, 0, s, a);
+      else hipLaunchKernelGGL((ppo_split_kernel<4, PDS_MLP_SPLIT, true>), gs, bs, 0, s, a);
+    } else {
+      if (two_input_steps(a.m)) hipLaunchKernelGGL((ppo_split_kernel<2, PDS_MLP_SPLIT>), gs, bs, 0, s, a);
+      else hipLaunchKernelGGL((ppo_split_kernel<4, PDS_MLP_SPLIT>), gs, bs, 0, s, a);
+    }
   } else if (loss == LOSS_PPO && a.m.activation == 0 && !gb && !wide && two_hidden_steps(a.m)) {
     if (two_input_steps(a.m)) hipLaunchKernelGGL((mlp_kernel<LOSS_PPO, 0, 1, false, 2, 2>), g, b, 0, s, a);
     else hipLaunchKernelGGL((mlp_kernel<LOSS_PPO, 0, 1, false, 4, 2>), g, b, 0, s, a);

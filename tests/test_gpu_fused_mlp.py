@@ -40,7 +40,10 @@ def test_forward_matches_torch(d_in, h1, h2, d_out, act, B):
                                           (48, 50, "relu", 777), (64, 33, "tanh", 1500), (17, 16, "relu", 100),
                                           # round 6: the K-tiled kernels (64 < d_in <= 192)
                                           (68, 50, "relu", 5000), (80, 32, "relu", 31), (136, 64, "relu", 2048 + 5),
-                                          (160, 48, "tanh", 777), (192, 64, "relu", 1500), (120, 64, "relu", 70001)])
+                                          (160, 48, "tanh", 777), (192, 64, "relu", 1500), (120, 64, "relu", 70001),
+                                          # round 6: batches of the size at which ppo_split_kernel runs its weight-gradient role on
+                                          # split-bf16 MFMAs (>= 163 840 samples; both input-step forms, a ragged last tile)
+                                          (34, 50, "relu", 200003), (42, 50, "relu", 163840), (48, 50, "relu", 300017)])
 def test_ppo_policy_grad_matches_autograd(d_in, h, act, B):
     from phoenix_drone_simulation_amd.fused import FusedMLP
     A, clip = (6 if d_in == 17 else 4), 0.2  # 6 outputs: the log-prob sum spans two lane groups
@@ -401,3 +404,53 @@ def test_permutation_equals_its_documented_algorithm(n, seed, call):
     from phoenix_drone_simulation_amd.fused import random_permutation
     got = random_permutation(n, seed, call, "cuda").cpu().numpy()
     assert np.array_equal(got, _feistel_permutation_numpy(n, seed, call))
+
+
+_FORMS_CHILD = r"""
+import math, sys, torch
+sys.path.insert(0, sys.argv[1])
+from phoenix_drone_simulation_amd.fused import FusedMLP
+from phoenix_drone_simulation_amd.ppo import _mlp
+B, D, H, A = 262144, 34, 50, 4
+torch.manual_seed(3)
+net = _mlp([D, H, H, A], "relu").cuda(); fm = FusedMLP(net, "relu")
+x = torch.randn(B, D, device="cuda"); log_std = torch.full((A,), math.log(0.3), device="cuda")
+with torch.no_grad():
+    mu0 = net(x); act = mu0 + torch.exp(log_std) * torch.randn(B, A, device="cuda")
+    lp = torch.distributions.Normal(mu0, torch.exp(log_std)).log_prob(act).sum(-1) + 0.3 * torch.randn(B, device="cuda")
+adv = torch.randn(B, device="cuda")
+fm.ppo_grad(x, act, adv, lp, log_std, 50.0); got = fm.flat_grad.double().clone()  # (clip range never reached)
+net64 = _mlp([D, H, H, A], "relu").cuda().double(); net64.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
+d = torch.distributions.Normal(net64(x.double()), torch.exp(log_std.double()))
+r = torch.exp(d.log_prob(act.double()).sum(-1) - lp.double())
+(-(torch.min(r * adv.double(), adv.double() * torch.clamp(r, -49.0, 51.0))).mean()).backward()
+want = torch.cat([p.grad.reshape(-1) for p in net64.parameters()])
+torch.save(got.cpu(), sys.argv[2])
+print("ERR", float(want.abs().max()), float(((got - want) ** 2).sum().sqrt() / (want ** 2).sum().sqrt()))
+"""
+
+
+def test_split_bf16_weight_gradient_role_is_no_less_accurate_than_the_f32_form(tmp_path):
+    """ppo_split_kernel's weight-gradient role (dZ1, dW2, dW1) runs on v_mfma_f32_16x16x32_bf16 with every operand in three bf16
+    pieces (six products: exact, one f32 rounding per 32 terms) from 163 840 samples on, on v_mfma_f32_16x16x4_f32 below
+    (csrc/pds_mlp.hip, PDS_SPLIT_BF16).  The same 262 144-sample policy gradient through both forms (PDS_BF16_MIN_SAMPLES, read
+    once per process: two child processes): they are different kernels (the results differ), agree with each other to 2e-6 of
+    the largest gradient entry, and against float64 autograd the bf16 form's relative error is not larger than the f32 form's
+    (both ~1e-3 in the L2 norm -- dominated by relu branches that f32 and f64 pre-activations take differently near 0 -- and
+    equal to 8 digits: 0.00093578244 vs 0.00093578991 when measured)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    errs, grads = {}, {}
+    for name, thr in (("bf16", "0"), ("f32", "99999999999")):
+        out = str(tmp_path / (name + ".pt"))
+        r = subprocess.run([sys.executable, "-c", _FORMS_CHILD, root, out], env=dict(os.environ, PDS_BF16_MIN_SAMPLES=thr), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("ERR")][0].split()
+        errs[name] = (float(line[1]), float(line[2]))
+        grads[name] = torch.load(out)
+    (scale, rb), (_, rf) = errs["bf16"], errs["f32"]
+    diff = float((grads["bf16"] - grads["f32"]).abs().max())
+    assert 0.0 < diff <= 2e-6 * scale, (diff, scale, errs)
+    assert rb <= rf * (1.0 + 1e-4), errs
