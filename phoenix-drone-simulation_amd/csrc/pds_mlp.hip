@@ -77,6 +77,9 @@ namespace pds_mlp_detail {
 #ifndef PDS_MLP_STRIPS
 #define PDS_MLP_STRIPS 1  // round 4, ppo_split_kernel: rows / columns 48..51 of dW2, rows 48..51 of dW1 and the whole dW3 as 4x4x1 strips; A/B: 0
 #endif
+#ifndef PDS_SPLIT_BF16_L2
+#define PDS_SPLIT_BF16_L2 1  // the forward role's layer 2 on the bf16 instruction too (its A operand in pieces stays in registers, layer 1's then comes from LDS); A/B: 0
+#endif
 #ifndef PDS_SPLIT_BF16
 #define PDS_SPLIT_BF16 1  // round 6, ppo_split_kernel: the weight-gradient role's three GEMMs (dZ1, dW2, dW1) as split-bf16 MFMAs; A/B: 0 = f32 MFMAs
 #endif
@@ -1044,6 +1047,15 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
       a3[kt] = lds4(w3p + kt * kTW);
     }
 #endif
+#if PDS_SPLIT_BF16_L2 && PDS_SPLIT_WRES  // A/B: layer 2 of the forward role on the bf16 instruction as well (k-slots as in G's dZ1)
+    Oct3 a2b[kNT - 1][2];
+    if constexpr (BF) {
+#pragma unroll
+      for (int it = 0; it < kNT - 1; ++it)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) a2b[it][ks] = oct3(split4(a2[it][2 * ks]), split4(a2[it][2 * ks + 1]));
+    }
+#endif
     f32x4 xraw[NIN];
     load_x(pid, xraw);
     int k = 0;
@@ -1101,13 +1113,22 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
       f32x4 h1r[kNT], h2r[kNT], cc[kNT];
 #pragma unroll
       for (int it = 0; it < kNT - 1; ++it) cc[it] = lds4(b1s + it * kTW + 4 * g);
+#if PDS_SPLIT_BF16_L2 && PDS_SPLIT_WRES  // (layer 2's operand is 72 registers in pieces: layer 1's then comes from LDS per tile, 9 b128 reads)
+      f32x4 a1t[kNT - 1][NIN];
+#pragma unroll
+      for (int kt = 0; kt < NIN; ++kt)
+#pragma unroll
+        for (int it = 0; it < kNT - 1; ++it) a1t[it][kt] = BF ? lds4(w1p + it * kTW * kS + kt * kTW) : a1[it][kt];
+#else
+      f32x4 (&a1t)[kNT - 1][NIN] = a1;
+#endif
 #pragma unroll
       for (int kt = 0; kt < NIN; ++kt)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int it = 0; it < kNT - 1; ++it)
-            if (kt < NIN - 1 || j < KJI) cc[it] = PDS_MFMA_F(a1[it][kt][j], xin[kt][j], cc[it]);
+            if (kt < NIN - 1 || j < KJI) cc[it] = PDS_MFMA_F(a1t[it][kt][j], xin[kt][j], cc[it]);
       PDS_FPRIO_VALU();
       PDS_SSTAMP(0, 2);
       load_x(t + np, xraw);  // the next tile's rows: in flight during the rest of this tile
@@ -1131,6 +1152,29 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
       // ---- layer 2 ----
 #pragma unroll
       for (int it = 0; it < kNT - 1; ++it) cc[it] = lds4(b2s + it * kTW + 4 * g);
+#if PDS_SPLIT_BF16_L2 && PDS_SPLIT_WRES
+      if constexpr (BF) {
+        Oct3 bh[2];
+        bh[0] = oct3(split4(h1r[0]), split4(h1r[1]));
+        bh[1] = oct3(split4(h1r[2]), split4(h1r[3]));
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+          for (int it = 0; it < kNT - 1; ++it) cc[it] = PDS_MFMA_BF(a2b[it][ks].mid, bh[ks].mid, cc[it]);
+#pragma unroll
+          for (int it = 0; it < kNT - 1; ++it) cc[it] = PDS_MFMA_BF(a2b[it][ks].hi, bh[ks].lo, cc[it]);
+#pragma unroll
+          for (int it = 0; it < kNT - 1; ++it) cc[it] = PDS_MFMA_BF(a2b[it][ks].lo, bh[ks].hi, cc[it]);
+#pragma unroll
+          for (int it = 0; it < kNT - 1; ++it) cc[it] = PDS_MFMA_BF(a2b[it][ks].hi, bh[ks].mid, cc[it]);
+#pragma unroll
+          for (int it = 0; it < kNT - 1; ++it) cc[it] = PDS_MFMA_BF(a2b[it][ks].mid, bh[ks].hi, cc[it]);
+#pragma unroll
+          for (int it = 0; it < kNT - 1; ++it) cc[it] = PDS_MFMA_BF(a2b[it][ks].hi, bh[ks].hi, cc[it]);
+        }
+      } else
+#endif
+      {
 #pragma unroll
       for (int kt = 0; kt < kNT; ++kt)
 #pragma unroll
@@ -1138,6 +1182,7 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
 #pragma unroll
           for (int it = 0; it < kNT - 1; ++it)
             if (kt < kNT - 1 || j < KJH) cc[it] = PDS_MFMA_F(a2[it][kt][j], h1r[kt][j], cc[it]);
+      }
       PDS_FPRIO_VALU();
       PDS_SSTAMP(0, 4);
       cc[kNT - 1] = edge_pair<kNT>(e2p, h1r, b2s + 48, g);
@@ -1545,8 +1590,8 @@ static int launch_grad(int loss, Args &a, float *d_grads, float *d_stats, float 
     const dim3 gs(blocks);
     const dim3 bs((1 + PDS_MLP_SPLIT) * 256);  // PDS_MLP_SPLIT = number of weight-gradient roles
     // the split-bf16 form of the weight-gradient role wins where a wave pair streams many tiles (its per-tile LATENCY is longer:
-    // the splits sit in front of the MFMAs), the f32 form below ~10 tiles per pair (measured crossover: 131 072 .. 196 608 samples, profiles/r06_bf16_threshold.txt)
-    static const long long bf16_min = [] { const char *e = getenv("PDS_BF16_MIN_SAMPLES"); return e ? atoll(e) : 163840ll; }();
+    // the splits sit in front of the MFMAs), the f32 form below ~4 tiles per pair (measured crossover: 32 000 .. 65 536 samples, profiles/r06_bf16_threshold.txt)
+    static const long long bf16_min = [] { const char *e = getenv("PDS_BF16_MIN_SAMPLES"); return e ? atoll(e) : 65536ll; }();
     if (PDS_SPLIT_BF16 && a.B >= bf16_min) {
       if (two_input_steps(a.m)) hipLaunchKernelGGL((ppo_split_kernel<2, PDS_MLP_SPLIT, true>), gs, bs, 0, s, a);
       else hipLaunchKernelGGL((ppo_split_kernel<4, PDS_MLP_SPLIT, true>), gs, bs, 0, s, a);
