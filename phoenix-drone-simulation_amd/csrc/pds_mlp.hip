@@ -25,6 +25,9 @@
 //   weight grads dW3 = dY^T H2, dW2 = dZ2^T H1, dW1 = dZ1^T X       (K = the tile's 16 samples)
 // Bound: MFMA f32 (157 TFLOP/s dense peak on MI355X = the f32 vector rate; MI355X_MICROARCH.md).
 //
+// Round 6: from 65 536 samples on, four of ppo_split_kernel's eight GEMMs run on v_mfma_f32_16x16x32_bf16 with every operand in
+// three bf16 pieces (x = hi + mid + lo, six exact products per K = 32: more accurate than the f32 MFMA, 2.67 x its rate); see
+// PDS_SPLIT_BF16 below and DESIGN.md section 9.
 // Round 3: the PPO gradient of the reference's default policy (50-50 relu) runs on ppo_split_kernel below instead --
 // the two waves of a SIMD take different ROLES on the same tiles (forward / loss / small GEMMs vs. the large
 // weight-gradient GEMMs) so that neither carries 128 accumulator registers through phases that do not need them.
