@@ -86,43 +86,6 @@ namespace pds_mlp_detail {
 #ifndef PDS_SPLIT_BF16
 #define PDS_SPLIT_BF16 1  // round 6, ppo_split_kernel: the weight-gradient role's three GEMMs (dZ1, dW2, dW1) as split-bf16 MFMAs; A/B: 0 = f32 MFMAs
 #endif
-// ---- split-bf16 operands (round 6) ------------------------------------------------------------------------------
-// x = hi + mid + lo, three bf16 pieces (round to nearest even; the residuals x - hi and (x - hi) - mid are exact in f32), and
-// the six products hi hi, hi mid, mid hi, hi lo, lo hi, mid mid on v_mfma_f32_16x16x32_bf16 (16 cycles per K = 32 against
-// 8 x 32 for v_mfma_f32_16x16x4_f32): products exact, one f32 rounding per 32 terms -- max error / sum |products| 2^-24.5 ..
-// 2^-23.1, below the f32 MFMA's own 2^-22.6 .. 2^-21.8 (profiles/r06_split_bf16.txt).  4.5 vector instructions per element.
-typedef float f32x2_ __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8_ __attribute__((ext_vector_type(8)));
-typedef uint32_t u32x2_ __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {  // v_cvt_pk_bf16_f32: low half a, high half b
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_){a, b}, bf16x2_));
-}
-struct Quad3 { u32x2_ hi, mid, lo; };  // four values in three pieces, two dwords per piece
-__device__ __forceinline__ Quad3 split4(const f32x4 x) {
-  Quad3 s;
-#pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const uint32_t h = pk_bf16(x[2 * p], x[2 * p + 1]);
-    const float r0 = x[2 * p] - __uint_as_float(h << 16), r1 = x[2 * p + 1] - __uint_as_float(h & 0xFFFF0000u);
-    const uint32_t m = pk_bf16(r0, r1);
-    s.hi[p] = h;
-    s.mid[p] = m;
-    s.lo[p] = pk_bf16(r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xFFFF0000u));
-  }
-  return s;
-}
-// the 8 k-slots of a lane: slots 0..3 = `a`, slots 4..7 = `b`
-__device__ __forceinline__ bf16x8_ cat8(const u32x2_ a, const u32x2_ b) {
-  const u32x4_ v = {a[0], a[1], b[0], b[1]};
-  return __builtin_bit_cast(bf16x8_, v);
-}
-#define PDS_MFMA_BF(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
-// C += A B over the 8 k-slots of every lane group, A = (a0 | a1), B = (b0 | b1) in three pieces each: the six products, smallest first
-struct Oct3 { bf16x8_ hi, mid, lo; };
-__device__ __forceinline__ Oct3 oct3(const Quad3 &a, const Quad3 &b) { return Oct3{cat8(a.hi, b.hi), cat8(a.mid, b.mid), cat8(a.lo, b.lo)}; }
-
 #if PDS_SPLIT_DEBUG == 3  // profiling: the forward role WITHOUT its MFMAs -- operands stay alive, no instruction is
                            // issued: what the rest of its instruction stream costs the pair (results invalid)
 typedef float pds_f32x4_ __attribute__((ext_vector_type(4)));

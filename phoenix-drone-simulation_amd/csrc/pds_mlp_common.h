@@ -82,6 +82,43 @@ __host__ __device__ inline Offsets offsets(const pds_mlp &m) {
 __device__ __forceinline__ f32x4 lds4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 __device__ __forceinline__ void sts4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
 
+// ---- split-bf16 operands (round 6) ------------------------------------------------------------------------------
+// x = hi + mid + lo, three bf16 pieces (round to nearest even; the residuals x - hi and (x - hi) - mid are exact in f32), and
+// the six products hi hi, hi mid, mid hi, hi lo, lo hi, mid mid on v_mfma_f32_16x16x32_bf16 (16 cycles per K = 32 against
+// 8 x 32 for v_mfma_f32_16x16x4_f32): products exact, one f32 rounding per 32 terms -- max error / sum |products| 2^-24.5 ..
+// 2^-23.1, below the f32 MFMA's own 2^-22.6 .. 2^-21.8 (profiles/r06_split_bf16.txt).  4.5 vector instructions per element.
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_ __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x2_ __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {  // v_cvt_pk_bf16_f32: low half a, high half b
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_){a, b}, bf16x2_));
+}
+struct Quad3 { u32x2_ hi, mid, lo; };  // four values in three pieces, two dwords per piece
+__device__ __forceinline__ Quad3 split4(const f32x4 x) {
+  Quad3 s;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const uint32_t h = pk_bf16(x[2 * p], x[2 * p + 1]);
+    const float r0 = x[2 * p] - __uint_as_float(h << 16), r1 = x[2 * p + 1] - __uint_as_float(h & 0xFFFF0000u);
+    const uint32_t m = pk_bf16(r0, r1);
+    s.hi[p] = h;
+    s.mid[p] = m;
+    s.lo[p] = pk_bf16(r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xFFFF0000u));
+  }
+  return s;
+}
+// the 8 k-slots of a lane: slots 0..3 = `a`, slots 4..7 = `b`
+__device__ __forceinline__ bf16x8_ cat8(const u32x2_ a, const u32x2_ b) {
+  const u32x4_ v = {a[0], a[1], b[0], b[1]};
+  return __builtin_bit_cast(bf16x8_, v);
+}
+#define PDS_MFMA_BF(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+// C += A B over the 8 k-slots of every lane group, A = (a0 | a1), B = (b0 | b1) in three pieces each: the six products, smallest first
+struct Oct3 { bf16x8_ hi, mid, lo; };
+__device__ __forceinline__ Oct3 oct3(const Quad3 &a, const Quad3 &b) { return Oct3{cat8(a.hi, b.hi), cat8(a.mid, b.mid), cat8(a.lo, b.lo)}; }
+
 // csrc/pds_mlp_wide.hip: launches mlp_wide_kernel<loss, activation, input tiles> on `s`; returns the number of partials
 // (one per wave of the grid) that the reduce kernel has to sum (gradient calls)
 int launch_wide(int loss, const Args &a, hipStream_t s);

@@ -22,7 +22,30 @@
 // Bound: MFMA f32, as the narrow kernels.
 #include "pds_mlp_common.h"
 
+#ifndef PDS_WIDE_BF16
+#define PDS_WIDE_BF16 1  // round 6: dW2 and dW1 (K = the tile's 16 samples) on split-bf16 MFMAs, see pds_mlp_common.h / pds_mlp.hip; A/B: 0
+#endif
+
 namespace pds_mlp_detail {
+
+// C[it][jt] += A_it^T B_jt over the 16 samples of a tile, operands as three bf16 pieces of the four values (samples 4 h .. 4 h + 3
+// of one feature) a lane holds per 16 x 16 block: slot (h, i < 4) = sample 4 h + i with pieces (a, b), slot (h, i >= 4) = the
+// same sample with (a', b') -- (lo | mid)(hi | mid), (mid | hi)(hi | lo), (hi | hi)(hi | mid) are the six products.
+template <int NA, int NB, class Acc>
+__device__ __forceinline__ void outer_bf16(const Quad3 (&qa)[NA], const Quad3 (&qb)[NB], Acc &&acc) {
+#pragma unroll
+  for (int it = 0; it < NA; ++it)
+#pragma unroll
+    for (int jt = 0; jt < NB; ++jt) acc(it, jt) = PDS_MFMA_BF(cat8(qa[it].lo, qa[it].mid), cat8(qb[jt].hi, qb[jt].mid), acc(it, jt));
+#pragma unroll
+  for (int it = 0; it < NA; ++it)
+#pragma unroll
+    for (int jt = 0; jt < NB; ++jt) acc(it, jt) = PDS_MFMA_BF(cat8(qa[it].mid, qa[it].hi), cat8(qb[jt].hi, qb[jt].lo), acc(it, jt));
+#pragma unroll
+  for (int it = 0; it < NA; ++it)
+#pragma unroll
+    for (int jt = 0; jt < NB; ++jt) acc(it, jt) = PDS_MFMA_BF(cat8(qa[it].hi, qa[it].hi), cat8(qb[jt].hi, qb[jt].mid), acc(it, jt));
+}
 
 template <int NIN>
 constexpr int wide_stride() { return kTW * NIN + 4; }
@@ -236,8 +259,23 @@ __global__ __launch_bounds__(kWideWaves * 64, 1) void mlp_wide_kernel(const Args
 #pragma unroll
       for (int it = 0; it < kNT; ++it) sts4(H2img + n * kS + it * kTW + 4 * g, dz2[it]);  // after the dW3 reads (in order)
       PDS_WAVE_SYNC();
+      if constexpr (PDS_WIDE_BF16 != 0) {  // dW2 += dZ2^T H1
+        Quad3 qa[kNT], qb[kNT];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {  // dW2 += dZ2^T H1
+        for (int i = 0; i < kNT; ++i) {
+          f32x4 va, vb;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            va[j] = H2img[(4 * h + j) * kS + i * kTW + r];
+            vb[j] = H1img[(4 * h + j) * kS + i * kTW + n];
+          }
+          qa[i] = split4(va);
+          qb[i] = split4(vb);
+        }
+        outer_bf16<kNT, kNT>(qa, qb, [&](int it, int jt) -> f32x4 & { return gW2[it][jt]; });
+      }
+#pragma unroll
+      for (int j = 0; j < (PDS_WIDE_BF16 != 0 ? 0 : 4); ++j) {  // dW2 += dZ2^T H1
         float av[kNT], bv[kNT];
 #pragma unroll
         for (int i = 0; i < kNT; ++i) {
@@ -269,8 +307,32 @@ __global__ __launch_bounds__(kWideWaves * 64, 1) void mlp_wide_kernel(const Args
 #pragma unroll
       for (int jt = 0; jt < kNT; ++jt) sts4(H1img + n * kS + jt * kTW + 4 * g, dz1[jt]);  // after the dW2 reads
       PDS_WAVE_SYNC();
+      if constexpr (PDS_WIDE_BF16 != 0) {  // dW1 += dZ1^T X
+        Quad3 qa[kNT];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {  // dW1 += dZ1^T X
+        for (int i = 0; i < kNT; ++i) {
+          f32x4 va;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) va[j] = H1img[(4 * h + j) * kS + i * kTW + r];
+          qa[i] = split4(va);
+        }
+        // two input tiles at a time: the pieces of all NIN of them (6 registers each) next to 16 NIN accumulators do not fit 512
+        static_assert(NG1 % 2 == 0, "input tiles come in pairs");
+#pragma unroll
+        for (int k0 = 0; k0 < NG1; k0 += 2) {
+          Quad3 qb2[2];
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) {
+            f32x4 vb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) vb[j] = Ximg[(4 * h + j) * S1 + (k0 + kk) * kTW + n];
+            qb2[kk] = split4(vb);
+          }
+          outer_bf16<kNT, 2>(qa, qb2, [&](int it, int kk) -> f32x4 & { return gW1[it][k0 + kk]; });
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < (PDS_WIDE_BF16 != 0 ? 0 : 4); ++j) {  // dW1 += dZ1^T X
         float av[kNT];
 #pragma unroll
         for (int i = 0; i < kNT; ++i) av[i] = H1img[(4 * h + j) * kS + i * kTW + r];
