@@ -80,6 +80,9 @@ namespace pds_mlp_detail {
 #ifndef PDS_MLP_STRIPS
 #define PDS_MLP_STRIPS 1  // round 4, ppo_split_kernel: rows / columns 48..51 of dW2, rows 48..51 of dW1 and the whole dW3 as 4x4x1 strips; A/B: 0
 #endif
+#ifndef PDS_SPLIT_BF16_L1
+#define PDS_SPLIT_BF16_L1 1  // the forward role's layer 1 on the bf16 instruction too (W1 as an LDS image of its operand pieces, 18 KB in place of the f32 image); A/B: 0
+#endif
 #ifndef PDS_SPLIT_BF16_L2
 #define PDS_SPLIT_BF16_L2 1  // the forward role's layer 2 on the bf16 instruction too (its A operand in pieces stays in registers, layer 1's then comes from LDS); A/B: 0
 #endif
@@ -673,7 +676,11 @@ template <int KJI, int NG, bool BFP = false>
 __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const Args a) {
   constexpr int NIN = 3, KJH = 2, ACT = 0;
   constexpr int kThreads = (1 + NG) * 256;
-  __shared__ __attribute__((aligned(16))) float W1s[kW1Rows * kS];  // rows 48, 49: the vector-ALU features
+  // L1B (PDS_SPLIT_BF16_L1): layer 1 of the forward role on the bf16 instruction -- W1 as an image of its A operands in pieces
+  // ([row tile][k step][piece][lane] x 16 bytes, 18 KB) INSTEAD of the f32 image (13.6 KB), of which only rows 48, 49 remain
+  constexpr bool L1B = BFP && PDS_SPLIT_BF16 != 0 && PDS_SPLIT_BF16_L1 != 0 && PDS_SPLIT_BF16_L2 != 0 && PDS_SPLIT_WRES != 0 && PDS_MLP_STRIPS != 0 && NG == 1;
+  __shared__ __attribute__((aligned(16))) float W1s[(L1B ? 2 : kW1Rows) * kS];  // rows 48, 49: the vector-ALU features
+  __shared__ __attribute__((aligned(16))) uint32_t W1b[L1B ? (kNT - 1) * 2 * 3 * 64 * 4 : 4];
   __shared__ __attribute__((aligned(16))) float W2s[kMaxDim * kS];
   __shared__ __attribute__((aligned(16))) float W3s[kTW * kS];
   __shared__ __attribute__((aligned(16))) float b1s[kMaxDim], b2s[kMaxDim], b3s[kTW];
@@ -697,7 +704,28 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
   const int role = wave >> 2;  // 0: F, 1: G (NG = 1) or G1, 2: G2
 #endif
   const int n = lane & 15, g = lane >> 4;
-  stage_weights<kW1Rows, kThreads>(m, W1s, W2s, W3s, tid);
+  stage_weights<L1B ? 0 : kW1Rows, kThreads>(m, W1s, W2s, W3s, tid);
+  if constexpr (L1B) {
+    for (int i = tid; i < 2 * kS; i += kThreads) {
+      const int rr = 48 + i / kS, k = i % kS;
+      W1s[i] = (rr < m.h1 && k < m.d_in) ? m.w1[rr * m.d_in + k] : 0.f;
+    }
+    for (int e = tid; e < (kNT - 1) * 2 * 64; e += kThreads) {  // slot (lane group gg, i) of step ks: input feature 32 ks + 4 gg + i (i < 4), + 16 (i >= 4)
+      const int it = e >> 7, ks = (e >> 6) & 1, l = e & 63, row = 16 * it + (l & 15), gg = l >> 4;
+      f32x4 w0, w1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k0 = 32 * ks + 4 * gg + q, k1 = k0 + 16;
+        w0[q] = (row < m.h1 && k0 < m.d_in) ? m.w1[row * m.d_in + k0] : 0.f;
+        w1[q] = (row < m.h1 && k1 < m.d_in) ? m.w1[row * m.d_in + k1] : 0.f;
+      }
+      const Oct3 o3 = oct3(split4(w0), split4(w1));
+      uint32_t *dst = W1b + (((it * 2 + ks) * 3) * 64 + l) * 4;
+      *reinterpret_cast<bf16x8_ *>(dst) = o3.hi;
+      *reinterpret_cast<bf16x8_ *>(dst + 64 * 4) = o3.mid;
+      *reinterpret_cast<bf16x8_ *>(dst + 2 * 64 * 4) = o3.lo;
+    }
+  }
   if (tid < kMaxDim) {
     b1s[tid] = tid < m.h1 ? m.b1[tid] : 0.f;
     b2s[tid] = tid < m.h2 ? m.b2[tid] : 0.f;
@@ -999,13 +1027,13 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
         for (int q = 0; q < 4; ++q) raw[kt][q] = xr[min(kt * kTW + 4 * g + q, m.d_in - 1)];
     };
     const float *w1p = W1s + n * kS + 4 * g, *w2p = W2s + n * kS + 4 * g, *w3p = W3s + n * kS + 4 * g;
-    const float *e1p = W1s + 48 * kS + 4 * g, *e2p = W2s + 48 * kS + 4 * g;
+    const float *e1p = W1s + (L1B ? 0 : 48) * kS + 4 * g, *e2p = W2s + 48 * kS + 4 * g;
 #if PDS_SPLIT_WRES  // the forward GEMMs' weight operands are tile invariant: 100 registers instead of 25 b128 LDS reads per tile
     f32x4 a1[kNT - 1][NIN], a2[kNT - 1][kNT], a3[kNT];
 #pragma unroll
     for (int kt = 0; kt < NIN; ++kt)
 #pragma unroll
-      for (int it = 0; it < kNT - 1; ++it) a1[it][kt] = lds4(w1p + it * kTW * kS + kt * kTW);
+      for (int it = 0; it < kNT - 1; ++it) a1[it][kt] = L1B ? (f32x4)(0.f) : lds4(w1p + it * kTW * kS + kt * kTW);
 #pragma unroll
     for (int kt = 0; kt < kNT; ++kt) {
 #pragma unroll
@@ -1079,6 +1107,30 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
       f32x4 h1r[kNT], h2r[kNT], cc[kNT];
 #pragma unroll
       for (int it = 0; it < kNT - 1; ++it) cc[it] = lds4(b1s + it * kTW + 4 * g);
+      if constexpr (L1B) {
+        static_assert(NIN == 3, "two k steps: input tiles (0, 1) and (2, none)");
+        Oct3 bx[2];
+        bx[0] = oct3(split4(xin[0]), split4(xin[1]));
+        bx[1] = oct3(split4(xin[2]), Quad3{(u32x2_)(0u), (u32x2_)(0u), (u32x2_)(0u)});
+        auto w1b = [&](int it, int ks, int piece) -> bf16x8_ {  // piece 0 hi, 1 mid, 2 lo
+          return *reinterpret_cast<const bf16x8_ *>(W1b + (((it * 2 + ks) * 3 + piece) * 64 + lane) * 4);
+        };
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+          for (int it = 0; it < kNT - 1; ++it) cc[it] = PDS_MFMA_BF(w1b(it, ks, 1), bx[ks].mid, cc[it]);
+#pragma unroll
+          for (int it = 0; it < kNT - 1; ++it) cc[it] = PDS_MFMA_BF(w1b(it, ks, 0), bx[ks].lo, cc[it]);
+#pragma unroll
+          for (int it = 0; it < kNT - 1; ++it) cc[it] = PDS_MFMA_BF(w1b(it, ks, 2), bx[ks].hi, cc[it]);
+#pragma unroll
+          for (int it = 0; it < kNT - 1; ++it) cc[it] = PDS_MFMA_BF(w1b(it, ks, 0), bx[ks].mid, cc[it]);
+#pragma unroll
+          for (int it = 0; it < kNT - 1; ++it) cc[it] = PDS_MFMA_BF(w1b(it, ks, 1), bx[ks].hi, cc[it]);
+#pragma unroll
+          for (int it = 0; it < kNT - 1; ++it) cc[it] = PDS_MFMA_BF(w1b(it, ks, 0), bx[ks].hi, cc[it]);
+        }
+      } else {
 #if PDS_SPLIT_BF16_L2 && PDS_SPLIT_WRES  // (layer 2's operand is 72 registers in pieces: layer 1's then comes from LDS per tile, 9 b128 reads)
       f32x4 a1t[kNT - 1][NIN];
 #pragma unroll
@@ -1095,6 +1147,7 @@ __global__ __launch_bounds__((1 + NG) * 256, 1 + NG) void ppo_split_kernel(const
 #pragma unroll
           for (int it = 0; it < kNT - 1; ++it)
             if (kt < NIN - 1 || j < KJI) cc[it] = PDS_MFMA_F(a1t[it][kt][j], xin[kt][j], cc[it]);
+      }
       PDS_FPRIO_VALU();
       PDS_SSTAMP(0, 2);
       load_x(t + np, xraw);  // the next tile's rows: in flight during the rest of this tile

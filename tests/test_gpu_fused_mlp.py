@@ -432,13 +432,14 @@ print("ERR", float(want.abs().max()), float(((got - want) ** 2).sum().sqrt() / (
 
 def test_split_bf16_weight_gradient_role_is_no_less_accurate_than_the_f32_form(tmp_path):
     """ppo_split_kernel's weight-gradient role (dZ1, dW2, dW1) runs on v_mfma_f32_16x16x32_bf16 with every operand in three bf16
-    pieces (six products: exact, one f32 rounding per 32 terms) from 65 536 samples on -- and layer 2 of the forward role with it --, on v_mfma_f32_16x16x4_f32 below
+    pieces (six products: exact, one f32 rounding per 32 terms) from 65 536 samples on -- and layers 1 and 2 of the forward role with it --, on v_mfma_f32_16x16x4_f32 below
     (csrc/pds_mlp.hip, PDS_SPLIT_BF16).  The same 262 144-sample policy gradient through both forms (PDS_BF16_MIN_SAMPLES, read
-    once per process: two child processes): they are different kernels (the results differ) and agree with each other to 1e-4
-    of the largest gradient entry (measured 4.5e-5: a handful of the 26 M relu units take the other branch when layer 2's
-    pre-activations differ in the last bit -- each such sample moves an entry by O(1 / B)); against float64 autograd both forms
-    sit at a relative L2 error of 9.4e-4 (0.00093781 vs 0.00093579 -- those same branch flips of f32 against f64 dominate), bar:
-    the bf16 form within 2 % of the f32 form's."""
+    once per process: two child processes) against float64 autograd.  Measured: relative L2 error 9.4e-4 for the f32 form --
+    two or three of the 13 M layer-1 relu units take the other branch than in float64, because v_mfma_f32_16x16x4_f32 leaves
+    ~1e-7 on a pre-activation, and each such sample moves the gradient by O(1 / B) -- and 3.7e-7 for the bf16 form, whose
+    layer 1 is accurate enough to flip none on this batch (the count is a Poisson number: the bars do not rely on zero).  Bars:
+    both forms within 2e-3 of float64, the bf16 form not worse than 1.02 x the f32 form, and the two results differ (they are
+    different kernels) by no more than 2e-3 of the largest entry."""
     import os
     import subprocess
     import sys
@@ -453,5 +454,5 @@ def test_split_bf16_weight_gradient_role_is_no_less_accurate_than_the_f32_form(t
         grads[name] = torch.load(out)
     (scale, rb), (_, rf) = errs["bf16"], errs["f32"]
     diff = float((grads["bf16"] - grads["f32"]).abs().max())
-    assert 0.0 < diff <= 1e-4 * scale, (diff, scale, errs)
-    assert rb <= rf * 1.02, errs
+    assert 0.0 < diff <= 2e-3 * scale, (diff, scale, errs)
+    assert rb <= 2e-3 and rf <= 2e-3 and rb <= rf * 1.02, errs
