@@ -167,6 +167,9 @@ def test_ppo_learns_hover_end_to_end(fused):
 @pytest.mark.gpu
 @pytest.mark.parametrize("task,H,ac_kwargs", [
     ("DroneCircleSimpleEnv-v0", 2, None),
+    # round 6: 8 192 envs x 16 steps = 131 072 samples -- the size from which the policy gradient runs five of its GEMMs on split-bf16 MFMAs
+    # (csrc/pds_mlp.hip PDS_SPLIT_BF16; "big": num_envs 8 192 instead of 1 024)
+    ("DroneHoverSimpleEnv-v0", 2, "big"),
     # round 6: more than 64 network inputs (csrc/pds_mlp_wide.hip) -- the widths and layer sizes of the reference's
     # experiments/04_history_of_state_action_inputs/04_train_with_history.py:34-42 (H = 4 / 6 / 8; policy 32-32 / 48-48 / 64-64)
     ("DroneHoverSimpleEnv-v0", 4, None),
@@ -181,7 +184,9 @@ def test_fused_update_matches_the_autograd_update(task, H, ac_kwargs):
     same gradients into .grad as loss.backward() of the PyTorch path (ppo_loss / value_loss)."""
     import phoenix_drone_simulation_amd as pds
     from phoenix_drone_simulation_amd.ppo import PPOTrainer, gae, ppo_loss, value_loss
-    env = pds.make(task, num_envs=1024, seed=2, observation_history_size=H)
+    num_envs = 8192 if ac_kwargs == "big" else 1024
+    ac_kwargs = None if ac_kwargs == "big" else ac_kwargs
+    env = pds.make(task, num_envs=num_envs, seed=2, observation_history_size=H)
     assert env.obs_dim == {"DroneHoverSimpleEnv-v0": 17, "DroneCircleSimpleEnv-v0": 20, "DroneTakeOffSimpleEnv-v0": 24}[task] * H
     tr = PPOTrainer(env, rollout_len=16, epochs=4, seed=2, fused=True, ac_kwargs=ac_kwargs)
     tr.roll_out()
