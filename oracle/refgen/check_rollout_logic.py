@@ -299,6 +299,8 @@ def main():
                     help="with --full-size: run update() from the REFERENCE's rollout buffers and re-synchronise the parameters after each "
                          "epoch (Adam amplifies the rollout's 1e-6 differences over 80 iterations otherwise)")
     ap.add_argument("--epochs-run", type=int, default=0, help="with --full-size: epochs to compare (default 3)")
+    ap.add_argument("--seed", type=int, default=3, help="with --full-size: the run's seed (without --replay-buffers the two programs then run freely from the "
+                    "same start with aligned random streams: their per-epoch EpLen differ by what 80 Adam steps make of rounding, nothing else)")
     a = ap.parse_args()
     if a.full_size:
         global STEPS, MINI, V_ITERS, PI_ITERS, EPOCHS_TOTAL, SCENARIOS, REPLAY_BUFFERS
@@ -307,7 +309,7 @@ def main():
             global EPOCHS_RUN
             EPOCHS_RUN = a.epochs_run
         STEPS, MINI, V_ITERS, PI_ITERS, EPOCHS_TOTAL = 32000, 16, 5, 80, 40
-        SCENARIOS = {"limit500_full_size": (None, 3)}
+        SCENARIOS = {"limit500_full_size": (None, a.seed)}
         a.no_write = True
     torch.set_num_threads(1)
     ppo = load_ppo()
